@@ -1,0 +1,49 @@
+/*
+ * yko_main.c -- ORACLE command line (test infrastructure only): `yko count` takes the same
+ * options as `yak count` (main.c:13-64) and writes the same .yak file, using the CPU restatement.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "yko.h"
+
+static int64_t parse_num(const char *s)                      /* yak-priv.h:75-84 */
+{
+	char *p;
+	double x = strtod(s, &p);
+	if (*p == 'G' || *p == 'g') x *= 1e9;
+	else if (*p == 'M' || *p == 'm') x *= 1e6;
+	else if (*p == 'K' || *p == 'k') x *= 1e3;
+	return (int64_t)(x + .499);
+}
+
+int main(int argc, char *argv[])
+{
+	yko_copt_t opt;
+	yko_ch_t *h;
+	const char *out = 0;
+	int c;
+	if (argc < 2 || strcmp(argv[1], "count") != 0) {
+		fprintf(stderr, "Usage: yko count [-k31] [-p10] [-K chunk] [-t thr] [-b bloom_bits] [-H n_hash] [-o out.yak] <in.fa> [in2.fa]\n");
+		return 1;
+	}
+	yko_copt_init(&opt);
+	--argc; ++argv;
+	while ((c = getopt(argc, argv, "k:p:K:t:b:H:o:")) >= 0) {
+		if (c == 'k') opt.k = atoi(optarg);
+		else if (c == 'p') opt.pre = atoi(optarg);
+		else if (c == 'K') opt.chunk_size = parse_num(optarg);
+		else if (c == 't') opt.n_thread = atoi(optarg);
+		else if (c == 'b') opt.bf_shift = atoi(optarg);
+		else if (c == 'H') opt.bf_n_hash = (int)parse_num(optarg);
+		else if (c == 'o') out = optarg;
+	}
+	if (argc - optind < 1 || opt.pre < YKO_COUNTER_BITS || opt.k >= 64) return 1;   /* main.c:30-52 */
+	h = yko_count_protocol_file(argv[optind], argc - optind >= 2 ? argv[optind + 1] : 0, &opt);
+	if (h == 0) return 2;
+	fprintf(stderr, "[yko] %ld distinct k-mers\n", (long)h->tot);
+	if (out) yko_ch_dump(h, out);
+	yko_ch_destroy(h);
+	return 0;
+}
