@@ -1,0 +1,80 @@
+/*
+ * yak_amd.h -- device-level entry points of the MI355X counting engine (C ABI, plain pointers).
+ *
+ * yak.h is the drop-in surface; the functions below are what yak_count()/yak_ch_*() are built
+ * from, exported so that a harness can (a) hand over bases that are ALREADY resident in HBM,
+ * (b) time the device path without host parsing / PCIe, and (c) shard the sub-tables over several
+ * GPUs.  No torch types, no C++ types: `void *` device pointers and sizes only.
+ *
+ * Input format ("base image"): ASCII sequence bytes; every byte that is not one of
+ * A C G T U a c g t u or a raw 0..3 (reference misc.c:4-21) breaks the rolling k-mer exactly like
+ * an 'N' or a record boundary does in reference count.c:41, so sequences are simply separated by
+ * at least one such byte (e.g. '\n').
+ */
+#ifndef YAK_AMD_H
+#define YAK_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "yak.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yakamd_ctx yakamd_ctx;        /* device state behind one yak_ch_t */
+
+/* number of usable gfx950 devices (0 if none); never falls back to the CPU */
+int yakamd_device_count(void);
+/* last error message of the calling thread ("" if none) */
+const char *yakamd_last_error(void);
+
+/* engine bound to an existing table (the yak_ch_t returned by yak_ch_init) */
+yakamd_ctx *yakamd_ctx_of(yak_ch_t *h);
+/* restrict the engine to the sub-tables [lo, hi): k-mers of other prefixes are dropped at
+ * insertion (multi-GPU prefix sharding, replaces the kt_for over prefixes of count.c:133) */
+int yakamd_set_shard(yak_ch_t *h, int prefix_lo, int prefix_hi);
+
+/* One counting pass = begin, any number of feeds, end  (replaces count.c:85-166).
+ * create_new as in yak_ch_insert_list (htab.c:51).  `t0` = position of the first byte of this
+ * buffer in the logical input stream (stream order decides the table layout). */
+int yakamd_pass_begin(yak_ch_t *h, int create_new);
+int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0);
+int yakamd_feed_bases_host(yak_ch_t *h, const void *h_bases, int64_t n_bytes, uint64_t t0);
+/* already hashed k-mers (yak_hash64 output) with their stream positions t0 + t[i], t[i] < t_span;
+ * device pointers */
+int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash_u64, const void *d_t_u32, int64_t n,
+                           uint64_t t0, uint64_t t_span);
+/* returns the number of keys added to the table by this pass (-1 on error).  Like
+ * yak_ch_insert_list it does not touch h->tot: the caller adds (count.c:138) */
+int64_t yakamd_pass_end(yak_ch_t *h);
+
+/* extraction only: hashed canonical k-mers (and their positions) of a device-resident base
+ * image, for sharded exchange.  Outputs must hold n_bytes entries; returns the count or -1. */
+int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
+                           void *d_hash_u64_out, void *d_t_u32_out, void *stream);
+
+/* bring the host view (slot arrays reachable from yak_ch_t) up to date with HBM */
+int yakamd_sync_host(yak_ch_t *h);
+/* serialise the table in .yak format straight from the host view into memory (malloc'ed) */
+int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out);
+
+/* sub-table shape, for tests: capacity and size of sub-table i (device-authoritative) */
+int yakamd_subtable(yak_ch_t *h, int i, uint32_t *capacity, uint32_t *size);
+
+/* timing / traffic counters of the last pass (filled by pass_end) */
+typedef struct {
+	double ms_extract, ms_insert, ms_bloom, ms_select, ms_sort, ms_replay, ms_total;
+	double ms_dominant_kernel;      /* accumulated duration of the insert kernel launches */
+	int64_t n_dominant_launches;
+	int64_t n_instances;            /* valid k-mer windows consumed */
+	int64_t n_distinct_seen;        /* distinct k-mers observed by the pass (create_new only) */
+	int64_t n_new_keys;             /* keys that entered the table */
+	int64_t n_bloom_candidates;     /* keys that needed exact in-batch bloom resolution */
+} yakamd_stats_t;
+int yakamd_get_stats(yak_ch_t *h, yakamd_stats_t *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

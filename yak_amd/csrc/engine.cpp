@@ -1,0 +1,719 @@
+/*
+ * engine.cpp -- host orchestration of the MI355X counting engine behind yak.h.
+ *
+ * State model.  The authoritative copy of a counting table lives in HBM as an exact image of the
+ * reference's 1<<pre khashl sets (one arena of 64-bit slots + one "used" bitmap, reference
+ * khashl.h:104-109 / htab.c:9-11) together with the blocked bloom filters (bbf.c).  The slot arrays
+ * reachable from the caller-visible yak_ch_t are a host mirror that is refreshed on demand
+ * (yak_ch_dump, yak_ch_get, ...).  There is NO CPU counting path: without a usable GPU every
+ * entry point fails loudly.
+ *
+ * A counting pass (reference count.c:147-166) is: pass_begin, feed..., pass_end.  For
+ * create_new = 1 the pass accumulates, per distinct hashed k-mer, its count and the stream times
+ * of its first and second occurrence (kernels.hip K1/K3), applies the order-exact bloom gate
+ * (K2), and pass_end turns that into the reference's slot layout (select -> sort -> K5 replay).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include "yk_device.h"
+#include "engine.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	fprintf(stderr, "[E::yak_amd] %s\n", g_err);
+	return -1;
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *yakamd_last_error(void) { return g_err; }
+
+extern "C" int yakamd_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	int ok = 0;
+	for (int i = 0; i < n; ++i) {
+		hipDeviceProp_t pr;
+		if (hipGetDeviceProperties(&pr, i) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ++ok;
+	}
+	return ok;
+}
+
+static double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int64_t env_i64(const char *name, int64_t dflt)
+{
+	const char *s = getenv(name);
+	return s && *s ? atoll(s) : dflt;
+}
+
+static inline int ceil_log2_u64(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
+
+/* khashl resize target (reference khashl.h:155-158): bits for a requested slot count */
+static inline u32 kh_bits_for(u32 want)
+{
+	u32 lg = 0, x = want;
+	while ((x >>= 1) != 0) ++lg;
+	if (want & (want - 1)) ++lg;
+	return lg > 2 ? lg : 2;
+}
+
+template <class T> static int dmalloc(T **p, size_t n)
+{
+	*p = 0;
+	if (n == 0) n = 1;
+	hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+	if (e != hipSuccess) return fail("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+	return 0;
+}
+template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = 0; } }
+
+/* ------------------------------------------------------------------------------------------ */
+
+struct yakamd_ctx {
+	int k, pre, P, n_hash, bf_shift, nb;
+	bool has_bloom;
+	int dev, plo, phi;
+	hipStream_t st;
+
+	/* table image */
+	u32 *d_bits, *d_used, *d_delta;
+	u64 *d_off, *d_keys;
+	u64 n_slots;                       /* arena size (multiple of 32) */
+	std::vector<u32> h_bits, h_count;
+	std::vector<u64> h_off;
+	u64 img_keys_total;                /* sum of counts */
+
+	/* bloom */
+	u32 *d_bf; size_t bf_words;
+	u32 *d_multi; int multi_bits;
+
+	/* running pass */
+	bool in_pass; int create_new; bool bloom_mode;
+	AccTab acc; u64 acc_count;
+	u64 *d_counters, *d_lastput, *d_lpbatch;
+	u32 *d_missing, *d_nmissing;
+	u64 *d_rh; u32 *d_rt; int64_t rec_cap;
+	u64 *d_newlist, *d_miss, *d_cand; int64_t new_cap;
+	uint8_t *d_stage; int64_t stage_cap;
+	u64 t_end;
+	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
+	yakamd_stats_t st_cur, st_last;
+
+	/* host mirror */
+	bool host_valid;
+	u64 *hm_keys; u32 *hm_used; u64 hm_slots;
+	struct yak_ht_t *hts;
+};
+
+struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; u32 magic; };
+#define EXT_MAGIC 0x59414b41u
+
+static yakamd_ctx *ctx_of(const yak_ch_t *h)
+{
+	const yak_ch_ext *e = (const yak_ch_ext*)h;
+	return (h && e->magic == EXT_MAGIC) ? e->ctx : 0;
+}
+extern "C" yakamd_ctx *yakamd_ctx_of(yak_ch_t *h) { return ctx_of(h); }
+
+static ImgView img_view(yakamd_ctx *c)
+{
+	ImgView v;
+	v.bits = c->d_bits; v.off = c->d_off; v.keys = c->d_keys; v.used = c->d_used; v.delta = c->d_delta;
+	v.pre = c->pre; v.k = c->k;
+	return v;
+}
+
+static BloomView bloom_view(yakamd_ctx *c)
+{
+	BloomView b;
+	b.bits32 = c->d_bf; b.nb = c->nb; b.n_hash = c->n_hash;
+	const int nd = c->n_hash < 512 ? c->n_hash : 512;
+	b.mw = (nd + 63) / 64; if (b.mw < 1) b.mw = 1;
+	return b;
+}
+
+/* install a fresh, empty image: every sub-table has capacity 0 but owns 32 arena slots */
+static int img_reset_empty(yakamd_ctx *c)
+{
+	const int P = c->P;
+	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
+	c->n_slots = (u64)P * 32;
+	if (dmalloc(&c->d_keys, c->n_slots) || dmalloc(&c->d_used, c->n_slots / 32) || dmalloc(&c->d_delta, c->n_slots)) return -1;
+	HIPCK(hipMemsetAsync(c->d_keys, 0xff, c->n_slots * 8, c->st));
+	HIPCK(hipMemsetAsync(c->d_used, 0, c->n_slots / 8, c->st));
+	HIPCK(hipMemsetAsync(c->d_delta, 0, c->n_slots * 4, c->st));
+	c->h_bits.assign(P, YK_NOCAP); c->h_count.assign(P, 0); c->h_off.resize(P);
+	for (int p = 0; p < P; ++p) c->h_off[p] = (u64)p * 32;
+	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	c->img_keys_total = 0;
+	c->host_valid = false;
+	return 0;
+}
+
+yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
+{
+	if (yakamd_device_count() < 1) { fail("no gfx950 GPU visible: the counting engine has no CPU fallback"); return 0; }
+	yakamd_ctx *c = new yakamd_ctx();
+	memset(&c->st_cur, 0, sizeof(c->st_cur)); memset(&c->st_last, 0, sizeof(c->st_last));
+	c->k = k; c->pre = pre; c->P = 1 << pre; c->plo = 0; c->phi = c->P;
+	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
+	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
+	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0;
+	c->in_pass = false; c->acc.s = 0; c->acc_count = 0;
+	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
+	c->d_rh = 0; c->d_rt = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
+	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
+	c->host_valid = false; c->hm_keys = 0; c->hm_used = 0; c->hm_slots = 0; c->hts = 0;
+	c->dev = (int)env_i64("YAKAMD_DEVICE", 0);
+	{
+		const char *lr = getenv("LOCAL_RANK");
+		int nd = 0;
+		if (!getenv("YAKAMD_DEVICE") && lr && hipGetDeviceCount(&nd) == hipSuccess && nd > 0) c->dev = atoi(lr) % nd;
+	}
+	if (hipSetDevice(c->dev) != hipSuccess || hipStreamCreate(&c->st) != hipSuccess) { fail("cannot open device %d", c->dev); delete c; return 0; }
+	if (n_hash > 0 && n_shift > pre) {                       /* reference htab.c:23-27 */
+		c->n_hash = n_hash; c->bf_shift = n_shift; c->nb = n_shift - pre;
+		c->has_bloom = c->nb >= 9 && c->nb + 9 <= 64;        /* yak_bf_init returns NULL otherwise (bbf.c:9) */
+	}
+	if (dmalloc(&c->d_bits, c->P) || dmalloc(&c->d_off, c->P) || dmalloc(&c->d_counters, YKC_N) ||
+	    dmalloc(&c->d_lastput, c->P) || dmalloc(&c->d_lpbatch, c->P) || dmalloc(&c->d_missing, (c->P + 31) / 32 + 1) ||
+	    dmalloc(&c->d_nmissing, 1) || img_reset_empty(c)) { yk_ctx_destroy(c); return 0; }
+	if (c->has_bloom) {
+		c->bf_words = (size_t)c->P << (c->nb - 5);
+		if (dmalloc(&c->d_bf, c->bf_words)) { yk_ctx_destroy(c); return 0; }
+		if (hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st) != hipSuccess) { yk_ctx_destroy(c); return 0; }
+		c->multi_bits = (int)env_i64("YAKAMD_MULTI_BITS", 30);
+		if (c->multi_bits < 10) c->multi_bits = 10;
+		if (dmalloc(&c->d_multi, (size_t)1 << (c->multi_bits - 5))) { yk_ctx_destroy(c); return 0; }
+		hipMemsetAsync(c->d_multi, 0, (size_t)1 << (c->multi_bits - 3), c->st);
+		hipStreamSynchronize(c->st);
+	}
+	return c;
+}
+
+static void pass_free(yakamd_ctx *c)
+{
+	dfree(c->acc.s); c->acc_count = 0;
+	dfree(c->d_rh); dfree(c->d_rt); c->rec_cap = 0;
+	dfree(c->d_newlist); dfree(c->d_miss); dfree(c->d_cand); c->new_cap = 0;
+	c->in_pass = false;
+}
+
+void yk_ctx_destroy(yakamd_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->dev);
+	pass_free(c);
+	dfree(c->d_stage);
+	dfree(c->d_bits); dfree(c->d_used); dfree(c->d_delta); dfree(c->d_off); dfree(c->d_keys);
+	dfree(c->d_bf); dfree(c->d_multi);
+	dfree(c->d_counters); dfree(c->d_lastput); dfree(c->d_lpbatch); dfree(c->d_missing); dfree(c->d_nmissing);
+	if (c->hm_keys) hipHostFree(c->hm_keys);
+	if (c->hm_used) hipHostFree(c->hm_used);
+	free(c->hts);
+	if (c->st) hipStreamDestroy(c->st);
+	delete c;
+}
+
+int yk_ctx_destroy_bf(yakamd_ctx *c)
+{
+	hipSetDevice(c->dev);
+	dfree(c->d_bf); dfree(c->d_multi);
+	c->has_bloom = false;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+
+static int acc_alloc(yakamd_ctx *c, AccTab *t, int bits)
+{
+	t->bits = bits; t->pre = c->pre; t->mask = (1ull << bits) - 1;
+	if (dmalloc(&t->s, (size_t)1 << bits)) return -1;
+	yk_launch_acc_init(t->s, 1ull << bits, c->st);
+	return 0;
+}
+
+/* make room for `incoming` more distinct keys at a load factor <= 0.6 */
+static int acc_reserve(yakamd_ctx *c, u64 incoming)
+{
+	const u64 need = c->acc_count + incoming;
+	int bits = c->acc.s ? c->acc.bits : 0;
+	int want = std::max(c->pre + 2, ceil_log2_u64((u64)(need / 0.6) + 1));
+	if (want < 12) want = 12;
+	if (c->acc.s && bits >= want) return 0;
+	AccTab nt;
+	if (acc_alloc(c, &nt, want)) return -1;
+	if (c->acc.s) {
+		yk_launch_acc_rehash(c->acc, nt, c->st);
+		HIPCK(hipStreamSynchronize(c->st));
+		dfree(c->acc.s);
+	}
+	c->acc = nt;
+	return 0;
+}
+
+extern "C" int yakamd_set_shard(yak_ch_t *h, int lo, int hi)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || lo < 0 || hi > c->P || lo >= hi) return fail("bad shard range");
+	c->plo = lo; c->phi = hi;
+	return 0;
+}
+
+extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c) return fail("not an engine table");
+	if (c->in_pass) return fail("pass already open");
+	HIPCK(hipSetDevice(c->dev));
+	c->create_new = create_new;
+	c->bloom_mode = create_new && c->has_bloom;
+	c->in_pass = true;
+	c->t_end = 0;
+	memset(&c->st_cur, 0, sizeof(c->st_cur));
+	HIPCK(hipMemsetAsync(c->d_counters, 0, YKC_N * 8, c->st));
+	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));
+	c->st_cur.ms_total = now_ms();
+	return 0;
+}
+
+struct EvTimer {
+	hipEvent_t a, b; hipStream_t st;
+	EvTimer(hipStream_t s) : st(s) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
+	double stop() { float ms = 0; hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); return ms; }
+	~EvTimer() { hipEventDestroy(a); hipEventDestroy(b); }
+};
+
+/* bloom gate over the keys first seen in the batch just inserted (kernels.hip K2) */
+static int bloom_phases(yakamd_ctx *c, u64 n_new)
+{
+	if (n_new == 0) return 0;
+	const BloomView bf = bloom_view(c);
+	u64 h_cnt[YKC_N];
+	EvTimer tm(c->st);
+	HIPCK(hipMemsetAsync(c->d_counters + YKC_ANYMULTI, 0, 3 * 8, c->st));   /* ANYMULTI, NCAND, NMARKED */
+	yk_launch_bf_test(c->acc, c->d_newlist, n_new, bf, c->d_miss, c->st);
+	yk_launch_bf_set(c->acc, c->d_newlist, n_new, bf, c->d_miss, c->d_multi, c->multi_bits, c->d_counters, c->st);
+	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (h_cnt[YKC_ANYMULTI]) {
+		yk_launch_bf_check(c->acc, c->d_newlist, n_new, bf, c->d_miss, c->d_multi, c->multi_bits, c->d_cand, c->d_counters, c->st);
+		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+		const u64 n_cand = h_cnt[YKC_NCAND], n_marked = h_cnt[YKC_NMARKED];
+		if (n_cand) {
+			const int map_bits = std::max(10, ceil_log2_u64(2 * n_marked + 2));
+			u64 *d_map = 0;
+			if (dmalloc(&d_map, (size_t)2 << map_bits)) return -1;
+			HIPCK(hipMemsetAsync(d_map, 0, (size_t)16 << map_bits, c->st));
+			yk_launch_bf_mapfill(c->acc, c->d_newlist, n_new, bf, c->d_miss, c->d_multi, c->multi_bits, d_map, map_bits, c->st);
+			yk_launch_bf_resolve(c->acc, c->d_newlist, c->d_cand, n_cand, bf, c->d_miss, d_map, map_bits, c->st);
+			HIPCK(hipStreamSynchronize(c->st));
+			dfree(d_map);
+			c->st_cur.n_bloom_candidates += (int64_t)n_cand;
+		}
+		HIPCK(hipMemsetAsync(c->d_multi, 0, (size_t)1 << (c->multi_bits - 3), c->st));
+	}
+	c->st_cur.ms_bloom += tm.stop();
+	return 0;
+}
+
+/* per sub-table time of the last put-call of this batch (see k_lastput) */
+static int lastput_phase(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, int img_nonempty)
+{
+	const int64_t tail = env_i64("YAKAMD_LASTPUT_TAIL", 4 << 20);
+	const u64 t_from = (batch_hi - batch_lo > (u64)tail) ? batch_hi - (u64)tail : batch_lo;
+	const ImgView img = img_view(c);
+	u32 n_missing = 0;
+	HIPCK(hipMemsetAsync(c->d_lpbatch, 0, c->P * 8, c->st));
+	HIPCK(hipMemsetAsync(c->d_missing, 0, ((c->P + 31) / 32) * 4, c->st));
+	HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));
+	yk_launch_lastput(c->d_rh, c->d_rt, n_rec, t0, t_from, c->acc, img, img_nonempty, c->bloom_mode, 0, c->d_lpbatch, c->st);
+	yk_launch_lastput_merge(c->d_lastput, c->d_lpbatch, c->d_missing, c->d_nmissing, c->P, c->plo, c->phi, c->st);
+	if (t_from > batch_lo) {
+		HIPCK(hipMemcpyAsync(&n_missing, c->d_nmissing, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+		if (n_missing) {    /* the tail did not reach every sub-table: scan the whole batch for those */
+			yk_launch_lastput(c->d_rh, c->d_rt, n_rec, t0, batch_lo, c->acc, img, img_nonempty, c->bloom_mode, c->d_missing, c->d_lpbatch, c->st);
+			HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));
+			yk_launch_lastput_merge(c->d_lastput, c->d_lpbatch, c->d_missing, c->d_nmissing, c->P, c->plo, c->phi, c->st);
+		}
+	}
+	return 0;
+}
+
+static int rec_reserve(yakamd_ctx *c, int64_t n)
+{
+	if (n <= c->rec_cap) return 0;
+	dfree(c->d_rh); dfree(c->d_rt);
+	c->rec_cap = n;
+	return dmalloc(&c->d_rh, (size_t)n) || dmalloc(&c->d_rt, (size_t)n) ? -1 : 0;
+}
+
+static int new_reserve(yakamd_ctx *c, int64_t n)
+{
+	if (!c->bloom_mode || n <= c->new_cap) return 0;
+	dfree(c->d_newlist); dfree(c->d_miss); dfree(c->d_cand);
+	c->new_cap = n;
+	const BloomView bf = bloom_view(c);
+	return dmalloc(&c->d_newlist, (size_t)n) || dmalloc(&c->d_miss, (size_t)n * bf.mw) || dmalloc(&c->d_cand, (size_t)n) ? -1 : 0;
+}
+
+/* records [0, n_rec) of d_rh/d_rt (times = t0 + d_rt[i], all within [batch_lo, batch_hi)) -> table */
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi)
+{
+	if (n_rec <= 0) return 0;
+	const ImgView img = img_view(c);
+	c->st_cur.n_instances += n_rec;
+	if (batch_hi > c->t_end) c->t_end = batch_hi;
+	if (!c->create_new) {
+		EvTimer tm(c->st);
+		yk_launch_img_count(c->d_rh, n_rec, img, c->st);
+		const double ms = tm.stop();
+		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+		return 0;
+	}
+	const int img_nonempty = c->img_keys_total > 0;
+	if (acc_reserve(c, (u64)n_rec) || new_reserve(c, n_rec)) return -1;
+	u64 h_cnt[YKC_N];
+	{
+		EvTimer tm(c->st);
+		yk_launch_acc_insert(c->d_rh, c->d_rt, n_rec, t0, c->acc, img, img_nonempty, c->bloom_mode,
+		                     c->bloom_mode ? c->d_newlist : 0, c->d_counters, c->st);
+		const double ms = tm.stop();
+		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+	}
+	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	const u64 n_new = h_cnt[YKC_NEW];
+	c->acc_count += n_new;
+	HIPCK(hipMemsetAsync(c->d_counters + YKC_NEW, 0, 8, c->st));
+	if (c->bloom_mode && bloom_phases(c, n_new)) return -1;
+	return lastput_phase(c, n_rec, t0, batch_lo, batch_hi, img_nonempty);
+}
+
+extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	if (c->k >= 32) return fail("k >= 32 is not implemented on the device yet");
+	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
+	HIPCK(hipSetDevice(c->dev));
+	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 26);
+	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
+	if (rec_reserve(c, std::min(batch, (n_bytes + 4095) & ~(int64_t)4095))) return -1;
+	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
+		const int64_t end = std::min(n_bytes, pos + batch);
+		u64 n_rec = 0;
+		HIPCK(hipMemsetAsync(c->d_counters + YKC_INST, 0, 8, c->st));
+		{
+			EvTimer tm(c->st);
+			yk_launch_extract((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->d_rh, c->d_rt, c->d_counters + YKC_INST, c->st);
+			HIPCK(hipMemcpyAsync(&n_rec, c->d_counters + YKC_INST, 8, hipMemcpyDeviceToHost, c->st));
+			c->st_cur.ms_extract += tm.stop();
+		}
+		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end)) return -1;
+	}
+	return 0;
+}
+
+extern "C" int yakamd_feed_bases_host(yak_ch_t *h, const void *h_bases, int64_t n_bytes, uint64_t t0)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	HIPCK(hipSetDevice(c->dev));
+	if (n_bytes > c->stage_cap) {
+		dfree(c->d_stage);
+		c->stage_cap = n_bytes + (n_bytes >> 3) + 4096;
+		if (dmalloc(&c->d_stage, (size_t)c->stage_cap)) { c->stage_cap = 0; return -1; }
+	}
+	HIPCK(hipMemcpyAsync(c->d_stage, h_bases, (size_t)n_bytes, hipMemcpyHostToDevice, c->st));
+	return yakamd_feed_bases_dev(h, c->d_stage, n_bytes, t0);
+}
+
+extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const void *d_t, int64_t n, uint64_t t0, uint64_t t_span)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	HIPCK(hipSetDevice(c->dev));
+	/* records are consumed in place */
+	u64 *keep_h = c->d_rh; u32 *keep_t = c->d_rt;
+	c->d_rh = (u64*)d_hash; c->d_rt = (u32*)d_t;
+	const int r = consume_records(c, n, t0, t0, t0 + t_span);
+	c->d_rh = keep_h; c->d_rt = keep_t;
+	return r;
+}
+
+extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t, void *stream)
+{
+	if (k >= 32 || k < 1) { fail("extract: unsupported k"); return -1; }
+	u64 *d_cur = 0, n = 0;
+	hipStream_t st = (hipStream_t)stream;
+	if (hipMalloc((void**)&d_cur, 8) != hipSuccess) { fail("hipMalloc"); return -1; }
+	hipMemsetAsync(d_cur, 0, 8, st);
+	yk_launch_extract((const uint8_t*)d_bases, 0, n_bytes, 0, k, 10, 0, 1 << 10, (u64*)d_hash, (u32*)d_t, d_cur, st);
+	hipMemcpyAsync(&n, d_cur, 8, hipMemcpyDeviceToHost, st);
+	hipStreamSynchronize(st);
+	hipFree(d_cur);
+	return (int64_t)n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * layout planning + replay
+ * ------------------------------------------------------------------------------------------ */
+
+/* capacity after `m` new keys on a table of (cap, cnt), plus one possible trailing doubling */
+static u32 plan_cap(u32 cap, u32 cnt, u32 m, bool may_trail)
+{
+	u64 n = cap, c = cnt, rem = m;
+	while (rem > 0) {
+		const u64 thr = (n >> 1) + (n >> 2);
+		if (c >= thr) { n = n ? n << 1 : 4; continue; }
+		const u64 b = std::min(rem, thr - c);
+		c += b; rem -= b;
+	}
+	if (may_trail && c >= (n >> 1) + (n >> 2)) n = n ? n << 1 : 4;
+	return (u32)n;
+}
+
+/* rebuild the image from per-sub-table ordered record lists.  rec_t/lastput may be NULL (shrink) */
+static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg_off, const u64 *d_rec_kc, const u64 *d_rec_t,
+                      const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty)
+{
+	const int P = c->P;
+	std::vector<ReplayTask> tasks(P);
+	std::vector<u64> new_off(P);
+	u64 tot = 0, rec = 0;
+	for (int p = 0; p < P; ++p) {
+		ReplayTask &t = tasks[p];
+		t.old_bits = from_empty ? YK_NOCAP : c->h_bits[p];
+		t.old_count = from_empty ? 0 : c->h_count[p];
+		t.old_off = c->h_off[p];
+		t.rec_off = rec; t.m = m[p]; rec += m[p];
+		t.init_bits = init_bits ? (*init_bits)[p] : YK_NOCAP;
+		u32 cap0 = t.old_bits == YK_NOCAP ? 0 : 1u << t.old_bits;
+		if (cap0 == 0 && t.init_bits != YK_NOCAP) cap0 = 1u << t.init_bits;
+		const u32 capm = plan_cap(cap0, t.old_count, t.m, d_lastput != 0);
+		t.cap_max_bits = capm ? (u32)ceil_log2_u64(capm) : 0;
+		t.pad = 0;
+		new_off[p] = tot; t.new_off = tot;
+		tot += std::max<u64>(32, capm);
+	}
+	(void)d_seg_off;
+	u64 *nk = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0;
+	ReplayTask *d_tasks = 0;
+	if (dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) || dmalloc(&nd, tot) ||
+	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
+	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
+	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
+	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
+	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
+	yk_launch_replay(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, so, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
+	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	dfree(su); dfree(so); dfree(d_tasks); dfree(d_ob); dfree(d_oc);
+	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
+	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
+	c->h_off = new_off;
+	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	c->img_keys_total = 0;
+	for (int p = 0; p < P; ++p) c->img_keys_total += c->h_count[p];
+	c->host_valid = false;
+	return 0;
+}
+
+extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("no pass open");
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	int64_t n_ins = 0;
+	if (!c->create_new) {
+		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
+		HIPCK(hipStreamSynchronize(c->st));
+		c->host_valid = false;
+	} else {
+		const u64 before = c->img_keys_total;
+		if (c->img_keys_total) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* put-calls that hit existing keys */
+		std::vector<u32> m(P, 0);
+		std::vector<u64> seg_off(P + 1, 0);
+		u32 *d_segcnt = 0, *d_segcur = 0; u64 *d_segoff = 0, *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
+		if (dmalloc(&d_segcnt, P) || dmalloc(&d_segcur, P) || dmalloc(&d_segoff, P + 1)) return -1;
+		HIPCK(hipMemsetAsync(d_segcnt, 0, P * 4, c->st));
+		HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
+		int cur = 0;
+		if (c->acc.s) {
+			{
+				EvTimer tm(c->st);
+				yk_launch_select_count(c->acc, c->bloom_mode, P, d_segcnt, c->st);
+				HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
+				HIPCK(hipStreamSynchronize(c->st));
+				for (int p = 0; p < P; ++p) seg_off[p + 1] = seg_off[p] + m[p];
+				const u64 tot = seg_off[P];
+				if (dmalloc(&kc[0], tot) || dmalloc(&kc[1], tot) || dmalloc(&tt[0], tot) || dmalloc(&tt[1], tot)) return -1;
+				HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+				yk_launch_select_scatter(c->acc, c->bloom_mode, P, d_segoff, d_segcur, kc[0], tt[0], c->st);
+				c->st_cur.ms_select += tm.stop();
+			}
+			dfree(c->acc.s);                              /* the accumulator is no longer needed */
+			{
+				EvTimer tm(c->st);
+				const int tbits = std::max(1, ceil_log2_u64(c->t_end + 1));
+				for (int shift = 0; shift < tbits; shift += 8) {
+					yk_launch_seg_sort_pass(d_segoff, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
+					cur ^= 1;
+				}
+				c->st_cur.ms_sort += tm.stop();
+			}
+		} else {
+			HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+			if (dmalloc(&kc[0], 1) || dmalloc(&tt[0], 1)) return -1;
+		}
+		{
+			EvTimer tm(c->st);
+			if (run_replay(c, m, d_segoff, kc[cur], tt[cur], c->d_lastput, 0, false)) return -1;
+			c->st_cur.ms_replay += tm.stop();
+		}
+		dfree(d_segcnt); dfree(d_segcur); dfree(d_segoff);
+		dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]);
+		n_ins = (int64_t)(c->img_keys_total - before);
+		c->st_cur.n_distinct_seen = (int64_t)c->acc_count;
+		c->st_cur.n_new_keys = n_ins;
+	}
+	pass_free(c);
+	c->st_cur.ms_total = now_ms() - c->st_cur.ms_total;
+	c->st_last = c->st_cur;
+	return n_ins;
+}
+
+extern "C" int yakamd_get_stats(yak_ch_t *h, yakamd_stats_t *st)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c) return -1;
+	*st = c->st_last;
+	return 0;
+}
+
+int yk_ctx_clear(yakamd_ctx *c)
+{
+	HIPCK(hipSetDevice(c->dev));
+	yk_launch_img_clear(img_view(c), c->n_slots, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	c->host_valid = false;
+	return 0;
+}
+
+/* reference htab.c:180-208 */
+int yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot)
+{
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	std::vector<u32> m(P), init(P);
+	std::vector<u64> seg_off(P + 1, 0);
+	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
+	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
+	yk_launch_shrink_count(img_view(c), P, cmin, cmax, d_segcnt, c->st);
+	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	for (int p = 0; p < P; ++p) { seg_off[p + 1] = seg_off[p] + m[p]; init[p] = kh_bits_for(c->h_count[p]); }
+	if (dmalloc(&d_kc, seg_off[P])) return -1;
+	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, d_segoff, d_kc, c->st);
+	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
+	dfree(d_segcnt); dfree(d_segoff); dfree(d_kc);
+	if (r) return r;
+	*tot = c->img_keys_total;
+	return 0;
+}
+
+/* reference htab.c:441-447: resize each sub-table to its saved capacity, then put in file order */
+int yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys)
+{
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	std::vector<u32> m(P), init(P);
+	u64 tot = 0;
+	for (int p = 0; p < P; ++p) { m[p] = sizes[p]; init[p] = kh_bits_for(caps[p]); tot += sizes[p]; }
+	u64 *d_kc = 0;
+	if (dmalloc(&d_kc, tot)) return -1;
+	HIPCK(hipMemcpyAsync(d_kc, keys, tot * 8, hipMemcpyHostToDevice, c->st));
+	const int r = run_replay(c, m, 0, d_kc, 0, 0, &init, true);
+	dfree(d_kc);
+	return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host mirror
+ * ------------------------------------------------------------------------------------------ */
+struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };   /* same shape as khashl.h:104-109 */
+
+int yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h)
+{
+	if (c->host_valid) return 0;
+	HIPCK(hipSetDevice(c->dev));
+	if (c->hm_slots < c->n_slots) {
+		if (c->hm_keys) hipHostFree(c->hm_keys);
+		if (c->hm_used) hipHostFree(c->hm_used);
+		c->hm_keys = 0; c->hm_used = 0;
+		HIPCK(hipHostMalloc((void**)&c->hm_keys, c->n_slots * 8));
+		HIPCK(hipHostMalloc((void**)&c->hm_used, c->n_slots / 8));
+		c->hm_slots = c->n_slots;
+	}
+	HIPCK(hipMemcpyAsync(c->hm_keys, c->d_keys, c->n_slots * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipMemcpyAsync(c->hm_used, c->d_used, c->n_slots / 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (!c->hts) c->hts = (yak_ht_t*)calloc(c->P, sizeof(yak_ht_t));
+	for (int p = 0; p < c->P; ++p) {
+		yak_ht_t *g = &c->hts[p];
+		const bool has = c->h_bits[p] != YK_NOCAP;
+		g->bits = has ? c->h_bits[p] : 0;
+		g->count = c->h_count[p];
+		g->keys = has ? (uint64_t*)(c->hm_keys + c->h_off[p]) : 0;
+		g->used = c->hm_used + c->h_off[p] / 32;
+		if (h) h->h[p].h = g;
+	}
+	c->host_valid = true;
+	return 0;
+}
+
+extern "C" int yakamd_sync_host(yak_ch_t *h)
+{
+	yakamd_ctx *c = ctx_of(h);
+	return c ? yk_ctx_sync_host(c, h) : fail("not an engine table");
+}
+
+extern "C" int yakamd_subtable(yak_ch_t *h, int i, uint32_t *capacity, uint32_t *size)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || i < 0 || i >= c->P) return -1;
+	*capacity = c->h_bits[i] == YK_NOCAP ? 0 : 1u << c->h_bits[i];
+	*size = c->h_count[i];
+	return 0;
+}
+
+u64 yk_ctx_list_time(yakamd_ctx *c, u64 n) { const u64 t = c->list_t; c->list_t += n; return t; }
+int yk_ctx_device(yakamd_ctx *c) { return c->dev; }
+hipStream_t yk_ctx_stream(yakamd_ctx *c) { return c->st; }
+const yak_ht_t *yk_ctx_ht(yakamd_ctx *c, int p) { return c->hts ? &c->hts[p] : 0; }

@@ -1,0 +1,18 @@
+/* engine.h -- internal interface between engine.cpp and yak_api.cpp */
+#ifndef YK_ENGINE_H
+#define YK_ENGINE_H
+#include "../../include/yak_amd.h"
+#include "yk_device.h"
+
+struct yak_ht_t;
+yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift);
+void yk_ctx_destroy(yakamd_ctx *c);
+int  yk_ctx_destroy_bf(yakamd_ctx *c);
+int  yk_ctx_clear(yakamd_ctx *c);
+int  yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot);
+int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys);
+int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
+u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);
+int  yk_ctx_device(yakamd_ctx *c);
+hipStream_t yk_ctx_stream(yakamd_ctx *c);
+#endif

@@ -1,0 +1,984 @@
+/*
+ * kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the k-mer counting engine.
+ *
+ * Pipeline of one counting pass (replaces reference count.c:85-166 + htab.c:51-78):
+ *   K1  k_extract        bases -> (yak_hash64 of canonical k-mer, stream position)   [count.c:28-43]
+ *   K3  k_acc_insert     records -> accumulator table (first/second occurrence time, count)
+ *   K2  k_bf_*           order-exact blocked-bloom gate on first occurrences        [bbf.c:25-42]
+ *   K4  k_img_count      create_new == 0: increment keys of the existing table     [htab.c:71-75]
+ *   sel k_select_*       keys that enter the table, grouped by sub-table
+ *   srt k_seg_sort_pass  per sub-table LSD radix sort by insertion time
+ *   K5  k_replay         exact khashl layout: staged FCFS placement + in-place doubling [khashl.h:152-221]
+ * All work is 64-bit integer arithmetic; the bound is HBM / L2-atomic traffic, never MFMA.
+ */
+#include "yk_device.h"
+
+#define WAVE 64
+
+/* ------------------------------------------------------------------------------------------
+ * small device helpers
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ u64 yk_hash64(u64 x, u64 m)           /* reference yak-priv.h:11-21 */
+{
+	x = (~x + (x << 21)) & m;
+	x ^= x >> 24;
+	x = (x + (x << 3) + (x << 8)) & m;
+	x ^= x >> 14;
+	x = (x + (x << 2) + (x << 4)) & m;
+	x ^= x >> 28;
+	x = (x + (x << 31)) & m;
+	return x;
+}
+
+__device__ __forceinline__ u32 yk_h2b(u32 h, u32 bits) { return (u32)(h * 2654435769u) >> (32 - bits); } /* khashl.h:98 */
+
+__device__ __forceinline__ u64 yk_mix64(u64 z)
+{
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+	return z ^ (z >> 31);
+}
+
+/* reverse the order of the 32 two-bit groups of a 64-bit word */
+__device__ __forceinline__ u64 yk_rev2(u64 w)
+{
+	u64 r = __brevll(w);
+	return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+}
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1; }
+
+__device__ __forceinline__ void block_sync_global()   /* make global writes/atomics of the block visible to the block */
+{
+	__threadfence();
+	__syncthreads();
+}
+
+/* base code table (reference misc.c:4-21) */
+__device__ const unsigned char d_nt4[256] = {
+#define R4(v) v, v, v, v
+#define R16(v) R4(v), R4(v), R4(v), R4(v)
+	0, 1, 2, 3, R4(4), R4(4), R4(4),
+	R16(4), R16(4), R16(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4)
+#undef R16
+#undef R4
+};
+
+/* ------------------------------------------------------------------------------------------
+ * K1: extraction.  One workgroup = one tile of XT_TILE stream positions.
+ *   phase 1: 16 B/lane coalesced loads, nt4 translation, 2-bit packing into LDS (+32-base halo)
+ *   phase 2: lane <-> position; the k-mer ending at the position is a 2k-bit window of the packed
+ *            stream; reverse strand = complement of the window, forward = 2-bit-group reversal;
+ *            canonical = min; yak_hash64.  A window is emitted iff its k validity bits are all set,
+ *            which is exactly the `l` run counter of count.c:33-42.
+ *   phase 3: wave ballot + prefix compaction, one global cursor bump per workgroup, coalesced
+ *            stores of (hash, position).
+ * ------------------------------------------------------------------------------------------ */
+#define XT_TILE    4096
+#define XT_THREADS 256
+#define XT_ROUNDS  (XT_TILE / XT_THREADS)
+#define XT_HALO    32
+
+__global__ __launch_bounds__(XT_THREADS)
+void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+               u64 *__restrict__ out_hash, u32 *__restrict__ out_t, u64 *cursor)
+{
+	__shared__ u32 s_code[XT_TILE / 16 + 4];
+	__shared__ u32 s_valid[XT_TILE / 32 + 4];
+	__shared__ unsigned char s_lut[256];
+	__shared__ u32 s_cnt[XT_ROUNDS * 4];
+	__shared__ u64 s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t tile0 = pos0 + (int64_t)blockIdx.x * XT_TILE;   /* pos0 is a multiple of 16 */
+	const int64_t origin = tile0 - XT_HALO;
+
+	if (tid < 64) ((u32*)s_lut)[tid] = ((const u32*)d_nt4)[tid];
+	if (tid < 4) { s_code[XT_TILE / 16 + tid] = 0; s_valid[XT_TILE / 32 + tid] = 0; }
+	__syncthreads();
+
+	for (int w = tid; w < (XT_TILE + XT_HALO) / 16; w += XT_THREADS) {
+		const int64_t pos = origin + 16 * (int64_t)w;
+		u32 code = 0, val = 0;
+		if (pos >= 0 && pos + 16 <= n) {
+			const uint4 v = *(const uint4*)(bases + pos);
+			const u32 q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const u32 c = s_lut[(q[j >> 2] >> (8 * (j & 3))) & 0xff];
+				if (c < 4) { code |= c << (2 * j); val |= 1u << j; }
+			}
+		} else {
+			for (int j = 0; j < 16; ++j) {
+				const int64_t x = pos + j;
+				if (x >= 0 && x < n) {
+					const u32 c = s_lut[bases[x]];
+					if (c < 4) { code |= c << (2 * j); val |= 1u << j; }
+				}
+			}
+		}
+		s_code[w] = code;
+		((unsigned short*)s_valid)[w] = (unsigned short)val;
+	}
+	__syncthreads();
+
+	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	const u32 pmask = (1u << pre) - 1;
+	u64 hv[XT_ROUNDS];
+	u32 okm = 0;
+#pragma unroll
+	for (int r = 0; r < XT_ROUNDS; ++r) {
+		const int e = XT_HALO + r * XT_THREADS + tid;      /* LDS base index of the k-mer's last base */
+		const int s = e - k + 1;
+		const u64 V = ((u64)s_valid[s >> 5] | (u64)s_valid[(s >> 5) + 1] << 32) >> (s & 31);
+		const int w0 = s >> 4, o = 2 * (s & 15);
+		const u64 lo = (u64)s_code[w0] | (u64)s_code[w0 + 1] << 32;
+		u64 W = lo >> o;
+		if (o) W |= (u64)s_code[w0 + 2] << (64 - o);
+		W &= mask;
+		const u64 rv = ~W & mask;                          /* count.c:37: base j of the window at bits 2j, complemented */
+		const u64 fw = yk_rev2(W) >> (64 - 2 * k);         /* count.c:36: first base most significant */
+		const u64 h = yk_hash64(fw < rv ? fw : rv, mask);
+		const u32 p = (u32)h & pmask;
+		const bool ok = (V & kones) == kones && tile0 + r * XT_THREADS + tid < n && (int)p >= plo && (int)p < phi;
+		hv[r] = h;
+		okm |= (u32)ok << r;
+		const u64 b = __ballot(ok);
+		if (lane == 0) s_cnt[r * 4 + wave] = __popcll(b);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		u32 acc = 0;
+		for (int i = 0; i < XT_ROUNDS * 4; ++i) { const u32 c = s_cnt[i]; s_cnt[i] = acc; acc += c; }
+		s_base = acc ? atomicAdd(cursor, (u64)acc) : 0;
+	}
+	__syncthreads();
+	const u64 base = s_base;
+#pragma unroll
+	for (int r = 0; r < XT_ROUNDS; ++r) {
+		const bool ok = okm >> r & 1;
+		const u64 b = __ballot(ok);
+		if (ok) {
+			const u64 d = base + s_cnt[r * 4 + wave] + __popcll(b & lanemask_lt());
+			out_hash[d] = hv[r];
+			out_t[d] = (u32)(tile0 + r * XT_THREADS + tid - t_sub);
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * table image probing (khashl get, reference khashl.h:137-150 / htab.c:93-100)
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int64_t img_find(const ImgView &img, u64 key)
+{
+	const u32 p = (u32)key & ((1u << img.pre) - 1);
+	const u32 bits = img.bits[p];
+	if (bits == YK_NOCAP) return -1;
+	const u64 kid = key >> img.pre;
+	const u64 off = img.off[p];
+	const u32 nmask = (1u << bits) - 1;
+	u32 i = yk_h2b((u32)kid, bits);
+	const u32 first = i;
+	for (;;) {
+		const u64 a = off + i;
+		if (!(img.used[a >> 5] >> (a & 31) & 1)) return -1;
+		if (img.keys[a] >> 10 == kid) return (int64_t)a;
+		i = (i + 1) & nmask;
+		if (i == first) return -1;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * accumulator table (our own layout: one 32-B slot per distinct k-mer, linear probing).
+ * Slot index = prefix-major: the high bits select the sub-table region so that a later
+ * prefix-partitioned pass touches one contiguous region per sub-table.
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ u64 acc_home(const AccTab &t, u64 key)
+{
+	const int rb = t.bits - t.pre;
+	const u64 p = key & ((1ull << t.pre) - 1);
+	const u64 r = ((key >> t.pre) * 0x9E3779B97F4A7C15ull) >> (64 - rb);
+	return p << rb | r;
+}
+
+/* find-or-claim; returns the slot, *created = 1 if this call claimed it */
+__device__ __forceinline__ AccSlot *acc_claim(const AccTab &t, u64 key, bool *created)
+{
+	u64 i = acc_home(t, key);
+	*created = false;
+	for (;;) {
+		AccSlot *s = t.s + i;
+		u64 cur = s->key;
+		if (cur == key) return s;
+		if (cur == YK_EMPTY) {
+			cur = atomicCAS(&s->key, YK_EMPTY, key);
+			if (cur == YK_EMPTY) { *created = true; return s; }
+			if (cur == key) return s;
+		}
+		i = (i + 1) & t.mask;
+	}
+}
+
+__device__ __forceinline__ AccSlot *acc_find(const AccTab &t, u64 key)
+{
+	u64 i = acc_home(t, key);
+	for (;;) {
+		AccSlot *s = t.s + i;
+		const u64 cur = s->key;
+		if (cur == key) return s;
+		if (cur == YK_EMPTY) return 0;
+		i = (i + 1) & t.mask;
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_acc_init(AccSlot *s, u64 n)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		ulonglong2 *q = (ulonglong2*)(s + i);
+		q[0] = make_ulonglong2(YK_EMPTY, YK_TINF);
+		q[1] = make_ulonglong2(YK_TINF, 0ull);
+	}
+}
+
+/* K3: every k-mer instance -> accumulator.  Per instance: one 32-B slot read, a CAS only for a new
+ * key, atomicMin on t1/t2 only when the instance can still lower them (both only ever decrease,
+ * so a stale read errs on the safe side), one fire-and-forget count increment. */
+__global__ __launch_bounds__(256)
+void k_acc_insert(const u64 *__restrict__ hash, const u32 *__restrict__ tlo, int64_t n, u64 t0,
+                  AccTab tab, ImgView img, int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const int lane = threadIdx.x & 63;
+	u32 n_exist = 0;
+	for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+		const int64_t i = i0 + threadIdx.x;
+		bool created = false;
+		AccSlot *s = 0;
+		if (i < n) {
+			const u64 key = hash[i], t = t0 + tlo[i];
+			int64_t hit = -1;
+			if (img_nonempty) hit = img_find(img, key);
+			if (hit >= 0) {
+				atomicAdd(&img.delta[hit], 1u);       /* a put-call on an existing key: count only */
+				++n_exist;
+			} else {
+				s = acc_claim(tab, key, &created);
+				const ulonglong2 tt = *(const ulonglong2*)&s->t1;      /* {t1, t2}, possibly stale-high */
+				const u32 c = s->cnt;
+				if (c < 4096u) atomicAdd(&s->cnt, 1u);        /* only min(cnt, 1023[+1]) is ever used */
+				if (bloom_mode) {
+					u64 loser = t;
+					if (t < tt.x) {
+						const u64 old = atomicMin(&s->t1, t);
+						loser = old < t ? t : old;            /* the larger of the two leaves t1 */
+					}
+					if (loser != YK_TINF && loser < tt.y) atomicMin(&s->t2, loser);
+				} else if (t < tt.x) atomicMin(&s->t1, t);
+			}
+		}
+		const u64 b = __ballot(created);
+		if (b) {
+			u64 base = 0;
+			const int leader = __ffsll((long long)b) - 1;
+			if (lane == leader) base = atomicAdd(&counters[YKC_NEW], (u64)__popcll(b));
+			base = __shfl(base, leader);
+			if (created && newlist) newlist[base + __popcll(b & lanemask_lt())] = (u64)(s - tab.s);
+		}
+	}
+	if (img_nonempty) {
+		for (int o = 32; o; o >>= 1) n_exist += __shfl_down(n_exist, o);
+		if (lane == 0 && n_exist) atomicAdd(&counters[YKC_EXIST], (u64)n_exist);
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_acc_rehash(AccTab oldt, AccTab newt)
+{
+	const u64 n = oldt.mask + 1, stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const AccSlot o = oldt.s[i];
+		if (o.key == YK_EMPTY) continue;
+		bool created;
+		AccSlot *s = acc_claim(newt, o.key, &created);
+		s->t1 = o.t1; s->t2 = o.t2; s->cnt = o.cnt; s->flags = o.flags;
+	}
+}
+
+/* K4: create_new == 0 (reference htab.c:71-75): look the key up in the existing table image and
+ * count the hit; the saturating fold into the 10 count bits happens once at the end of the pass */
+__global__ __launch_bounds__(256)
+void k_img_count(const u64 *__restrict__ hash, int64_t n, ImgView img)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const int64_t hit = img_find(img, hash[i]);
+		if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_img_fold(ImgView img, u64 n_slots)                    /* htab.c:68-69,73-74: saturate at 1023 */
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+		const u32 d = img.delta[i];
+		if (d) {
+			const u64 kc = img.keys[i];
+			const u64 c = (kc & 1023) + d;
+			img.keys[i] = (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+			img.delta[i] = 0;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_img_clear(ImgView img, u64 n_slots)                   /* reference htab.c:116-125 */
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride)
+		if (img.used[i >> 5] >> (i & 31) & 1) img.keys[i] &= ~1023ull;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * last put-call per sub-table.  khashl grows at the NEXT put-call after the load factor reaches
+ * 0.75 (khashl.h:202), even when that call finds its key.  So the layout needs, per sub-table, the
+ * stream time of the last put-call of the pass.  Only the tail of the stream can matter; the host
+ * scans the tail first and the whole batch only for sub-tables the tail did not reach.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256)
+void k_lastput(const u64 *__restrict__ hash, const u32 *__restrict__ tlo, int64_t n, u64 t0, u64 t_from,
+               AccTab tab, ImgView img, int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const u32 pmask = (1u << tab.pre) - 1;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const u64 t = t0 + tlo[i];
+		if (t < t_from) continue;
+		const u64 key = hash[i];
+		const u32 p = (u32)key & pmask;
+		if (only_missing && !(only_missing[p >> 5] >> (p & 31) & 1)) continue;
+		bool put = true;
+		if (bloom_mode && !(img_nonempty && img_find(img, key) >= 0)) {
+			const AccSlot *s = acc_find(tab, key);
+			/* the first occurrence is a put-call only if it passed the gate (htab.c:63-65) */
+			if (s && s->t1 == t && !(s->flags & YK_FLAG_FP)) put = false;
+		}
+		if (put) atomicMax(&lp_batch[p], t + 1);
+	}
+}
+
+__global__ void k_lastput_merge(u64 *lastput, const u64 *lp_batch, u32 *missing, u32 *n_missing, int P, int plo, int phi)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= P) return;
+	const u64 v = lp_batch[p];
+	if (v) { if (v > lastput[p]) lastput[p] = v; }
+	else if (p >= plo && p < phi) { atomicOr(&missing[p >> 5], 1u << (p & 31)); atomicAdd(n_missing, 1u); }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K2: order-exact blocked bloom gate (reference bbf.c:25-42 + htab.c:63-65).
+ * Only the FIRST occurrence of a k-mer can be rejected by the gate, and it is accepted iff every
+ * one of its probe bits was set by the first occurrence of some other k-mer earlier in the stream.
+ * Per time-ordered batch, over the keys first seen in the batch:
+ *   test   : probe bits against the pre-batch filter -> all set: accepted (FP); else missing mask
+ *   set    : OR the missing bits in; a bit found already set here was set by another key of the
+ *            same batch -> note it in the (hashed) `multi` filter
+ *   check  : a key whose missing bits are ALL noted is a candidate (its fate depends on order)
+ *   mapfill/resolve : exact order for candidates through a min-time map over the noted bits
+ * ------------------------------------------------------------------------------------------ */
+struct BfProbe { u64 bit_base; u32 h1, h2, nd; };
+
+__device__ __forceinline__ BfProbe bf_probe(const BloomView &bf, u64 key, int pre)
+{
+	BfProbe q;
+	const u64 p = key & ((1ull << pre) - 1), x = key >> pre;
+	const int xb = bf.nb - 9;
+	const u64 blk = x & ((1ull << xb) - 1);
+	q.h1 = (u32)(x >> xb) & 511;
+	q.h2 = bf.nb < 64 ? (u32)(x >> bf.nb) & 511 : 0;
+	if ((q.h2 & 31) == 0) q.h2 = (q.h2 + 1) & 511;
+	const u32 cyc = 512u / (q.h2 & (0u - q.h2));         /* probes repeat after 512/gcd(h2,512) steps */
+	q.nd = (u32)bf.n_hash < cyc ? (u32)bf.n_hash : cyc;
+	q.bit_base = p << bf.nb | blk << 9;
+	return q;
+}
+
+__global__ __launch_bounds__(256)
+void k_bf_test(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, u64 *miss)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += stride) {
+		AccSlot *s = tab.s + newlist[i];
+		const BfProbe q = bf_probe(bf, s->key, tab.pre);
+		const u32 *blk = bf.bits32 + (q.bit_base >> 5);
+		bool any = false;
+		for (int w = 0; w < bf.mw; ++w) {
+			u64 m = 0;
+			for (u32 j = w * 64; j < q.nd && j < (u32)(w + 1) * 64; ++j) {
+				const u32 z = (q.h1 + j * q.h2) & 511;
+				if (!(blk[z >> 5] >> (z & 31) & 1)) m |= 1ull << (j & 63);
+			}
+			miss[i * bf.mw + w] = m;
+			any |= m != 0;
+		}
+		if (!any) s->flags |= YK_FLAG_FP;
+	}
+}
+
+__device__ __forceinline__ u32 multi_idx(u64 bitid, int multi_bits) { return (u32)(yk_mix64(bitid) >> (64 - multi_bits)); }
+
+__global__ __launch_bounds__(256)
+void k_bf_set(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+              u32 *multi, int multi_bits, u64 *counters)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += stride) {
+		const AccSlot *s = tab.s + newlist[i];
+		if (s->flags & YK_FLAG_FP) continue;
+		const BfProbe q = bf_probe(bf, s->key, tab.pre);
+		u32 *blk = bf.bits32 + (q.bit_base >> 5);
+		for (int w = 0; w < bf.mw; ++w) {
+			u64 m = miss[i * bf.mw + w];
+			while (m) {
+				const u32 j = w * 64 + (__ffsll((long long)m) - 1);
+				m &= m - 1;
+				const u32 z = (q.h1 + j * q.h2) & 511, bit = 1u << (z & 31);
+				const u32 old = atomicOr(&blk[z >> 5], bit);
+				if (old & bit) {
+					const u32 x = multi_idx(q.bit_base + z, multi_bits);
+					atomicOr(&multi[x >> 5], 1u << (x & 31));
+					counters[YKC_ANYMULTI] = 1;
+				}
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_bf_check(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                const u32 *multi, int multi_bits, u64 *cand, u64 *counters)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += stride) {
+		const AccSlot *s = tab.s + newlist[i];
+		if (s->flags & YK_FLAG_FP) continue;
+		const BfProbe q = bf_probe(bf, s->key, tab.pre);
+		bool all = true;
+		u32 n_noted = 0;
+		for (int w = 0; w < bf.mw; ++w) {
+			u64 m = miss[i * bf.mw + w];
+			while (m) {
+				const u32 j = w * 64 + (__ffsll((long long)m) - 1);
+				m &= m - 1;
+				const u32 z = (q.h1 + j * q.h2) & 511;
+				const u32 x = multi_idx(q.bit_base + z, multi_bits);
+				if (multi[x >> 5] >> (x & 31) & 1) ++n_noted; else all = false;
+			}
+		}
+		if (n_noted) atomicAdd(&counters[YKC_NMARKED], (u64)n_noted);
+		if (all) cand[atomicAdd(&counters[YKC_NCAND], 1ull)] = i;
+	}
+}
+
+/* min-time map: open addressing, key = bit id + 1 (0 = free), value = ~(earliest first-occurrence
+ * time) so that a zero-filled map means "never" and atomicMax implements the minimum */
+__device__ __forceinline__ void map_min(u64 *map, int map_bits, u64 bitid, u64 t)
+{
+	const u64 mask = (1ull << map_bits) - 1, k1 = bitid + 1;
+	u64 i = yk_mix64(bitid) >> (64 - map_bits);
+	for (;;) {
+		u64 cur = map[2 * i];
+		if (cur == 0) cur = atomicCAS(&map[2 * i], 0ull, k1);
+		if (cur == 0 || cur == k1) { atomicMax(&map[2 * i + 1], ~t); return; }
+		i = (i + 1) & mask;
+	}
+}
+
+__device__ __forceinline__ u64 map_get(const u64 *map, int map_bits, u64 bitid)
+{
+	const u64 mask = (1ull << map_bits) - 1, k1 = bitid + 1;
+	u64 i = yk_mix64(bitid) >> (64 - map_bits);
+	for (;;) {
+		const u64 cur = map[2 * i];
+		if (cur == k1) return ~map[2 * i + 1];
+		if (cur == 0) return YK_TINF;
+		i = (i + 1) & mask;
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_bf_mapfill(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                  const u32 *multi, int multi_bits, u64 *map, int map_bits)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += stride) {
+		const AccSlot *s = tab.s + newlist[i];
+		if (s->flags & YK_FLAG_FP) continue;
+		const BfProbe q = bf_probe(bf, s->key, tab.pre);
+		const u64 t1 = s->t1;
+		for (int w = 0; w < bf.mw; ++w) {
+			u64 m = miss[i * bf.mw + w];
+			while (m) {
+				const u32 j = w * 64 + (__ffsll((long long)m) - 1);
+				m &= m - 1;
+				const u32 z = (q.h1 + j * q.h2) & 511;
+				const u32 x = multi_idx(q.bit_base + z, multi_bits);
+				if (multi[x >> 5] >> (x & 31) & 1) map_min(map, map_bits, q.bit_base + z, t1);
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_bf_resolve(AccTab tab, const u64 *newlist, const u64 *cand, u64 n_cand, BloomView bf,
+                  const u64 *miss, const u64 *map, int map_bits)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += stride) {
+		const u64 i = cand[c];
+		AccSlot *s = tab.s + newlist[i];
+		const BfProbe q = bf_probe(bf, s->key, tab.pre);
+		const u64 t1 = s->t1;
+		bool all = true;
+		for (int w = 0; w < bf.mw && all; ++w) {
+			u64 m = miss[i * bf.mw + w];
+			while (m) {
+				const u32 j = w * 64 + (__ffsll((long long)m) - 1);
+				m &= m - 1;
+				const u32 z = (q.h1 + j * q.h2) & 511;
+				if (!(map_get(map, map_bits, q.bit_base + z) < t1)) { all = false; break; }
+			}
+		}
+		if (all) s->flags |= YK_FLAG_FP;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * selection: accumulator slots that enter the table -> (insertion time T, key<<10|count) records
+ * grouped by sub-table.  No bloom: T = t1, count = occurrences (htab.c:66-69).  Bloom: accepted at
+ * the first occurrence (T = t1, every occurrence counted) or at the second (T = t2, one less).
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ bool acc_select(const AccSlot &s, int bloom_mode, int pre, u32 *p, u64 *T, u64 *kc)
+{
+	if (s.key == YK_EMPTY) return false;
+	u64 c = s.cnt;
+	if (!bloom_mode || (s.flags & YK_FLAG_FP)) *T = s.t1;
+	else if (s.t2 != YK_TINF) { *T = s.t2; c -= 1; }
+	else return false;
+	if (c > 1023) c = 1023;
+	*p = (u32)s.key & ((1u << pre) - 1);
+	*kc = (s.key >> pre) << 10 | c;
+	return true;
+}
+
+__global__ __launch_bounds__(256)
+void k_select_count(AccTab tab, int bloom_mode, u32 *seg_cnt)
+{
+	const u64 n = tab.mask + 1, stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const AccSlot s = tab.s[i];
+		u32 p; u64 T, kc;
+		if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) atomicAdd(&seg_cnt[p], 1u);
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_select_scatter(AccTab tab, int bloom_mode, const u64 *seg_off, u32 *seg_cur, u64 *rec_kc, u64 *rec_t)
+{
+	const u64 n = tab.mask + 1, stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const AccSlot s = tab.s[i];
+		u32 p; u64 T, kc;
+		if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) {
+			const u64 d = seg_off[p] + atomicAdd(&seg_cur[p], 1u);
+			rec_kc[d] = kc; rec_t[d] = T;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per sub-table stable LSD radix sort pass (8-bit digit of T), one workgroup per sub-table.
+ * Stable ranking: the tile is split wave-major, each wave ranks its 64 elements per round with
+ * eight ballots (peers with an equal digit), per-wave digit counters live in LDS.
+ * ------------------------------------------------------------------------------------------ */
+#define SS_E 8
+__global__ __launch_bounds__(256)
+void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
+                     u64 *__restrict__ dst_kc, u64 *__restrict__ dst_t, int shift)
+{
+	__shared__ u32 s_hist[256];
+	__shared__ u32 s_wc[4][256];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u64 a = seg_off[blockIdx.x], len = seg_off[blockIdx.x + 1] - a;
+	if (len == 0) return;
+	if (len == 1) { if (tid == 0) { dst_kc[a] = src_kc[a]; dst_t[a] = src_t[a]; } return; }
+	s_hist[tid] = 0;
+	__syncthreads();
+	for (u64 i = tid; i < len; i += 256) atomicAdd(&s_hist[(src_t[a + i] >> shift) & 255], 1u);
+	__syncthreads();
+	if (tid == 0) { u32 acc = 0; for (int d = 0; d < 256; ++d) { const u32 c = s_hist[d]; s_hist[d] = acc; acc += c; } }
+	__syncthreads();
+	for (u64 tile = 0; tile < len; tile += 256 * SS_E) {
+		for (int w = 0; w < 4; ++w) s_wc[w][tid] = 0;
+		__syncthreads();
+		u64 et[SS_E], ek[SS_E];
+		u32 erk[SS_E];
+#pragma unroll
+		for (int r = 0; r < SS_E; ++r) {
+			const u64 idx = tile + (u64)wave * (64 * SS_E) + r * 64 + lane;
+			const bool valid = idx < len;
+			u64 t = 0, kc = 0;
+			if (valid) { t = src_t[a + idx]; kc = src_kc[a + idx]; }
+			const u32 d = (u32)(t >> shift) & 255;
+			u64 peers = __ballot(valid);
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const u64 vb = __ballot(valid && (d >> b & 1));
+				peers &= (d >> b & 1) ? vb : ~vb;
+			}
+			u32 old = 0;
+			const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+			if (valid && lane == leader) { old = s_wc[wave][d]; s_wc[wave][d] = old + __popcll(peers); }
+			old = __shfl(old, leader);
+			et[r] = t; ek[r] = kc;
+			erk[r] = valid ? (d << 24 | (old + __popcll(peers & lanemask_lt()))) : 0xffffffffu;
+		}
+		__syncthreads();
+		{	/* digit `tid`: turn per-wave counts into start offsets, advance the running offset */
+			u32 run = s_hist[tid];
+			for (int w = 0; w < 4; ++w) { const u32 c = s_wc[w][tid]; s_wc[w][tid] = run; run += c; }
+			s_hist[tid] = run;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < SS_E; ++r) {
+			if (erk[r] != 0xffffffffu) {
+				const u64 d = a + s_wc[wave][erk[r] >> 24] + (erk[r] & 0xffffff);
+				dst_kc[d] = ek[r]; dst_t[d] = et[r];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K5: exact khashl layout replay, one workgroup per sub-table.
+ *   * between two doublings every put is a first-come-first-served linear-probing placement of a
+ *     NEW key; FCFS in order sigma == ordered probing with priority = rank in sigma, which is
+ *     order-free and therefore done in parallel with atomicMin on a per-slot owner rank;
+ *   * a doubling is khashl's in-place kick-out rehash (khashl.h:171-189), whose placement order is
+ *     data dependent: executed literally by one lane;
+ *   * growth happens at the next put-call once count >= 0.75 capacity (khashl.h:202), including a
+ *     trailing put-call on an existing key (lastput vs. time of the last new key).
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ bool bm_get(const u32 *u, u32 i) { return u[i >> 5] >> (i & 31) & 1; }
+
+__device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 nbits_new)
+{
+	const u32 Nmask = N - 1;
+	for (u32 jw = 0; jw < (n + 31) / 32; ++jw) {
+		while (cur[jw]) {                                  /* next still-unmoved old slot of this word */
+			const u32 j = jw * 32 + (__ffs((int)cur[jw]) - 1);
+			if (j >= n) { cur[jw] = 0; break; }
+			u64 key = keys[j];
+			cur[jw] &= cur[jw] - 1;
+			for (;;) {
+				u32 i = yk_h2b((u32)(key >> 10), nbits_new);
+				while (bm_get(oth, i)) i = (i + 1) & Nmask;
+				oth[i >> 5] |= 1u << (i & 31);
+				if (i < n && bm_get(cur, i)) {
+					const u64 tmp = keys[i]; keys[i] = key; key = tmp;
+					cur[i >> 5] &= ~(1u << (i & 31));
+				} else { keys[i] = key; break; }
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used,
+              u32 *scr_used, u32 *scr_owner, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
+              u32 *out_bits, u32 *out_count)
+{
+	const ReplayTask T = tasks[blockIdx.x];
+	const int tid = threadIdx.x;
+	u64 *keys = new_keys + T.new_off;
+	u32 *UA = new_used + (T.new_off >> 5), *UB = scr_used + (T.new_off >> 5);
+	u32 *owner = scr_owner + T.new_off;
+	u32 *cur = UA, *oth = UB;
+	u32 n = T.old_bits == YK_NOCAP ? 0 : 1u << T.old_bits, bits = T.old_bits == YK_NOCAP ? 0 : T.old_bits;
+	u32 cnt = T.old_count;
+
+	for (u32 i = tid; i < n; i += 256) keys[i] = old_keys[T.old_off + i];
+	for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = old_used[(T.old_off >> 5) + w];
+	if (n == 0 && T.init_bits != YK_NOCAP) {                 /* yak_ht_resize(f, size) on an empty set (htab.c:186) */
+		bits = T.init_bits; n = 1u << bits;
+		for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = 0;
+	}
+	block_sync_global();
+
+	u32 i0 = 0;
+	for (;;) {
+		const u32 thr = (n >> 1) + (n >> 2);
+		bool grow = false;
+		if (i0 < T.m) grow = cnt >= thr;
+		else {
+			/* all new keys are in; one more doubling if a put-call follows the moment the load hit 75 % */
+			const u64 lp = lastput ? lastput[blockIdx.x] : 0;
+			const bool later_put = lp != 0 && (T.m == 0 || lp - 1 > rec_t[T.rec_off + T.m - 1]);
+			grow = later_put && cnt >= thr && i0 != 0xffffffffu;
+			if (!grow) break;
+			i0 = 0xffffffffu;                              /* at most one trailing doubling */
+		}
+		if (grow) {
+			const u32 N = n ? n << 1 : 4, nb = n ? bits + 1 : 2;
+			for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = 0;
+			block_sync_global();
+			if (tid == 0) replay_double(keys, cur, oth, n, N, nb);
+			block_sync_global();
+			u32 *t = cur; cur = oth; oth = t;
+			n = N; bits = nb;
+			if (i0 == 0xffffffffu) break;
+			continue;
+		}
+		/* FCFS placement of the next keys, up to the growth threshold */
+		const u32 batch = (T.m - i0 < thr - cnt) ? T.m - i0 : thr - cnt;
+		const u32 nmask = n - 1;
+		for (u32 i = tid; i < n; i += 256) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
+		block_sync_global();
+		for (u32 q = tid; q < batch; q += 256) {
+			u32 r = q + 1;
+			u32 slot = yk_h2b((u32)(rec_kc[T.rec_off + i0 + q] >> 10), bits);
+			for (;;) {
+				const u32 old = atomicMin(&owner[slot], r);
+				if (old == 0xffffffffu) break;
+				if (old > r) {                            /* we took the slot; carry the displaced later key on */
+					r = old;
+				}
+				slot = (slot + 1) & nmask;
+			}
+		}
+		block_sync_global();
+		for (u32 i = tid; i < n; i += 256) {
+			const u32 o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (o != 0 && o != 0xffffffffu) {
+				keys[i] = rec_kc[T.rec_off + i0 + o - 1];
+				atomicOr(&cur[i >> 5], 1u << (i & 31));
+			}
+		}
+		block_sync_global();
+		cnt += batch; i0 += batch;
+	}
+	block_sync_global();
+	/* publish: bitmap in the arena, unused slots normalised to YK_EMPTY */
+	if (cur != UA) for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = cur[w];
+	for (u32 i = tid; i < n; i += 256) if (!bm_get(cur, i)) keys[i] = YK_EMPTY;
+	if (tid == 0) { out_bits[blockIdx.x] = n ? bits : YK_NOCAP; out_count[blockIdx.x] = cnt; }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * shrink (reference htab.c:180-197): keys with min <= count <= max, in ascending OLD slot order
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ bool shrink_keep(const ImgView &img, u64 a, int cmin, int cmax)
+{
+	if (!(img.used[a >> 5] >> (a & 31) & 1)) return false;
+	const int c = (int)(img.keys[a] & 1023);
+	return c >= cmin && c <= cmax;
+}
+
+__global__ __launch_bounds__(256)
+void k_shrink_count(ImgView img, int cmin, int cmax, u32 *seg_cnt)
+{
+	__shared__ u32 s_tot;
+	const u32 bits = img.bits[blockIdx.x];
+	if (threadIdx.x == 0) s_tot = 0;
+	__syncthreads();
+	if (bits != YK_NOCAP) {
+		const u64 off = img.off[blockIdx.x];
+		u32 c = 0;
+		for (u32 i = threadIdx.x; i < 1u << bits; i += 256) c += shrink_keep(img, off + i, cmin, cmax);
+		for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+		if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_tot, c);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) seg_cnt[blockIdx.x] = s_tot;
+}
+
+__global__ __launch_bounds__(256)
+void k_shrink_scatter(ImgView img, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc)
+{
+	__shared__ u32 s_w[4];
+	const u32 bits = img.bits[blockIdx.x];
+	if (bits == YK_NOCAP) return;
+	const u64 off = img.off[blockIdx.x];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	u64 out = seg_off[blockIdx.x];
+	for (u32 base = 0; base < 1u << bits; base += 256) {
+		const u32 i = base + threadIdx.x;
+		const bool keep = i < 1u << bits && shrink_keep(img, off + i, cmin, cmax);
+		const u64 b = __ballot(keep);
+		if (lane == 0) s_w[wave] = __popcll(b);
+		__syncthreads();
+		u32 pre = 0, tot = 0;
+		for (int w = 0; w < 4; ++w) { if (w < wave) pre += s_w[w]; tot += s_w[w]; }
+		if (keep) rec_kc[out + pre + __popcll(b & lanemask_lt())] = img.keys[off + i];
+		out += tot;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_fill_u64(u64 *p, u64 v, u64 n)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * launch wrappers
+ * ------------------------------------------------------------------------------------------ */
+static inline int grid_for(u64 n, int per_block = 256, int cap = 256 * 8)
+{
+	u64 g = (n + per_block - 1) / per_block;
+	if (g < 1) g = 1;
+	if (g > (u64)cap) g = cap;            /* 256 CUs x 8 workgroups, grid-stride beyond that */
+	return (int)g;
+}
+
+extern "C" {
+
+/* k-mers ENDING at positions [pos0, n) of `bases` (bytes before pos0 are read as left context);
+ * emitted position = index in `bases` - t_sub */
+void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+                       u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st)
+{
+	if (n <= pos0) return;
+	const u64 tiles = ((u64)(n - pos0) + XT_TILE - 1) / XT_TILE;
+	hipLaunchKernelGGL(k_extract, dim3((unsigned)tiles), dim3(XT_THREADS), 0, st, bases, pos0, n, t_sub, k, pre, plo, phi, out_hash, out_t, cursor);
+}
+
+void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_acc_init, dim3(grid_for(n)), dim3(256), 0, st, s, n);
+}
+
+void yk_launch_acc_insert(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, AccTab tab, ImgView img,
+                          int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_acc_insert, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, tlo, n, t0, tab, img, img_nonempty, bloom_mode, newlist, counters);
+}
+
+void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_acc_rehash, dim3(grid_for(oldt.mask + 1)), dim3(256), 0, st, oldt, newt);
+}
+
+void yk_launch_img_count(const u64 *hash, int64_t n, ImgView img, hipStream_t st)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_img_count, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, n, img);
+}
+
+void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st)
+{
+	if (n_slots) hipLaunchKernelGGL(k_img_fold, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots);
+}
+
+void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st)
+{
+	if (n_slots) hipLaunchKernelGGL(k_img_clear, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots);
+}
+
+void yk_launch_lastput(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
+                       int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch, hipStream_t st)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_lastput, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, tlo, n, t0, t_from, tab, img, img_nonempty, bloom_mode, only_missing, lp_batch);
+}
+
+void yk_launch_lastput_merge(u64 *lastput, const u64 *lp_batch, u32 *missing, u32 *n_missing, int P, int plo, int phi, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_lastput_merge, dim3((P + 255) / 256), dim3(256), 0, st, lastput, lp_batch, missing, n_missing, P, plo, phi);
+}
+
+void yk_launch_bf_test(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, u64 *miss, hipStream_t st)
+{
+	if (n_new) hipLaunchKernelGGL(k_bf_test, dim3(grid_for(n_new)), dim3(256), 0, st, tab, newlist, n_new, bf, miss);
+}
+
+void yk_launch_bf_set(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                      u32 *multi, int multi_bits, u64 *counters, hipStream_t st)
+{
+	if (n_new) hipLaunchKernelGGL(k_bf_set, dim3(grid_for(n_new)), dim3(256), 0, st, tab, newlist, n_new, bf, miss, multi, multi_bits, counters);
+}
+
+void yk_launch_bf_check(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                        const u32 *multi, int multi_bits, u64 *cand, u64 *counters, hipStream_t st)
+{
+	if (n_new) hipLaunchKernelGGL(k_bf_check, dim3(grid_for(n_new)), dim3(256), 0, st, tab, newlist, n_new, bf, miss, multi, multi_bits, cand, counters);
+}
+
+void yk_launch_bf_mapfill(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                          const u32 *multi, int multi_bits, u64 *map, int map_bits, hipStream_t st)
+{
+	if (n_new) hipLaunchKernelGGL(k_bf_mapfill, dim3(grid_for(n_new)), dim3(256), 0, st, tab, newlist, n_new, bf, miss, multi, multi_bits, map, map_bits);
+}
+
+void yk_launch_bf_resolve(AccTab tab, const u64 *newlist, const u64 *cand, u64 n_cand, BloomView bf,
+                          const u64 *miss, const u64 *map, int map_bits, hipStream_t st)
+{
+	if (n_cand) hipLaunchKernelGGL(k_bf_resolve, dim3(grid_for(n_cand)), dim3(256), 0, st, tab, newlist, cand, n_cand, bf, miss, map, map_bits);
+}
+
+void yk_launch_select_count(AccTab tab, int bloom_mode, int P, u32 *seg_cnt, hipStream_t st)
+{
+	(void)P;
+	hipLaunchKernelGGL(k_select_count, dim3(grid_for(tab.mask + 1)), dim3(256), 0, st, tab, bloom_mode, seg_cnt);
+}
+
+void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_off, u32 *seg_cur,
+                              u64 *rec_kc, u64 *rec_t, hipStream_t st)
+{
+	(void)P;
+	hipLaunchKernelGGL(k_select_scatter, dim3(grid_for(tab.mask + 1)), dim3(256), 0, st, tab, bloom_mode, seg_off, seg_cur, rec_kc, rec_t);
+}
+
+void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
+                             u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_off, src_kc, src_t, dst_kc, dst_t, shift);
+}
+
+void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
+                      u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner,
+                      const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
+                      u32 *out_bits, u32 *out_count, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(256), 0, st, tasks, old_keys, old_used, new_keys, new_used,
+	                   scr_used, scr_owner, rec_kc, rec_t, lastput, out_bits, out_count);
+}
+
+void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_shrink_count, dim3(P), dim3(256), 0, st, img, cmin, cmax, seg_cnt);
+}
+
+void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_shrink_scatter, dim3(P), dim3(256), 0, st, img, cmin, cmax, seg_off, rec_kc);
+}
+
+void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st)
+{
+	if (n) hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
+}
+
+} /* extern "C" */

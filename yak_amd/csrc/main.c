@@ -1,0 +1,72 @@
+/*
+ * main.c -- `yak-amd count`: the caller side of the hot path, i.e. what reference main.c:13-64
+ * (main_count) does, written in C against include/yak.h only.  It exists to show that the
+ * library is a drop-in: the protocol below is the reference's, line for line in meaning
+ * (count -> [destroy_bf, clear, second pass, shrink] -> dump).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "yak.h"
+
+static long long parse_num(const char *s)                    /* K/M/G suffixes as yak-priv.h:75-84 */
+{
+	char *p;
+	double x = strtod(s, &p);
+	if (*p == 'G' || *p == 'g') x *= 1e9;
+	else if (*p == 'M' || *p == 'm') x *= 1e6;
+	else if (*p == 'K' || *p == 'k') x *= 1e3;
+	return (long long)(x + .499);
+}
+
+int main(int argc, char *argv[])
+{
+	yak_copt_t opt;
+	yak_ch_t *h;
+	const char *fn_out = 0;
+	int c;
+	if (argc < 2 || strcmp(argv[1], "count") != 0) {
+		fprintf(stderr, "Usage: yak-amd count [options] <in.fa> [in.fa]\n");
+		return 1;
+	}
+	--argc, ++argv;
+	yak_copt_init(&opt);
+	while ((c = getopt(argc, argv, "k:p:K:t:b:H:o:")) >= 0) {
+		if (c == 'k') opt.k = atoi(optarg);
+		else if (c == 'p') opt.pre = atoi(optarg);
+		else if (c == 'K') opt.chunk_size = parse_num(optarg);
+		else if (c == 't') opt.n_thread = atoi(optarg);
+		else if (c == 'b') opt.bf_shift = atoi(optarg);
+		else if (c == 'H') opt.bf_n_hash = (int)parse_num(optarg);
+		else if (c == 'o') fn_out = optarg;
+	}
+	if (argc - optind < 1) {
+		fprintf(stderr, "Usage: yak-amd count [options] <in.fa> [in.fa]\n");
+		fprintf(stderr, "Options:\n");
+		fprintf(stderr, "  -k INT     k-mer size [%d]\n", opt.k);
+		fprintf(stderr, "  -p INT     prefix length [%d]\n", opt.pre);
+		fprintf(stderr, "  -b INT     set Bloom filter size to 2**INT bits; 0 to disable [%d]\n", opt.bf_shift);
+		fprintf(stderr, "  -H INT     use INT hash functions for Bloom filter [%d]\n", opt.bf_n_hash);
+		fprintf(stderr, "  -t INT     number of host worker threads [%d]\n", opt.n_thread);
+		fprintf(stderr, "  -o FILE    dump the count hash table to FILE []\n");
+		fprintf(stderr, "  -K INT     chunk size [100m]\n");
+		return 1;
+	}
+	if (opt.pre < YAK_COUNTER_BITS) { fprintf(stderr, "ERROR: -p should be at least %d\n", YAK_COUNTER_BITS); return 1; }
+	if (opt.k >= 64) { fprintf(stderr, "ERROR: -k must be smaller than 64\n"); return 1; }
+	else if (opt.k >= 32) fprintf(stderr, "WARNING: counts are inexact if -k is greater than 31\n");
+	h = yak_count(argv[optind], &opt, 0);
+	if (h == 0) { fprintf(stderr, "ERROR: counting failed (input unreadable or no MI355X available)\n"); return 2; }
+	if (opt.bf_shift > 0) {
+		yak_ch_destroy_bf(h);
+		yak_ch_clear(h, opt.n_thread);
+		h = yak_count(argc - optind >= 2 ? argv[optind + 1] : argv[optind], &opt, h);
+		if (h == 0) return 2;
+		yak_ch_shrink(h, 2, YAK_MAX_COUNT, opt.n_thread);
+		fprintf(stderr, "[M::%s] %ld distinct k-mers after shrinking\n", __func__, (long)h->tot);
+	}
+	if (fn_out) yak_ch_dump(h, fn_out);
+	yak_ch_destroy(h);
+	return 0;
+}

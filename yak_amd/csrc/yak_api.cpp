@@ -1,0 +1,440 @@
+/*
+ * yak_api.cpp -- the drop-in C surface (include/yak.h) on top of the HBM-resident engine.
+ *
+ * Every function keeps the reference's name, argument meaning, return convention and messages
+ * (reference file:line cited per function).  Host work here is orchestration only: parsing the
+ * input file, staging bases, writing the .yak file from the host mirror.  All counting, bloom
+ * gating, table layout, clearing and shrinking run in the HIP kernels of kernels.hip.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <assert.h>
+#include <zlib.h>
+#include <sys/time.h>
+#include <sys/resource.h>
+#include <vector>
+#include "engine.h"
+
+struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };
+struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; uint32_t magic; };
+#define EXT_MAGIC 0x59414b41u
+
+extern "C" {
+
+int yak_verbose = 3;                                         /* reference sys.c:5 */
+
+unsigned char seq_nt4_table[256] = {                         /* reference misc.c:4-21 */
+#define R4(v) v, v, v, v
+#define R16(v) R4(v), R4(v), R4(v), R4(v)
+	0, 1, 2, 3, R4(4), R4(4), R4(4),
+	R16(4), R16(4), R16(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4)
+#undef R16
+#undef R4
+};
+
+static double yk_realtime0 = -1;
+static double yk_realtime(void)
+{
+	struct timeval tp;
+	gettimeofday(&tp, 0);
+	const double t = tp.tv_sec + tp.tv_usec * 1e-6;
+	if (yk_realtime0 < 0) yk_realtime0 = t;
+	return t - yk_realtime0;
+}
+static double yk_cputime(void)
+{
+	struct rusage r;
+	getrusage(RUSAGE_SELF, &r);
+	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+void yak_copt_init(yak_copt_t *o)                            /* reference misc.c:23-32 */
+{
+	memset(o, 0, sizeof(*o));
+	o->bf_shift = 0; o->bf_n_hash = 4; o->k = 31; o->pre = 10; o->n_thread = 4;
+	o->chunk_size = 10000000;
+}
+
+/* ---- stand-alone host bloom filter: API completeness only (reference bbf.c); the counting path
+ * keeps its filters in HBM and never calls these ---- */
+yak_bf_t *yak_bf_init(int n_shift, int n_hashes)
+{
+	if (n_shift + YAK_BLK_SHIFT > 64 || n_shift < YAK_BLK_SHIFT) return 0;
+	yak_bf_t *b = (yak_bf_t*)calloc(1, sizeof(*b));
+	void *p = 0;
+	b->n_shift = n_shift; b->n_hashes = n_hashes;
+	if (posix_memalign(&p, 64, (size_t)1 << (n_shift - 3)) != 0) { free(b); return 0; }
+	memset(p, 0, (size_t)1 << (n_shift - 3));
+	b->b = (uint8_t*)p;
+	return b;
+}
+
+void yak_bf_destroy(yak_bf_t *b) { if (b) { free(b->b); free(b); } }
+
+int yak_bf_insert(yak_bf_t *b, uint64_t hash)
+{
+	const int lgblk = b->n_shift - YAK_BLK_SHIFT;
+	uint8_t *blk = b->b + ((hash & ((1ULL << lgblk) - 1)) << 6);
+	int z = (int)(hash >> lgblk) & YAK_BLK_MASK, step = (int)(hash >> b->n_shift) & YAK_BLK_MASK, hits = 0;
+	if ((step & 31) == 0) step = (step + 1) & YAK_BLK_MASK;
+	for (int i = 0; i < b->n_hashes; ++i, z = (z + step) & YAK_BLK_MASK) {
+		hits += blk[z >> 3] >> (z & 7) & 1;
+		blk[z >> 3] |= (uint8_t)(1 << (z & 7));
+	}
+	return hits;
+}
+
+/* ---- table life cycle (reference htab.c:13-49) ---- */
+yak_ch_t *yak_ch_init(int k, int pre, int n_hash, int n_shift)
+{
+	if (pre < YAK_COUNTER_BITS) return 0;
+	yakamd_ctx *ctx = yk_ctx_create(k, pre, n_hash, n_shift);
+	if (!ctx) return 0;                                      /* no GPU: fail, never count on the CPU */
+	yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
+	e->ctx = ctx; e->magic = EXT_MAGIC;
+	yak_ch_t *h = &e->pub;
+	h->k = k; h->pre = pre;
+	h->h = (yak_ch1_t*)calloc((size_t)1 << pre, sizeof(yak_ch1_t));
+	if (n_hash > 0 && n_shift > pre) {
+		h->n_hash = n_hash; h->n_shift = n_shift;
+		if (n_shift - pre >= YAK_BLK_SHIFT && n_shift - pre + YAK_BLK_SHIFT <= 64) {
+			/* descriptors only: the bits live in HBM (b == NULL on the host side) */
+			yak_bf_t *bf = (yak_bf_t*)calloc((size_t)1 << pre, sizeof(yak_bf_t));
+			for (int i = 0; i < 1 << pre; ++i) { bf[i].n_shift = n_shift - pre; bf[i].n_hashes = n_hash; h->h[i].b = &bf[i]; }
+		}
+	}
+	yk_ctx_sync_host(ctx, h);
+	return h;
+}
+
+void yak_ch_destroy_bf(yak_ch_t *h)
+{
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (h->h[0].b) free(h->h[0].b);                          /* one block of descriptors */
+	for (int i = 0; i < 1 << h->pre; ++i) h->h[i].b = 0;
+	yk_ctx_destroy_bf(e->ctx);
+}
+
+void yak_ch_destroy(yak_ch_t *h)
+{
+	if (h == 0) return;
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	yak_ch_destroy_bf(h);
+	yk_ctx_destroy(e->ctx);
+	free(h->h); free(e);
+}
+
+/* ---- reference htab.c:51-78.  The list is one bucket of hashed k-mers sharing a prefix; list
+ * order is stream order.  Runs as a one-batch device pass. ---- */
+int yak_ch_insert_list(yak_ch_t *h, int create_new, int n, const uint64_t *a)
+{
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (n <= 0) return 0;
+	const uint64_t pm = (1ULL << h->pre) - 1;
+	std::vector<uint64_t> hv; std::vector<uint32_t> tv;
+	hv.reserve(n); tv.reserve(n);
+	for (int j = 0; j < n; ++j)
+		if ((a[j] & pm) == (a[0] & pm)) { hv.push_back(a[j]); tv.push_back((uint32_t)j); }   /* htab.c:61 */
+	uint64_t *d_h = 0; uint32_t *d_t = 0;
+	hipSetDevice(yk_ctx_device(e->ctx));
+	if (hipMalloc((void**)&d_h, hv.size() * 8) != hipSuccess || hipMalloc((void**)&d_t, hv.size() * 4) != hipSuccess) return 0;
+	hipMemcpy(d_h, hv.data(), hv.size() * 8, hipMemcpyHostToDevice);
+	hipMemcpy(d_t, tv.data(), tv.size() * 4, hipMemcpyHostToDevice);
+	int64_t n_ins = 0;
+	const uint64_t t0 = yk_ctx_list_time(e->ctx, (uint64_t)n);
+	if (yakamd_pass_begin(h, create_new) == 0) {
+		yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)hv.size(), t0, (uint64_t)n);
+		n_ins = yakamd_pass_end(h);
+	}
+	hipFree(d_h); hipFree(d_t);
+	return n_ins < 0 ? 0 : (int)n_ins;
+}
+
+static inline uint32_t ht_cap(const yak_ht_t *g) { return g->keys ? 1U << g->bits : 0U; }
+
+static uint32_t ht_get(const yak_ht_t *g, uint64_t key)      /* khashl.h:137-150 on the host mirror */
+{
+	if (g->keys == 0) return 0;
+	const uint32_t n = 1U << g->bits, mask = n - 1;
+	uint32_t i = (uint32_t)((uint32_t)(key >> YAK_COUNTER_BITS) * 2654435769U) >> (32 - g->bits), first = i;
+	while ((g->used[i >> 5] >> (i & 31) & 1) && g->keys[i] >> YAK_COUNTER_BITS != key >> YAK_COUNTER_BITS) {
+		i = (i + 1) & mask;
+		if (i == first) return n;
+	}
+	return (g->used[i >> 5] >> (i & 31) & 1) ? i : n;
+}
+
+int yak_ch_get(const yak_ch_t *h, uint64_t x)                /* reference htab.c:93-100 */
+{
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (yk_ctx_sync_host(e->ctx, (yak_ch_t*)h)) return -1;
+	const yak_ht_t *g = h->h[x & ((1ULL << h->pre) - 1)].h;
+	const uint32_t i = ht_get(g, x >> h->pre << YAK_COUNTER_BITS);
+	return i == ht_cap(g) ? -1 : (int)(g->keys[i] & YAK_MAX_COUNT);
+}
+
+int yak_ch_inc(yak_ch_t *h, uint64_t x)                      /* reference htab.c:80-91 */
+{
+	const int c = yak_ch_get(h, x);
+	if (c < 0) return -1;
+	yak_ch_insert_list(h, 0, 1, &x);                         /* one-element device pass keeps HBM authoritative */
+	return c < YAK_MAX_COUNT ? c + 1 : c;
+}
+
+void yak_ch_clear(yak_ch_t *h, int n_thread)                 /* reference htab.c:127-130 */
+{
+	(void)n_thread;
+	yk_ctx_clear(((yak_ch_ext*)h)->ctx);
+}
+
+void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread) /* reference htab.c:199-208 */
+{
+	(void)n_thread;
+	unsigned long long tot = 0;
+	const int hi = (max >= min && max <= YAK_MAX_COUNT) ? max : YAK_MAX_COUNT;
+	if (yk_ctx_shrink(((yak_ch_ext*)h)->ctx, min, hi, &tot) == 0) h->tot = tot;
+}
+
+void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread) /* reference htab.c:156-169 */
+{
+	(void)n_thread;
+	memset(cnt, 0, YAK_N_COUNTS * sizeof(int64_t));
+	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, (yak_ch_t*)h)) return;
+	for (int p = 0; p < 1 << h->pre; ++p) {
+		const yak_ht_t *g = h->h[p].h;
+		for (uint32_t i = 0, n = ht_cap(g); i < n; ++i)
+			if (g->used[i >> 5] >> (i & 31) & 1) ++cnt[g->keys[i] & YAK_MAX_COUNT];
+	}
+}
+
+static uint64_t hash64_inv(uint64_t x, uint64_t m)           /* reference yak-priv.h:41-68 */
+{
+	uint64_t t;
+	t = x - (x << 31); x = (x - (t << 31)) & m;
+	t = x ^ x >> 28; x = x ^ t >> 28;
+	x = (x * 14933078535860113213ULL) & m;
+	t = x ^ x >> 14; t = x ^ t >> 14; t = x ^ t >> 14; x = x ^ t >> 14;
+	x = (x * 15244667743933553977ULL) & m;
+	t = x ^ x >> 24; x = x ^ t >> 24;
+	t = ~x; t = ~(x - (t << 21)); t = ~(x - (t << 21)); x = ~(x - (t << 21)) & m;
+	return x;
+}
+
+yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n) /* reference htab.c:353-367 */
+{
+	assert(h->k < 32 && w < 1 << h->pre);
+	*n = 0;
+	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, (yak_ch_t*)h)) return 0;
+	const yak_ht_t *g = h->h[w].h;
+	const uint64_t mask = (1ULL << h->k * 2) - 1;
+	yak_knt_t *a = (yak_knt_t*)calloc(g->count ? g->count : 1, sizeof(*a));
+	uint32_t j = 0;
+	for (uint32_t i = 0, cap = ht_cap(g); i < cap; ++i)
+		if (g->used[i >> 5] >> (i & 31) & 1) {
+			a[j].x = hash64_inv(g->keys[i] >> YAK_COUNTER_BITS << h->pre | (uint64_t)w, mask);
+			a[j++].c = (int)(g->keys[i] & YAK_MAX_COUNT);
+		}
+	*n = g->count;
+	return a;
+}
+
+/* ---- .yak serialisation (reference htab.c:373-394): header, then per sub-table capacity, size and
+ * the keys in ascending slot order ---- */
+int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out)
+{
+	*out = 0;
+	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, h)) return -1;
+	const int P = 1 << h->pre;
+	size_t sz = 16 + (size_t)8 * P;
+	for (int p = 0; p < P; ++p) sz += (size_t)8 * h->h[p].h->count;
+	uint8_t *o = (uint8_t*)malloc(sz);
+	uint32_t t[3] = { (uint32_t)h->k, (uint32_t)h->pre, YAK_COUNTER_BITS };
+	memcpy(o, YAK_MAGIC, 4); memcpy(o + 4, t, 12);
+	size_t off = 16;
+	for (int p = 0; p < P; ++p) {
+		const yak_ht_t *g = h->h[p].h;
+		const uint32_t cap = ht_cap(g);
+		t[0] = cap; t[1] = g->count;
+		memcpy(o + off, t, 8); off += 8;
+		uint64_t *dst = (uint64_t*)(o + off);
+		uint32_t j = 0;
+		for (uint32_t w = 0; w < (cap + 31) / 32; ++w) {
+			uint32_t bits = g->used[w];
+			while (bits) { const uint32_t i = w * 32 + __builtin_ctz(bits); bits &= bits - 1; if (i < cap) dst[j++] = g->keys[i]; }
+		}
+		off += (size_t)8 * j;
+	}
+	*out = o;
+	return (int64_t)sz;
+}
+
+int yak_ch_dump(const yak_ch_t *h, const char *fn)
+{
+	FILE *fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout;
+	if (fp == 0) return -1;
+	uint8_t *buf = 0;
+	const int64_t sz = yakamd_dump_mem((yak_ch_t*)h, &buf);
+	if (sz < 0) { if (fp != stdout) fclose(fp); return -1; }
+	fwrite(buf, 1, (size_t)sz, fp);
+	free(buf);
+	fprintf(stderr, "[M::%s] dumpped the hash table to file '%s'.\n", __func__, fn);
+	if (fp != stdout) fclose(fp); else fflush(fp);
+	return 0;
+}
+
+/* reference htab.c:396-481 (mode YAK_LOAD_ALL): every sub-table is pre-sized to the saved
+ * capacity and the keys are put back in file order -- the same staged FCFS replay as shrink */
+yak_ch_t *yak_ch_restore(const char *fn)
+{
+	FILE *fp = fopen(fn, "rb");
+	char magic[4];
+	uint32_t t[3];
+	if (fp == 0) return 0;
+	if (fread(magic, 1, 4, fp) != 4) { fclose(fp); return 0; }
+	if (strncmp(magic, YAK_MAGIC, 4) != 0) { fprintf(stderr, "ERROR: wrong file magic.\n"); fclose(fp); return 0; }
+	if (fread(t, 4, 3, fp) != 3) { fclose(fp); return 0; }
+	if (t[2] != YAK_COUNTER_BITS) {
+		fprintf(stderr, "ERROR: saved counter bits: %d; compile-time counter bits: %d\n", t[2], YAK_COUNTER_BITS);
+		fclose(fp); return 0;
+	}
+	yak_ch_t *h = yak_ch_init((int)t[0], (int)t[1], 0, 0);
+	if (h == 0) { fclose(fp); return 0; }
+	const int P = 1 << h->pre;
+	std::vector<uint32_t> caps(P, 0), sizes(P, 0);
+	std::vector<uint64_t> keys;
+	for (int p = 0; p < P; ++p) {
+		uint32_t u[2];
+		if (fread(u, 4, 2, fp) != 2) break;
+		caps[p] = u[0]; sizes[p] = u[1];
+		const size_t at = keys.size();
+		keys.resize(at + u[1]);
+		if (u[1] && fread(&keys[at], 8, u[1], fp) != u[1]) break;
+	}
+	fclose(fp);
+	if (yk_ctx_load(((yak_ch_ext*)h)->ctx, caps.data(), sizes.data(), keys.data()) != 0) { yak_ch_destroy(h); return 0; }
+	fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", "yak_ch_restore_core", (long)keys.size(), (long)keys.size());
+	return h;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FASTA/FASTQ record reader with the observable behaviour of the reference's parser as driven by
+ * count.c:88-110 (record grammar of kseq.h:192-232): header lines start with '>' or '@', the
+ * sequence is every following line up to one starting with '>', '@' or '+', a '+' line introduces
+ * quality lines covering at least the sequence length; a truncated quality ends the input.
+ * ------------------------------------------------------------------------------------------ */
+struct FxReader {
+	gzFile fp; unsigned char *buf; int beg, end, eof, last;
+	std::vector<char> seq; size_t qlen; int qlast;
+	enum { BUF = 1 << 16 };
+	FxReader() : fp(0), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0) {}
+	bool fill() {
+		if (beg < end) return true;
+		if (eof) return false;
+		beg = 0; end = gzread(fp, buf, BUF);
+		if (end < BUF) eof = 1;
+		if (end <= 0) { end = 0; return false; }
+		return true;
+	}
+	int getc() { return fill() ? buf[beg++] : -1; }
+	/* consume through the next delimiter; what: 0 discard, 1 append to seq, 2 count quality bytes */
+	int until(bool line, int what, int *dret) {
+		if (dret) *dret = 0;
+		if (beg >= end && eof) return -1;
+		while (fill()) {
+			int i = beg;
+			if (line) { const unsigned char *q = (const unsigned char*)memchr(buf + beg, '\n', end - beg); i = q ? (int)(q - buf) : end; }
+			else while (i < end && !isspace(buf[i])) ++i;
+			if (what == 1) seq.insert(seq.end(), buf + beg, buf + i);
+			else if (what == 2 && i > beg) { qlen += i - beg; qlast = buf[i - 1]; }
+			const bool hit = i < end;
+			if (hit && dret) *dret = buf[i];
+			beg = i + 1;
+			if (hit) break;
+		}
+		if (line && what == 1 && seq.size() > 1 && seq.back() == '\r') seq.pop_back();
+		if (line && what == 2 && qlen > 1 && qlast == '\r') { --qlen; qlast = 0; }
+		return 0;
+	}
+	int64_t next() {
+		int c, d;
+		if (last == 0) {
+			while ((c = getc()) != -1 && c != '>' && c != '@') {}
+			if (c == -1) return -1;
+			last = c;
+		}
+		seq.clear(); qlen = 0; qlast = 0;
+		if (until(false, 0, &d) < 0) return -1;
+		if (d != '\n') until(true, 0, 0);
+		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n') continue;
+			seq.push_back((char)c);
+			until(true, 1, 0);
+		}
+		if (c == '>' || c == '@') last = c;
+		if (c != '+') return (int64_t)seq.size();
+		while ((c = getc()) != -1 && c != '\n') {}
+		if (c == -1) return -2;
+		while (until(true, 2, 0) >= 0 && qlen < seq.size()) {}
+		last = 0;
+		return qlen == seq.size() ? (int64_t)seq.size() : -2;
+	}
+};
+
+/* reference count.c:147-166 */
+yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
+{
+	FxReader fx;
+	fx.fp = (fn == 0 || strcmp(fn, "-") == 0) ? gzdopen(0, "r") : gzopen(fn, "r");
+	if (fx.fp == 0) return 0;                                /* count.c:152 */
+	yak_ch_t *h;
+	int create_new;
+	if (h0) {
+		assert(h0->k == opt->k && h0->pre == opt->pre);      /* count.c:157 */
+		h = h0; create_new = 0;
+	} else {
+		create_new = 1;
+		h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
+		if (h == 0) { gzclose(fx.fp); return 0; }
+	}
+	fx.buf = (unsigned char*)malloc(FxReader::BUF);
+	yk_realtime();
+	int ok = yakamd_pass_begin(h, create_new) == 0;
+	std::vector<char> chunk;
+	chunk.reserve((size_t)std::min<int64_t>(opt->chunk_size + (opt->chunk_size >> 3) + 65536, (int64_t)1 << 31));
+	uint64_t t0 = 0;
+	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
+	auto flush = [&]() {
+		if (!chunk.empty() && ok) ok = yakamd_feed_bases_host(h, chunk.data(), (int64_t)chunk.size(), t0) == 0;
+		t0 += chunk.size();
+		n_seq_tot += n_seq;
+		fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq);
+		chunk.clear(); sum_len = 0; n_seq = 0;
+	};
+	while (ok && (l = fx.next()) >= 0) {                     /* count.c:93 */
+		if (l < opt->k) continue;                            /* count.c:95 */
+		chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end());
+		chunk.push_back('\n');                                /* a non-ACGT byte ends the read (count.c:41) */
+		sum_len += l; ++n_seq;
+		if (sum_len >= opt->chunk_size || chunk.size() > ((size_t)1 << 31)) flush();   /* count.c:106 */
+	}
+	if (n_seq) flush();
+	if (ok) {
+		const int64_t n_ins = yakamd_pass_end(h);
+		if (n_ins < 0) ok = 0; else h->tot += (uint64_t)n_ins;   /* count.c:138 */
+	}
+	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table\n", "yak_count",
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot);
+	free(fx.buf);
+	gzclose(fx.fp);
+	if (!ok) { if (!h0) yak_ch_destroy(h); return 0; }
+	return h;
+}
+
+} /* extern "C" */

@@ -1,0 +1,114 @@
+/*
+ * yk_device.h -- shared declarations between the HIP kernels (kernels.hip) and the host engine
+ * (engine.cpp).  Internal; the public surface is include/yak.h + include/yak_amd.h.
+ */
+#ifndef YK_DEVICE_H
+#define YK_DEVICE_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define YK_EMPTY   0xFFFFFFFFFFFFFFFFull     /* unclaimed slot (accumulator and table image) */
+#define YK_TINF    0xFFFFFFFFFFFFFFFFull     /* "never" */
+#define YK_NOCAP   0xFFFFFFFFu               /* sub-table without a slot array (kh_capacity == 0) */
+#define YK_FLAG_FP 1u                        /* first occurrence passed the bloom gate */
+
+/* accumulator slot: one per distinct hashed k-mer seen by the current pass (32 B, one sector) */
+struct __attribute__((aligned(32))) AccSlot {
+	u64 key;        /* full yak_hash64 value, YK_EMPTY if free */
+	u64 t1;         /* stream position of the first occurrence  (atomicMin) */
+	u64 t2;         /* stream position of the second occurrence (atomicMin of the losers) */
+	u32 cnt;        /* occurrences (exact up to 2^32-1, clamped to 1023 on output) */
+	u32 flags;
+};
+
+struct AccTab {
+	AccSlot *s;
+	u64 mask;       /* capacity - 1 */
+	int bits;       /* log2 capacity, >= pre + 1 */
+	int pre;
+};
+
+/* device-resident image of the 1<<pre khashl tables (exact layout) */
+struct ImgView {
+	const u32 *bits;    /* [P] log2 capacity or YK_NOCAP */
+	const u64 *off;     /* [P] first slot in the arena (multiple of 32) */
+	u64 *keys;          /* arena: (hash>>pre)<<10 | count, YK_EMPTY in unused slots */
+	u32 *used;          /* arena bitmap, bit i <-> arena slot i */
+	u32 *delta;         /* per-slot pending count increments of the running pass (may be 0) */
+	int pre;
+	int k;
+};
+
+/* bloom geometry (reference bbf.c): per sub-table 1<<nb bits in 512-bit blocks */
+struct BloomView {
+	u32 *bits32;        /* P << (nb-5) words */
+	int nb;             /* log2 bits per sub-table (= bf_shift - pre) */
+	int n_hash;
+	int mw;             /* u64 words of a "missing probes" mask */
+};
+
+/* parameters of one replay task (one sub-table) */
+struct ReplayTask {
+	u32 old_bits, old_count;
+	u64 old_off;        /* slot offset in the old arena */
+	u64 new_off;        /* slot offset in the new arena (multiple of 32) */
+	u64 rec_off;        /* first record of this sub-table's sorted new keys */
+	u32 m;              /* number of new keys */
+	u32 init_bits;      /* pre-sized empty table (shrink), YK_NOCAP otherwise */
+	u32 cap_max_bits;   /* room reserved in the new arena */
+	u32 pad;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ---- */
+void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+                       u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
+void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st);
+void yk_launch_acc_insert(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, AccTab tab, ImgView img,
+                          int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
+void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
+void yk_launch_img_count(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
+void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
+void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
+void yk_launch_lastput(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
+                       int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch, hipStream_t st);
+void yk_launch_lastput_merge(u64 *lastput, const u64 *lp_batch, u32 *missing, u32 *n_missing, int P, int plo, int phi, hipStream_t st);
+
+void yk_launch_bf_test(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, u64 *miss, hipStream_t st);
+void yk_launch_bf_set(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                      u32 *multi, int multi_bits, u64 *counters, hipStream_t st);
+void yk_launch_bf_check(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                        const u32 *multi, int multi_bits, u64 *cand, u64 *counters, hipStream_t st);
+void yk_launch_bf_mapfill(AccTab tab, const u64 *newlist, u64 n_new, BloomView bf, const u64 *miss,
+                          const u32 *multi, int multi_bits, u64 *map, int map_bits, hipStream_t st);
+void yk_launch_bf_resolve(AccTab tab, const u64 *newlist, const u64 *cand, u64 n_cand, BloomView bf,
+                          const u64 *miss, const u64 *map, int map_bits, hipStream_t st);
+
+void yk_launch_select_count(AccTab tab, int bloom_mode, int P, u32 *seg_cnt, hipStream_t st);
+void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_off, u32 *seg_cur,
+                              u64 *rec_kc, u64 *rec_t, hipStream_t st);
+void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
+                             u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
+void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
+                      u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner,
+                      const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
+                      u32 *out_bits, u32 *out_count, hipStream_t st);
+void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st);
+void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc, hipStream_t st);
+void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* counters[] layout (u64 each) */
+enum { YKC_NEW = 0, YKC_INST = 1, YKC_ANYMULTI = 2, YKC_NCAND = 3, YKC_NMARKED = 4, YKC_EXIST = 5, YKC_N = 8 };
+
+#endif
