@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- `yak count -k31 -b37` on synthetic 150-bp reads, device path, N GPUs of one node.
+
+One "step" = the whole counting job of reference main.c:53-61 on one batch of synthetic reads that
+is already resident in HBM: yak_ch_init (bloom filters included) -> pass 1 (extract, bloom gate,
+insert; exact khashl layout) -> destroy_bf -> clear -> pass 2 (count existing) -> shrink(2,1023).
+N = 1 runs BASELINE.json configs[1] (10 M x 150 bp, G = 50 Mb, e = 0.5 %).  N > 1 is weak scaling:
+every rank brings its own 10 M reads of a genome N times as long, the 1024 sub-tables are sharded
+by hash prefix over the ranks and the hashed k-mers travel to their owner with one RCCL
+all-to-all per pass.
+
+Prints ONE JSON line (rank 0).  `value` = distinct k-mers in the final table (h->tot, the number
+the reference logs) per second, whole job over all ranks; `kmer_instances_per_s` = k-mer windows
+consumed per second (both passes).  `roofline` is for the dominant kernel, timed with HIP events on
+the engine's own stream inside the library; `cpu_baseline` is the reference (oracle/_ref) or the
+oracle port timed on this host on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, PRE, N_HASH = 31, 10, 4
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+B_INSERT = 24.0                # algorithmic B / instance of k_acc_insert
+B_LOOKUP = 16.0                # k_img_count: 8 read + 8 slot read (+ 8 * f_hit, added at run time)
+
+
+def synth_lib():
+    L = C.CDLL(os.path.join(ROOT, "tools", "libyaksynth.so"))
+    L.yaksynth_reads.restype = C.c_int64
+    L.yaksynth_reads.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_uint64,
+                                 C.c_double, C.c_double, C.c_int64, C.c_int]
+    return L
+
+
+def make_reads(n_reads, genome, seed, first, torch, threads):
+    """reads of this rank as a pinned uint8 tensor (memory image: 150 bases + '\\n' per read)"""
+    t = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, pin_memory=True)
+    synth_lib().yaksynth_reads(t.data_ptr(), n_reads, READ_LEN, genome, seed, 0.005, 0.0005, first, threads)
+    return t
+
+
+def cpu_baseline(sample_reads, threads):
+    """the reference binary (oracle/_ref/yak) if it travelled, else the oracle port, on a sample"""
+    from oracle import pyoracle
+    genome = max(sample_reads * READ_LEN // 30, 1000)
+    # bloom scaled like -b37 for 1.2 G instances: ~114 bits per instance
+    bits = 37
+    while (1 << bits) > 114 * sample_reads * 120 * 2 and bits > 20:
+        bits -= 1
+    tmp = tempfile.mkdtemp(prefix="ykb")
+    try:
+        if pyoracle.have_ref():
+            fq = os.path.join(tmp, "s.fq")
+            subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(sample_reads), "-l", str(READ_LEN),
+                                   "-g", str(genome), "-s", "4242", "-o", fq])
+            t0 = time.time()
+            r = subprocess.run([pyoracle.REF_BIN, "count", f"-k{K}", f"-b{bits}", f"-t{threads}", fq],
+                               stderr=subprocess.PIPE, check=True)
+            dt = time.time() - t0
+            m = re.search(rb"(\d+) distinct k-mers after shrinking", r.stderr)
+            tot = int(m.group(1)) if m else 0
+            kind, cores = "reference", threads
+        else:
+            import __graft_entry__ as ge
+            reads = ge._synth(sample_reads, READ_LEN, genome, 4242)
+            t0 = time.time()
+            _, tot = pyoracle.count_protocol_mem(reads, k=K, bf_shift=bits)
+            dt = time.time() - t0
+            kind, cores = "port", 1
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+    inst = sample_reads * (READ_LEN - K + 1) * 2
+    return {"value": tot / dt, "unit": "distinct k-mers/s", "cores": cores, "kind": kind,
+            "kmer_instances_per_s": inst / dt, "seconds": round(dt, 2),
+            "sample": f"yak count -k{K} -b{bits} -t{cores} on {sample_reads} x {READ_LEN} bp synthetic reads "
+                      f"(G={genome}, e=0.5%), both passes, file in page cache"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--bf-shift", type=int, default=37)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import yak_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    L = yak_amd.lib()
+    if L.yakamd_device_count() < 1:
+        raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")
+
+    P = 1 << PRE
+    if P % world:
+        raise SystemExit("the number of GPUs must divide 1024 sub-tables")
+    lo, hi = rank * P // world, (rank + 1) * P // world
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    genome = 5 * a.reads * world                    # 30x coverage of the whole job
+    h_reads = make_reads(a.reads, genome, 42, rank * a.reads, torch, min(threads, 64))
+    d_reads = h_reads.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    n_bytes = d_reads.numel()
+
+    # exchange buffers (multi-GPU only)
+    if world > 1:
+        x_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # extraction scratch
+        x_t = torch.empty(n_bytes, dtype=torch.int32, device=dev)
+        s_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # send, grouped by destination
+        s_t = torch.empty(n_bytes, dtype=torch.int32, device=dev)
+
+    def exchange(with_t):
+        """extract per destination, all-to-all the hashed k-mers to their owner (RCCL over xGMI)"""
+        send_counts, off = [], 0
+        for d in range(world):
+            n = L.yakamd_extract_dev(K, d_reads.data_ptr(), n_bytes, x_hash.data_ptr(), x_t.data_ptr(),
+                                     PRE, d * P // world, (d + 1) * P // world, None)
+            if n < 0:
+                raise RuntimeError("extract failed")
+            s_hash[off:off + n].copy_(x_hash[:n])
+            if with_t:
+                s_t[off:off + n].copy_(x_t[:n])
+            send_counts.append(n); off += n
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc)
+        recv_counts = rc.tolist()
+        r_hash = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(r_hash, s_hash[:off], recv_counts, send_counts)
+        r_t = None
+        if with_t:
+            r_t = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
+            dist.all_to_all_single(r_t, s_t[:off], recv_counts, send_counts)
+        torch.cuda.synchronize()
+        return r_hash, r_t, recv_counts
+
+    def one_pass(t, create_new):
+        if world == 1:
+            t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
+            return
+        r_hash, r_t, recv_counts = exchange(bool(create_new))
+        if L.yakamd_pass_begin(t.h, create_new) != 0:
+            raise RuntimeError("pass_begin")
+        off = 0
+        for s, n in enumerate(recv_counts):       # segments by source rank = stream order of the job
+            if n:
+                tp = r_t[off:off + n].data_ptr() if r_t is not None else x_t.data_ptr()
+                if L.yakamd_feed_hashed_dev(t.h, r_hash[off:off + n].data_ptr(), tp, n, s * n_bytes, n_bytes) != 0:
+                    raise RuntimeError("feed_hashed")
+            off += n
+        n_ins = L.yakamd_pass_end(t.h)
+        if n_ins < 0:
+            raise RuntimeError("pass_end")
+        t.h.contents.tot += n_ins
+
+    def step(keep=False):
+        t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
+        if world > 1:
+            L.yakamd_set_shard(t.h, lo, hi)
+        one_pass(t, 1)
+        s1 = t.stats()
+        if a.bf_shift > 0:
+            t.destroy_bf(); t.clear()
+            one_pass(t, 0)
+            s2 = t.stats()
+            t.shrink(2, 1023)
+        else:
+            s2 = None
+        tot = t.tot
+        if keep:
+            return t, tot, s1, s2
+        t.close()
+        return None, tot, s1, s2
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        _, tot, s1, s2 = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        v = torch.tensor([dt, float(tot), float(s1["n_instances"] + (s2["n_instances"] if s2 else 0))],
+                         dtype=torch.float64, device=dev)
+        vmax = v.clone(); dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        vsum = v.clone(); dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        dt, tot_all, inst_all = vmax[0].item(), vsum[1].item(), vsum[2].item()
+    else:
+        tot_all, inst_all = float(tot), float(s1["n_instances"] + (s2["n_instances"] if s2 else 0))
+    ms_step = dt / a.steps * 1e3
+
+    verify = None
+    if not a.no_verify and world == 1:
+        # full-size property: the .yak bytes do not depend on how the stream is cut into device
+        # batches (the reference's independence of -K / -t)
+        t_a, _, _, _ = step(keep=True)
+        md5_a = hashlib.md5(t_a.dump_bytes()).hexdigest(); t_a.close()
+        os.environ["YAKAMD_BATCH"] = str(1 << 25)
+        t_b, _, _, _ = step(keep=True)
+        md5_b = hashlib.md5(t_b.dump_bytes()).hexdigest(); t_b.close()
+        del os.environ["YAKAMD_BATCH"]
+        verify = {"yak_md5": md5_a, "batch_independent": md5_a == md5_b}
+        if md5_a != md5_b:
+            raise SystemExit("FAILED: .yak bytes depend on the device batch size")
+        # small-size gate against the oracle, byte for byte
+        import __graft_entry__ as ge
+        ge.smoke()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # roofline of the dominant kernel (HIP-event timed inside the library, per launch)
+    kern = [("k_acc_insert", s1, B_INSERT)]
+    if s2:
+        f_hit = 0.9
+        kern.append(("k_img_count", s2, B_LOOKUP + 8.0 * f_hit))
+    name, st, bpi = max(kern, key=lambda x: x[1]["ms_dominant_kernel"])
+    launches = max(1, st["n_dominant_launches"])
+    avg_ms = st["ms_dominant_kernel"] / launches
+    ach = bpi * st["n_instances"] / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "distinct k-mers counted/sec (k=31), yak count -b37 two-pass protocol, .yak bit-exact",
+        "value": tot_all / (dt / a.steps), "unit": "distinct k-mers/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": f"yak count -k{K} -b{a.bf_shift} on {a.reads} x {READ_LEN} bp synthetic reads per GPU "
+                               f"(G={genome}, e=0.5%, N=0.05%), 30x, bloom prefilter on, both passes + shrink",
+                   "reads_per_gpu": a.reads, "k": K, "pre": PRE, "bf_shift": a.bf_shift,
+                   "sharding": "prefix-sharded sub-tables, RCCL all-to-all of hashed k-mers" if world > 1 else "1 GPU"},
+        "kmer_instances_per_s": inst_all / (dt / a.steps),
+        "final_distinct": tot_all,
+        "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_")},
+                               "pass2": {k: round(v, 3) for k, v in s2.items() if k.startswith("ms_")} if s2 else None},
+        "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
+        "bloom_exact_resolutions": s1["n_bloom_candidates"],
+        "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": avg_ms, "launches": launches,
+                     "algorithmic_bytes_per_instance": bpi, "instances_per_launch": st["n_instances"] / launches},
+        "verify": verify,
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, min(os.cpu_count() or 8, 32))
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,10 +49,13 @@ int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash_u64, const void *d_t_
  * yak_ch_insert_list it does not touch h->tot: the caller adds (count.c:138) */
 int64_t yakamd_pass_end(yak_ch_t *h);
 
-/* extraction only: hashed canonical k-mers (and their positions) of a device-resident base
- * image, for sharded exchange.  Outputs must hold n_bytes entries; returns the count or -1. */
+/* extraction only (count.c:28-43): hashed canonical k-mers, and their positions, of a
+ * device-resident base image, restricted to prefixes [prefix_lo, prefix_hi) of a 1<<pre split --
+ * one call per destination GPU gives the send buffers of the prefix exchange.  Outputs must hold
+ * n_bytes entries; returns the count or -1. */
 int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
-                           void *d_hash_u64_out, void *d_t_u32_out, void *stream);
+                           void *d_hash_u64_out, void *d_t_u32_out,
+                           int pre, int prefix_lo, int prefix_hi, void *stream);
 
 /* bring the host view (slot arrays reachable from yak_ch_t) up to date with HBM */
 int yakamd_sync_host(yak_ch_t *h);

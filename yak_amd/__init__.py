@@ -1,0 +1,198 @@
+"""yak_amd -- MI355X-native k-mer counting engine behind lh3/yak's C API.
+
+This package is only the Python-side loader used by tests and bench.py.  The product is the
+C-ABI shared library ``yak_amd/libyak_amd.so`` (hand-written gfx950 HIP kernels + the drop-in
+``yak.h`` surface declared in ``include/yak.h`` / ``include/yak_amd.h``).  There is no Python or
+CPU implementation of the counting path here: if the library is missing, importing :func:`lib`
+raises; if no MI355X is visible, ``yak_ch_init`` / ``yak_count`` return NULL and the wrappers raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyak_amd.so")
+
+# every symbol include/yak.h and include/yak_amd.h declare (checked by tests/test_abi.py)
+YAK_H_SYMBOLS = [
+    "yak_copt_init", "yak_bf_init", "yak_bf_destroy", "yak_bf_insert",
+    "yak_ch_init", "yak_ch_destroy", "yak_ch_destroy_bf", "yak_ch_insert_list", "yak_ch_get",
+    "yak_ch_inc", "yak_ch_getseq", "yak_ch_clear", "yak_ch_hist", "yak_ch_shrink", "yak_ch_dump",
+    "yak_ch_restore", "yak_count", "yak_verbose", "seq_nt4_table",
+]
+YAK_AMD_H_SYMBOLS = [
+    "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
+    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_hashed_dev",
+    "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
+    "yakamd_get_stats",
+]
+
+
+class CoptT(C.Structure):                      # yak_copt_t, include/yak.h (reference yak.h:25-31)
+    _fields_ = [("bf_shift", C.c_int32), ("bf_n_hash", C.c_int32), ("k", C.c_int32),
+                ("pre", C.c_int32), ("n_thread", C.c_int32), ("chunk_size", C.c_int64)]
+
+
+class ChT(C.Structure):                        # yak_ch_t (reference yak.h:61-65)
+    _fields_ = [("k", C.c_int), ("pre", C.c_int), ("n_hash", C.c_int), ("n_shift", C.c_int),
+                ("tot", C.c_uint64), ("h", C.c_void_p)]
+
+
+class StatsT(C.Structure):                     # yakamd_stats_t
+    _fields_ = [("ms_extract", C.c_double), ("ms_insert", C.c_double), ("ms_bloom", C.c_double),
+                ("ms_select", C.c_double), ("ms_sort", C.c_double), ("ms_replay", C.c_double),
+                ("ms_total", C.c_double), ("ms_dominant_kernel", C.c_double),
+                ("n_dominant_launches", C.c_int64), ("n_instances", C.c_int64),
+                ("n_distinct_seen", C.c_int64), ("n_new_keys", C.c_int64),
+                ("n_bloom_candidates", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libyak_amd.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make lib` "
+                           "(python __graft_entry__.py build); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.yak_copt_init.argtypes = [P(CoptT)]
+    L.yak_ch_init.restype = P(ChT); L.yak_ch_init.argtypes = [C.c_int] * 4
+    L.yak_ch_destroy.argtypes = [P(ChT)]
+    L.yak_ch_destroy_bf.argtypes = [P(ChT)]
+    L.yak_ch_insert_list.restype = C.c_int
+    L.yak_ch_insert_list.argtypes = [P(ChT), C.c_int, C.c_int, P(C.c_uint64)]
+    L.yak_ch_get.restype = C.c_int; L.yak_ch_get.argtypes = [P(ChT), C.c_uint64]
+    L.yak_ch_inc.restype = C.c_int; L.yak_ch_inc.argtypes = [P(ChT), C.c_uint64]
+    L.yak_ch_clear.argtypes = [P(ChT), C.c_int]
+    L.yak_ch_shrink.argtypes = [P(ChT), C.c_int, C.c_int, C.c_int]
+    L.yak_ch_hist.argtypes = [P(ChT), P(C.c_int64), C.c_int]
+    L.yak_ch_dump.restype = C.c_int; L.yak_ch_dump.argtypes = [P(ChT), C.c_char_p]
+    L.yak_ch_restore.restype = P(ChT); L.yak_ch_restore.argtypes = [C.c_char_p]
+    L.yak_count.restype = P(ChT); L.yak_count.argtypes = [C.c_char_p, P(CoptT), P(ChT)]
+    L.yak_bf_init.restype = C.c_void_p; L.yak_bf_init.argtypes = [C.c_int, C.c_int]
+    L.yak_bf_insert.restype = C.c_int; L.yak_bf_insert.argtypes = [C.c_void_p, C.c_uint64]
+    L.yak_bf_destroy.argtypes = [C.c_void_p]
+    L.yakamd_device_count.restype = C.c_int
+    L.yakamd_last_error.restype = C.c_char_p
+    L.yakamd_set_shard.restype = C.c_int; L.yakamd_set_shard.argtypes = [P(ChT), C.c_int, C.c_int]
+    L.yakamd_pass_begin.restype = C.c_int; L.yakamd_pass_begin.argtypes = [P(ChT), C.c_int]
+    L.yakamd_feed_bases_dev.restype = C.c_int
+    L.yakamd_feed_bases_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_feed_bases_host.restype = C.c_int
+    L.yakamd_feed_bases_host.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_feed_hashed_dev.restype = C.c_int
+    L.yakamd_feed_hashed_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
+    L.yakamd_pass_end.restype = C.c_int64; L.yakamd_pass_end.argtypes = [P(ChT)]
+    L.yakamd_extract_dev.restype = C.c_int64
+    L.yakamd_extract_dev.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.yakamd_sync_host.restype = C.c_int; L.yakamd_sync_host.argtypes = [P(ChT)]
+    L.yakamd_dump_mem.restype = C.c_int64
+    L.yakamd_dump_mem.argtypes = [P(ChT), P(P(C.c_uint8))]
+    L.yakamd_subtable.restype = C.c_int
+    L.yakamd_subtable.argtypes = [P(ChT), C.c_int, P(C.c_uint32), P(C.c_uint32)]
+    L.yakamd_get_stats.restype = C.c_int; L.yakamd_get_stats.argtypes = [P(ChT), P(StatsT)]
+    _lib = L
+    return L
+
+
+def _err():
+    return (lib().yakamd_last_error() or b"").decode()
+
+
+class Table:
+    """Thin owner of a ``yak_ch_t *`` created through the C ABI."""
+
+    def __init__(self, k=31, pre=10, n_hash=4, bf_shift=0, ptr=None):
+        self.L = lib()
+        self.h = ptr if ptr is not None else self.L.yak_ch_init(k, pre, n_hash, bf_shift)
+        if not self.h:
+            raise RuntimeError("yak_ch_init failed: " + _err())
+
+    # -- reference protocol pieces ---------------------------------------------------------
+    def count_pass(self, create_new, feeds):
+        """one pass: feeds = iterable of (device_ptr, n_bytes, t0)"""
+        if self.L.yakamd_pass_begin(self.h, create_new) != 0:
+            raise RuntimeError(_err())
+        for ptr, n, t0 in feeds:
+            if self.L.yakamd_feed_bases_dev(self.h, ptr, n, t0) != 0:
+                raise RuntimeError(_err())
+        n_ins = self.L.yakamd_pass_end(self.h)
+        if n_ins < 0:
+            raise RuntimeError(_err())
+        self.h.contents.tot += n_ins
+        return n_ins
+
+    def count_pass_host(self, create_new, buf, t0=0):
+        if self.L.yakamd_pass_begin(self.h, create_new) != 0:
+            raise RuntimeError(_err())
+        cbuf = (C.c_char * len(buf)).from_buffer_copy(buf)
+        if self.L.yakamd_feed_bases_host(self.h, cbuf, len(buf), t0) != 0:
+            raise RuntimeError(_err())
+        n_ins = self.L.yakamd_pass_end(self.h)
+        if n_ins < 0:
+            raise RuntimeError(_err())
+        self.h.contents.tot += n_ins
+        return n_ins
+
+    def destroy_bf(self):
+        self.L.yak_ch_destroy_bf(self.h)
+
+    def clear(self):
+        self.L.yak_ch_clear(self.h, 1)
+
+    def shrink(self, lo, hi):
+        self.L.yak_ch_shrink(self.h, lo, hi, 1)
+
+    @property
+    def tot(self):
+        return self.h.contents.tot
+
+    def stats(self):
+        st = StatsT()
+        self.L.yakamd_get_stats(self.h, C.byref(st))
+        return {f: getattr(st, f) for f, _ in StatsT._fields_}
+
+    def dump_bytes(self):
+        out = C.POINTER(C.c_uint8)()
+        n = self.L.yakamd_dump_mem(self.h, C.byref(out))
+        if n < 0:
+            raise RuntimeError(_err())
+        data = C.string_at(out, n)
+        C.CDLL(None).free(out)
+        return data
+
+    def subtable(self, i):
+        cap, size = C.c_uint32(), C.c_uint32()
+        self.L.yakamd_subtable(self.h, i, C.byref(cap), C.byref(size))
+        return cap.value, size.value
+
+    def close(self):
+        if self.h:
+            self.L.yak_ch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_protocol_host(buf1, k=31, pre=10, n_hash=4, bf_shift=0, buf2=None):
+    """`yak count` protocol of reference main.c:53-60 on in-memory base images -> .yak bytes"""
+    t = Table(k, pre, n_hash, bf_shift)
+    try:
+        t.count_pass_host(1, buf1)
+        if bf_shift > 0:
+            t.destroy_bf()
+            t.clear()
+            t.count_pass_host(0, buf2 if buf2 is not None else buf1)
+            t.shrink(2, 1023)
+        return t.dump_bytes(), t.tot
+    finally:
+        t.close()

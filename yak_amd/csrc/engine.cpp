@@ -462,14 +462,15 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	return r;
 }
 
-extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t, void *stream)
+extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
+                                      int pre, int plo, int phi, void *stream)
 {
 	if (k >= 32 || k < 1) { fail("extract: unsupported k"); return -1; }
 	u64 *d_cur = 0, n = 0;
 	hipStream_t st = (hipStream_t)stream;
 	if (hipMalloc((void**)&d_cur, 8) != hipSuccess) { fail("hipMalloc"); return -1; }
 	hipMemsetAsync(d_cur, 0, 8, st);
-	yk_launch_extract((const uint8_t*)d_bases, 0, n_bytes, 0, k, 10, 0, 1 << 10, (u64*)d_hash, (u32*)d_t, d_cur, st);
+	yk_launch_extract((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, plo, phi, (u64*)d_hash, (u32*)d_t, d_cur, st);
 	hipMemcpyAsync(&n, d_cur, 8, hipMemcpyDeviceToHost, st);
 	hipStreamSynchronize(st);
 	hipFree(d_cur);
