@@ -1,0 +1,105 @@
+"""yak_ch_* entry points on the device state vs the same call sequence on the oracle."""
+import ctypes as C
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yak_amd
+    assert yak_amd.lib().yakamd_device_count() >= 1
+    return yak_amd
+
+
+def _lists(oracle, seed, n_lists, n, pre=10, dup=0.5):
+    """hashed k-mer lists sharing one prefix each, with repeats inside and across lists"""
+    rnd = random.Random(seed)
+    m = (1 << 62) - 1
+    pool = {}
+    out = []
+    for _ in range(n_lists):
+        p = rnd.randrange(8)
+        cur = []
+        while len(cur) < n:
+            if pool.get(p) and rnd.random() < dup:
+                cur.append(rnd.choice(pool[p]))
+            else:
+                h = (oracle.lib().yko_hash64(rnd.getrandbits(62), m) >> pre << pre) | p
+                pool.setdefault(p, []).append(h); cur.append(h)
+        out.append(cur)
+    return out
+
+
+@pytest.mark.parametrize("bf", [0, 21])
+def test_insert_list_sequences(bf, ya, oracle):
+    """htab.c:51-78 called list by list, as count.c:82 does; create_new = 1 then 0; table bytes and
+    return values must match after every call (covers growth on an existing table image, the bloom
+    carried across calls, the foreign-prefix skip and count saturation)"""
+    L, O = ya.lib(), oracle.lib()
+    t = ya.Table(31, 10, 4, bf)
+    o = O.yko_ch_init(31, 10, 4, bf)
+    lists = _lists(oracle, 5, 40, 300)
+    lists[3] = lists[3][:100] + [lists[3][0] ^ 1] + lists[3][100:]       # a foreign prefix in the middle
+    lists.append([lists[0][0]] * 1500)                                    # saturate one key
+    for i, a in enumerate(lists):
+        arr = (C.c_uint64 * len(a))(*a)
+        create = 1 if i % 5 != 4 else 0
+        assert L.yak_ch_insert_list(t.h, create, len(a), arr) == O.yko_ch_insert_list(o, create, len(a), arr), i
+        if i % 7 == 0 or i == len(lists) - 1:
+            assert t.dump_bytes() == oracle.dump_bytes(o), i
+    for a in lists[:5]:
+        for x in a[:20]:
+            assert L.yak_ch_get(t.h, x) == O.yko_ch_get(o, x)
+    assert L.yak_ch_get(t.h, 12345 << 10) == -1
+    t.close(); O.yko_ch_destroy(o)
+
+
+def test_clear_shrink_restore_hist(ya, oracle, synth, tmp_path):
+    L, O = ya.lib(), oracle.lib()
+    img = synth(3000, g=15000, s=4)
+    t = ya.Table(31, 10, 4, 0)
+    t.count_pass_host(1, img)
+    oc = oracle.copt()
+    o = O.yko_count_mem(img, len(img), C.byref(oc), None)
+    assert t.tot == o.contents.tot
+    h1 = (C.c_int64 * 1024)(); h2 = (C.c_int64 * 1024)()
+    L.yak_ch_hist(t.h, h1, 1); O.yko_ch_hist.argtypes = [C.POINTER(oracle.Ch), C.POINTER(C.c_int64)]; O.yko_ch_hist(o, h2)
+    assert list(h1) == list(h2)
+    for lo, hi in ((2, 1023), (3, 7), (1, 2000), (5, 4)):
+        t.shrink(lo, hi); O.yko_ch_shrink(o, lo, hi)
+        assert t.dump_bytes() == oracle.dump_bytes(o) and t.tot == o.contents.tot
+    fn = str(tmp_path / "t.yak").encode()
+    assert L.yak_ch_dump(t.h, fn) == 0
+    r = ya.Table(ptr=L.yak_ch_restore(fn))
+    ro = O.yko_ch_restore(fn)
+    assert r.dump_bytes() == oracle.dump_bytes(ro)       # restore re-puts in file order; empties get capacity 4
+    t.clear(); O.yko_ch_clear(o)
+    assert t.dump_bytes() == oracle.dump_bytes(o)
+    t.count_pass_host(0, img)                            # recount into the cleared table
+    O.yko_count_mem(img, len(img), C.byref(oc), o)
+    assert t.dump_bytes() == oracle.dump_bytes(o)
+    assert L.yak_ch_dump(t.h, b"/nonexistent_dir/x.yak") == -1
+    assert not L.yak_ch_restore(b"/nonexistent.yak")
+    t.close(); r.close(); O.yko_ch_destroy(o); O.yko_ch_destroy(ro)
+
+
+def test_yak_count_file_api(ya, oracle, tmp_path):
+    """yak_count() itself: NULL on an unreadable file, h0 semantics, chunking by opt->chunk_size"""
+    import subprocess
+    from conftest import ROOT
+    L = ya.lib()
+    fq = str(tmp_path / "r.fq")
+    subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", "2000", "-g", "10000", "-s", "3", "-o", fq])
+    o = ya.CoptT(); L.yak_copt_init(C.byref(o)); o.chunk_size = 30000
+    assert not L.yak_count(b"/no/such/file.fq", C.byref(o), None)
+    h = L.yak_count(fq.encode(), C.byref(o), None)
+    t = ya.Table(ptr=h)
+    oc = oracle.copt(chunk=30000)
+    want = oracle.lib().yko_count_protocol_file(fq.encode(), None, C.byref(oc))
+    assert t.dump_bytes() == oracle.dump_bytes(want) and t.tot == want.contents.tot
+    assert L.yak_count(fq.encode(), C.byref(o), h)       # second call returns h0 itself
+    t.close(); oracle.lib().yko_ch_destroy(want)

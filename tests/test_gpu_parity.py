@@ -1,0 +1,133 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/yak.h +
+include/yak_amd.h), must reproduce the reference's .yak bytes -- against the committed golden
+vectors (made by the reference) and against the oracle on seeded inputs.  Bit-exact: integer work."""
+import ctypes as C
+import hashlib
+import json
+import os
+import struct
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT, args_to_opts, image_for_case
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(json.load(open(os.path.join(GOLD, "manifest.json"))).keys())
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yak_amd
+    L = yak_amd.lib()
+    assert L.yakamd_device_count() >= 1, "GPU tests need an MI355X; the engine has no CPU fallback"
+    return yak_amd
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_vectors(name, ya, synth, manifest):
+    desc = manifest[name]
+    if any(a.startswith("-k") and int(a[2:]) >= 32 for a in desc["args"]):
+        pytest.skip("k >= 32 not on the device yet")
+    img = image_for_case(desc, synth)
+    data, _ = ya.count_protocol_host(img, **args_to_opts(desc["args"]))
+    assert len(data) == desc["size"]
+    assert hashlib.md5(data).hexdigest() == desc["md5"]
+    if desc["stored"]:
+        assert data == open(os.path.join(GOLD, name + ".yak"), "rb").read()
+
+
+OPTS = [dict(k=31), dict(k=21), dict(k=11), dict(k=5), dict(k=31, pre=12), dict(k=31, pre=14, bf_shift=27),
+        dict(k=31, bf_shift=19), dict(k=31, bf_shift=21), dict(k=31, bf_shift=26), dict(k=25, bf_shift=20, n_hash=9),
+        dict(k=31, bf_shift=22, n_hash=70), dict(k=31, bf_shift=12), dict(k=31, bf_shift=10), dict(k=31, bf_shift=24, n_hash=1)]
+
+
+@pytest.mark.parametrize("opt", OPTS, ids=lambda o: "-".join(f"{k}{v}" for k, v in o.items()))
+def test_vs_oracle_short_reads(opt, ya, oracle, synth):
+    img = synth(5000, g=25000, s=31)
+    got, tot = ya.count_protocol_host(img, **opt)
+    want, wtot = oracle.count_protocol_mem(img, **opt)
+    assert tot == wtot
+    assert got == want
+
+
+def test_vs_oracle_long_contigs_with_n(ya, oracle, synth):
+    img = synth(40, l=30000, g=400000, s=3, N=0.001)        # long-sequence path (SURVEY section 5, config 4 shape)
+    for opt in (dict(k=21), dict(k=31, bf_shift=25)):
+        assert ya.count_protocol_host(img, **opt)[0] == oracle.count_protocol_mem(img, **opt)[0]
+
+
+def test_second_pass_on_a_different_file(ya, oracle, synth):
+    a, b = synth(4000, g=20000, s=5), synth(3000, g=20000, s=5, e=0.02, first=100000)
+    got, _ = ya.count_protocol_host(a, bf_shift=24, buf2=b)
+    want, _ = oracle.count_protocol_mem(a, bf_shift=24, buf2=b)
+    assert got == want
+
+
+EDGE = {
+    "empty": b"",
+    "only_separators": b"\n\n\nNNNN\n",
+    "shorter_than_k": b"ACGTACGT\nACG\n",
+    "exactly_k": b"ACGTTGCAAGGCTTAACCGGTTAACCGGATC\n",
+    "all_n": b"N" * 500 + b"\n",
+    "lower_case_and_u": b"acgtugcaaggcuuaaccgguuaaccggaucacgatcgatcgatcagctagctagctagcatcgatcg\n",
+    "raw_0123_bytes": bytes([0, 1, 2, 3] * 40) + b"\n" + bytes([3, 2, 1, 0] * 40) + b"\n",
+    "iupac": b"ACGTRYKMACGTACGTACGTACGTACGTTGCATGCATGCATGCAACGTSWACGTACGTTGCATGCATGCATGCAAACCGGTT\n",
+    "palindromes": b"ACGT" * 60 + b"\n" + b"AATT" * 60 + b"\n",
+    "saturation": b"A" * 2500 + b"\n" + b"T" * 900 + b"\n" + b"ACGTTGCA" * 300 + b"\n",
+    "no_trailing_separator": b"ACGTTGCAAGGCTTAACCGGTTAACCGGATCGGATTACAGGATTTACA",
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE))
+@pytest.mark.parametrize("opt", [dict(k=31), dict(k=7), dict(k=31, bf_shift=20)], ids=["k31", "k7", "k31b20"])
+def test_edge_inputs(name, opt, ya, oracle):
+    img = EDGE[name]
+    got, tot = ya.count_protocol_host(img, **opt)
+    want, wtot = oracle.count_protocol_mem(img, **opt)
+    assert (got, tot) == (want, wtot)
+
+
+def test_grow_on_existing_key(ya, oracle, manifest):
+    """the same read twice doubles the capacity of sub-tables sitting at 75 % load"""
+    one = image_for_case(manifest["one_read"], None)
+    two = image_for_case(manifest["one_read_x2"], None)
+    a, _ = ya.count_protocol_host(one)
+    b, _ = ya.count_protocol_host(two)
+
+    def caps(d):
+        out, off = [], 16
+        for _ in range(1024):
+            cap, n = struct.unpack_from("<II", d, off)
+            out.append((cap, n)); off += 8 + 8 * n
+        return out
+    ca, cb = caps(a), caps(b)
+    assert any(x == (4, 3) and y == (8, 3) for x, y in zip(ca, cb))
+    assert any(x == (0, 0) for x in ca)
+    assert a == oracle.count_protocol_mem(one)[0] and b == oracle.count_protocol_mem(two)[0]
+
+
+@pytest.mark.parametrize("env", [dict(YAKAMD_BATCH="4096"), dict(YAKAMD_BATCH="8192", YAKAMD_LASTPUT_TAIL="100"),
+                                 dict(YAKAMD_BATCH="65536", YAKAMD_LASTPUT_TAIL="1"), dict(YAKAMD_MULTI_BITS="10")],
+                         ids=["batch4k", "batch8k_tail100", "batch64k_tail1", "multi10"])
+def test_device_batching_is_invisible(env, ya, oracle, synth, monkeypatch):
+    """cutting the stream into many device batches (accumulator growth + rehash, per-batch bloom
+    phases, last-put fallback scan, tiny `multi` filter) must not change a byte -- the reference's
+    independence of -K/-t"""
+    img = synth(3000, g=15000, s=12)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for opt in (dict(k=31), dict(k=31, bf_shift=20), dict(k=31, bf_shift=24)):
+        assert ya.count_protocol_host(img, **opt)[0] == oracle.count_protocol_mem(img, **opt)[0]
+
+
+def test_cli_drop_in(ya, oracle, tmp_path):
+    """the C caller (yak-amd count == reference main_count) on real files: FASTQ, gz, multi-line FASTA"""
+    fq = str(tmp_path / "r.fq")
+    subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", "3000", "-g", "15000", "-s", "8", "-o", fq])
+    subprocess.check_call(["gzip", "-kf", fq])
+    for args, inp in ((["-k31"], fq), (["-k31", "-b22"], fq + ".gz"), (["-k5"], os.path.join(GOLD, "inputs", "edge.fx"))):
+        a, b = str(tmp_path / "a.yak"), str(tmp_path / "b.yak")
+        subprocess.run([os.path.join(ROOT, "yak_amd", "yak-amd"), "count"] + args + ["-o", a, inp], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(ROOT, "oracle", "yko"), "count"] + args + ["-o", b, inp], check=True, stderr=subprocess.DEVNULL)
+        assert open(a, "rb").read() == open(b, "rb").read()

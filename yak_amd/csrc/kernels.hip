@@ -578,26 +578,56 @@ __device__ __forceinline__ bool acc_select(const AccSlot &s, int bloom_mode, int
 	return true;
 }
 
+/* One workgroup owns SEL_CHUNK consecutive accumulator slots.  The accumulator is prefix-major,
+ * so a chunk holds keys of one or two sub-tables only: counts are aggregated in an LDS histogram
+ * and flushed with a handful of global atomics per workgroup instead of one per key. */
+#define SEL_CHUNK 8192
+#define SEL_MAXP  8192
+
 __global__ __launch_bounds__(256)
 void k_select_count(AccTab tab, int bloom_mode, u32 *seg_cnt)
 {
-	const u64 n = tab.mask + 1, stride = (u64)gridDim.x * blockDim.x;
-	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+	__shared__ u32 s_hist[SEL_MAXP];
+	const u32 P = 1u << tab.pre;
+	const bool lds = P <= SEL_MAXP;
+	const u64 n = tab.mask + 1, lo = (u64)blockIdx.x * SEL_CHUNK, hi = lo + SEL_CHUNK < n ? lo + SEL_CHUNK : n;
+	if (lds) { for (u32 p = threadIdx.x; p < P; p += 256) s_hist[p] = 0; __syncthreads(); }
+	for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
 		const AccSlot s = tab.s[i];
 		u32 p; u64 T, kc;
-		if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) atomicAdd(&seg_cnt[p], 1u);
+		if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) atomicAdd(lds ? &s_hist[p] : &seg_cnt[p], 1u);
+	}
+	if (lds) {
+		__syncthreads();
+		for (u32 p = threadIdx.x; p < P; p += 256) if (s_hist[p]) atomicAdd(&seg_cnt[p], s_hist[p]);
 	}
 }
 
 __global__ __launch_bounds__(256)
 void k_select_scatter(AccTab tab, int bloom_mode, const u64 *seg_off, u32 *seg_cur, u64 *rec_kc, u64 *rec_t)
 {
-	const u64 n = tab.mask + 1, stride = (u64)gridDim.x * blockDim.x;
-	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+	__shared__ u32 s_hist[SEL_MAXP];
+	const u32 P = 1u << tab.pre;
+	const bool lds = P <= SEL_MAXP;
+	const u64 n = tab.mask + 1, lo = (u64)blockIdx.x * SEL_CHUNK, hi = lo + SEL_CHUNK < n ? lo + SEL_CHUNK : n;
+	if (lds) {
+		for (u32 p = threadIdx.x; p < P; p += 256) s_hist[p] = 0;
+		__syncthreads();
+		for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
+			const AccSlot s = tab.s[i];
+			u32 p; u64 T, kc;
+			if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) atomicAdd(&s_hist[p], 1u);
+		}
+		__syncthreads();
+		/* reserve this workgroup's range of every sub-table it met; s_hist becomes the running cursor */
+		for (u32 p = threadIdx.x; p < P; p += 256) { const u32 c = s_hist[p]; if (c) s_hist[p] = atomicAdd(&seg_cur[p], c); }
+		__syncthreads();
+	}
+	for (u64 i = lo + threadIdx.x; i < hi; i += 256) {      /* second read of the chunk hits L2 */
 		const AccSlot s = tab.s[i];
 		u32 p; u64 T, kc;
 		if (acc_select(s, bloom_mode, tab.pre, &p, &T, &kc)) {
-			const u64 d = seg_off[p] + atomicAdd(&seg_cur[p], 1u);
+			const u64 d = seg_off[p] + atomicAdd(lds ? &s_hist[p] : &seg_cur[p], 1u);
 			rec_kc[d] = kc; rec_t[d] = T;
 		}
 	}
@@ -941,14 +971,14 @@ void yk_launch_bf_resolve(AccTab tab, const u64 *newlist, const u64 *cand, u64 n
 void yk_launch_select_count(AccTab tab, int bloom_mode, int P, u32 *seg_cnt, hipStream_t st)
 {
 	(void)P;
-	hipLaunchKernelGGL(k_select_count, dim3(grid_for(tab.mask + 1)), dim3(256), 0, st, tab, bloom_mode, seg_cnt);
+	hipLaunchKernelGGL(k_select_count, dim3((unsigned)((tab.mask + SEL_CHUNK) / SEL_CHUNK)), dim3(256), 0, st, tab, bloom_mode, seg_cnt);
 }
 
 void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_off, u32 *seg_cur,
                               u64 *rec_kc, u64 *rec_t, hipStream_t st)
 {
 	(void)P;
-	hipLaunchKernelGGL(k_select_scatter, dim3(grid_for(tab.mask + 1)), dim3(256), 0, st, tab, bloom_mode, seg_off, seg_cur, rec_kc, rec_t);
+	hipLaunchKernelGGL(k_select_scatter, dim3((unsigned)((tab.mask + SEL_CHUNK) / SEL_CHUNK)), dim3(256), 0, st, tab, bloom_mode, seg_off, seg_cur, rec_kc, rec_t);
 }
 
 void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
