@@ -179,23 +179,37 @@ def main():
             raise RuntimeError("pass_end")
         t.h.contents.tot += n_ins
 
+    wall = {}
+
     def step(keep=False):
+        def tick(name, t0):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            wall[name] = (t1 - t0) * 1e3
+            return t1
+        tp = time.perf_counter()
         t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
         if world > 1:
             L.yakamd_set_shard(t.h, lo, hi)
+        tp = tick("init", tp)
         one_pass(t, 1)
+        tp = tick("pass1", tp)
         s1 = t.stats()
         if a.bf_shift > 0:
             t.destroy_bf(); t.clear()
+            tp = tick("destroy_bf_clear", tp)
             one_pass(t, 0)
+            tp = tick("pass2", tp)
             s2 = t.stats()
             t.shrink(2, 1023)
+            tp = tick("shrink", tp)
         else:
             s2 = None
         tot = t.tot
         if keep:
             return t, tot, s1, s2
         t.close()
+        tick("close", tp)
         return None, tot, s1, s2
 
     def barrier():
@@ -266,6 +280,7 @@ def main():
         "final_distinct": tot_all,
         "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_")},
                                "pass2": {k: round(v, 3) for k, v in s2.items() if k.startswith("ms_")} if s2 else None},
+        "phase_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
         "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
         "bloom_exact_resolutions": s1["n_bloom_candidates"],
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -57,6 +57,9 @@ int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
                            void *d_hash_u64_out, void *d_t_u32_out,
                            int pre, int prefix_lo, int prefix_hi, void *stream);
 
+/* release the device-memory cache kept between passes (memory pool) */
+void yakamd_trim(void);
+
 /* bring the host view (slot arrays reachable from yak_ch_t) up to date with HBM */
 int yakamd_sync_host(yak_ch_t *h);
 /* serialise the table in .yak format straight from the host view into memory (malloc'ed) */

@@ -23,7 +23,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
     "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
-    "yakamd_get_stats",
+    "yakamd_get_stats", "yakamd_trim",
 ]
 
 

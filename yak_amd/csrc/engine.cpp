@@ -73,15 +73,77 @@ static inline u32 kh_bits_for(u32 want)
 	return lg > 2 ? lg : 2;
 }
 
+/* Device memory pool.  A counting job allocates and frees tens of GB per pass (bloom filters,
+ * partition buffers, table arenas); on ROCm each hipMalloc/hipFree of that size costs tens to
+ * hundreds of ms, so freed blocks are kept and handed out again (best fit within +25 %).
+ * YAKAMD_POOL=0 disables it; the cache is dropped when an allocation fails. */
+#include <map>
+#include <mutex>
+#include <unordered_map>
+struct DevPool {
+	std::mutex mu;
+	std::multimap<size_t, void*> idle;
+	std::unordered_map<void*, size_t> size_of;
+	size_t cached = 0;
+};
+static DevPool g_pool[16];
+static DevPool &pool_here() { int d = 0; (void)hipGetDevice(&d); return g_pool[d & 15]; }
+
+static void pool_trim(DevPool &P)
+{
+	for (auto &kv : P.idle) { (void)hipFree(kv.second); P.size_of.erase(kv.second); }
+	P.idle.clear(); P.cached = 0;
+}
+
+static void *pool_alloc(size_t bytes)
+{
+	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
+	DevPool &P = pool_here();
+	const size_t gran = bytes >= (1u << 20) ? (2u << 20) : 256;
+	bytes = (bytes + gran - 1) / gran * gran;
+	std::lock_guard<std::mutex> lk(P.mu);
+	if (on) {
+		auto it = P.idle.lower_bound(bytes);
+		if (it != P.idle.end() && it->first <= bytes + bytes / 4) {
+			void *p = it->second;
+			P.cached -= it->first;
+			P.idle.erase(it);
+			return p;
+		}
+	}
+	void *p = 0;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		pool_trim(P);
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	}
+	P.size_of[p] = bytes;
+	return p;
+}
+
+static void pool_free(void *p)
+{
+	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
+	DevPool &P = pool_here();
+	std::lock_guard<std::mutex> lk(P.mu);
+	auto it = P.size_of.find(p);
+	if (!on || it == P.size_of.end()) { if (it != P.size_of.end()) P.size_of.erase(it); (void)hipFree(p); return; }
+	P.idle.insert({ it->second, p });
+	P.cached += it->second;
+}
+
+size_t yk_pool_cached_bytes(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); return P.cached; }
+
+extern "C" void yakamd_trim(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); pool_trim(P); }
+
 template <class T> static int dmalloc(T **p, size_t n)
 {
-	*p = 0;
 	if (n == 0) n = 1;
-	hipError_t e = hipMalloc((void**)p, n * sizeof(T));
-	if (e != hipSuccess) return fail("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+	*p = (T*)pool_alloc(n * sizeof(T));
+	if (!*p) return fail("device allocation of %zu bytes failed", n * sizeof(T));
 	return 0;
 }
-template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = 0; } }
+template <class T> static void dfree(T *&p) { if (p) { pool_free((void*)p); p = 0; } }
 
 /* ------------------------------------------------------------------------------------------ */
 
@@ -111,6 +173,12 @@ struct yakamd_ctx {
 	u64 *d_rh; u32 *d_rt; int64_t rec_cap;
 	u64 *d_newlist, *d_miss, *d_cand; int64_t new_cap;
 	uint8_t *d_stage; int64_t stage_cap;
+	u32 *d_rows; u64 *d_partial, *d_bstart; int rows_blk; int nb_bits;
+	/* fast path: level-1 partitioned batches kept until pass_end */
+	struct Kept { u64 *d_hash; u32 *d_t; u64 n; u64 t0, span; std::vector<u64> bstart; };
+	std::vector<Kept> kept;
+	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set;
+	double ms_part2, ms_lds;
 	u64 t_end;
 	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
 	yakamd_stats_t st_cur, st_last;
@@ -181,6 +249,11 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rh = 0; c->d_rt = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
 	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
+	c->d_rows = 0; c->d_partial = 0; c->d_bstart = 0; c->rows_blk = 0;
+	c->nb_bits = (int)std::min<int64_t>(pre, env_i64("YAKAMD_PART_BITS", 13));
+	if (c->nb_bits < 3) c->nb_bits = 3;
+	if (c->nb_bits > 13) c->nb_bits = 13;
+	c->fast = false; c->kept_bytes = 0; c->fast_budget = 0; c->t_pass0 = 0; c->t_pass0_set = false;
 	c->host_valid = false; c->hm_keys = 0; c->hm_used = 0; c->hm_slots = 0; c->hts = 0;
 	c->dev = (int)env_i64("YAKAMD_DEVICE", 0);
 	{
@@ -211,6 +284,8 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 
 static void pass_free(yakamd_ctx *c)
 {
+	for (auto &k : c->kept) { dfree(k.d_hash); dfree(k.d_t); }
+	c->kept.clear(); c->kept_bytes = 0;
 	dfree(c->acc.s); c->acc_count = 0;
 	dfree(c->d_rh); dfree(c->d_rt); c->rec_cap = 0;
 	dfree(c->d_newlist); dfree(c->d_miss); dfree(c->d_cand); c->new_cap = 0;
@@ -222,7 +297,7 @@ void yk_ctx_destroy(yakamd_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->dev);
 	pass_free(c);
-	dfree(c->d_stage);
+	dfree(c->d_stage); dfree(c->d_rows); dfree(c->d_partial); dfree(c->d_bstart);
 	dfree(c->d_bits); dfree(c->d_used); dfree(c->d_delta); dfree(c->d_off); dfree(c->d_keys);
 	dfree(c->d_bf); dfree(c->d_multi);
 	dfree(c->d_counters); dfree(c->d_lastput); dfree(c->d_lpbatch); dfree(c->d_missing); dfree(c->d_nmissing);
@@ -292,6 +367,14 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipMemsetAsync(c->d_counters, 0, YKC_N * 8, c->st));
 	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));
 	c->st_cur.ms_total = now_ms();
+	/* exclusive-ownership LDS counting needs level-1 buckets == sub-tables and 2-bit k-mers */
+	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && c->k < 32;
+	c->kept_bytes = 0; c->t_pass0_set = false; c->ms_part2 = c->ms_lds = 0;
+	if (c->fast) {
+		size_t fr = 0, tot = 0;
+		HIPCK(hipMemGetInfo(&fr, &tot));
+		c->fast_budget = (u64)env_i64("YAKAMD_FAST_BUDGET", (int64_t)((fr + yk_pool_cached_bytes()) / 4));
+	}
 	return 0;
 }
 
@@ -368,6 +451,16 @@ static int rec_reserve(yakamd_ctx *c, int64_t n)
 	return dmalloc(&c->d_rh, (size_t)n) || dmalloc(&c->d_rt, (size_t)n) ? -1 : 0;
 }
 
+static int part_reserve(yakamd_ctx *c, int n_blk)
+{
+	const size_t NB = (size_t)1 << c->nb_bits;
+	if (!c->d_partial && (dmalloc(&c->d_partial, NB * yk_part_groups()) || dmalloc(&c->d_bstart, NB + 1))) return -1;
+	if (n_blk <= c->rows_blk) return 0;
+	dfree(c->d_rows);
+	c->rows_blk = n_blk;
+	return dmalloc(&c->d_rows, NB * (size_t)n_blk);
+}
+
 static int new_reserve(yakamd_ctx *c, int64_t n)
 {
 	if (!c->bloom_mode || n <= c->new_cap) return 0;
@@ -410,6 +503,53 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	return lastput_phase(c, n_rec, t0, batch_lo, batch_hi, img_nonempty);
 }
 
+/* ---- fast path bookkeeping ---- */
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi);
+
+/* leave the fast path: push every kept batch through the accumulator path, in stream order */
+static int fast_abandon(yakamd_ctx *c)
+{
+	c->fast = false;
+	u64 *keep_h = c->d_rh; u32 *keep_t = c->d_rt;
+	int r = 0;
+	for (auto &k : c->kept) {
+		c->d_rh = k.d_hash; c->d_rt = k.d_t;
+		if (!r) r = consume_records(c, (int64_t)k.n, k.t0, k.t0, k.t0 + k.span);
+		dfree(k.d_hash); dfree(k.d_t);
+	}
+	c->d_rh = keep_h; c->d_rt = keep_t;
+	c->kept.clear(); c->kept_bytes = 0;
+	return r;
+}
+
+/* may this batch (n_pos stream positions starting at time t) stay on the fast path?  If so,
+ * allocate its level-1 output buffers */
+static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, u64 **oh, u32 **ot)
+{
+	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
+	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + n_cap * 12 <= c->fast_budget;
+	if (!fits) { if (fast_abandon(c)) return -1; return 0; }
+	yakamd_ctx::Kept k;
+	k.d_hash = 0; k.d_t = 0; k.n = 0; k.t0 = t; k.span = n_pos;
+	if (dmalloc(&k.d_hash, (size_t)n_cap) || dmalloc(&k.d_t, (size_t)n_cap)) return -1;
+	c->kept_bytes += n_cap * 12;
+	c->kept.push_back(k);
+	*oh = k.d_hash; *ot = k.d_t;
+	return 0;
+}
+
+static int fast_keep(yakamd_ctx *c, u64 n_rec)
+{
+	yakamd_ctx::Kept &k = c->kept.back();
+	const size_t NB = (size_t)1 << c->nb_bits;
+	k.bstart.resize(NB + 1);
+	HIPCK(hipMemcpyAsync(k.bstart.data(), c->d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	k.n = n_rec;
+	c->st_cur.n_instances += (int64_t)n_rec;
+	return 0;
+}
+
 extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0)
 {
 	yakamd_ctx *c = ctx_of(h);
@@ -417,19 +557,25 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	if (c->k >= 32) return fail("k >= 32 is not implemented on the device yet");
 	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
 	HIPCK(hipSetDevice(c->dev));
-	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 26);
+	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 27);
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
-	if (rec_reserve(c, std::min(batch, (n_bytes + 4095) & ~(int64_t)4095))) return -1;
+	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
+	if (rec_reserve(c, bmax) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;
 	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
 		const int64_t end = std::min(n_bytes, pos + batch);
 		u64 n_rec = 0;
-		HIPCK(hipMemsetAsync(c->d_counters + YKC_INST, 0, 8, c->st));
+		u64 *oh = c->d_rh; u32 *ot = c->d_rt;
+		if (c->fast) {                                   /* the batch stays resident until pass_end */
+			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &oh, &ot)) return -1;
+		}
 		{
 			EvTimer tm(c->st);
-			yk_launch_extract((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->d_rh, c->d_rt, c->d_counters + YKC_INST, c->st);
-			HIPCK(hipMemcpyAsync(&n_rec, c->d_counters + YKC_INST, 8, hipMemcpyDeviceToHost, c->st));
+			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
+			                c->d_rows, c->d_partial, c->d_bstart, oh, ot, c->st);
+			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 			c->st_cur.ms_extract += tm.stop();
 		}
+		if (c->fast) { if (fast_keep(c, n_rec)) return -1; if (t0 + (u64)end > c->t_end) c->t_end = t0 + (u64)end; continue; }
 		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end)) return -1;
 	}
 	return 0;
@@ -454,12 +600,18 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("feed outside a pass");
 	HIPCK(hipSetDevice(c->dev));
-	/* records are consumed in place */
-	u64 *keep_h = c->d_rh; u32 *keep_t = c->d_rt;
-	c->d_rh = (u64*)d_hash; c->d_rt = (u32*)d_t;
-	const int r = consume_records(c, n, t0, t0, t0 + t_span);
-	c->d_rh = keep_h; c->d_rt = keep_t;
-	return r;
+	/* group the records by sub-table prefix first (same locality as the extraction path) */
+	if (n <= 0) return 0;
+	if (rec_reserve(c, n) || part_reserve(c, yk_rpart_blocks(n))) return -1;
+	u64 n_rec = 0;
+	u64 *oh = c->d_rh; u32 *ot = c->d_rt;
+	if (c->fast && fast_admit(c, t0, t_span, (u64)n, &oh, &ot)) return -1;
+	yk_launch_rpart((const u64*)d_hash, (const u32*)d_t, n, c->pre, c->plo, c->phi, c->nb_bits,
+	                c->d_rows, c->d_partial, c->d_bstart, oh, ot, c->st);
+	HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (c->fast) { if (t0 + t_span > c->t_end) c->t_end = t0 + t_span; return fast_keep(c, n_rec); }
+	return consume_records(c, (int64_t)n_rec, t0, t0, t0 + t_span);
 }
 
 extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
@@ -497,7 +649,7 @@ static u32 plan_cap(u32 cap, u32 cnt, u32 m, bool may_trail)
 
 /* rebuild the image from per-sub-table ordered record lists.  rec_t/lastput may be NULL (shrink) */
 static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg_off, const u64 *d_rec_kc, const u64 *d_rec_t,
-                      const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty)
+                      const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty, const std::vector<u64> *rec_off = 0)
 {
 	const int P = c->P;
 	std::vector<ReplayTask> tasks(P);
@@ -508,7 +660,7 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 		t.old_bits = from_empty ? YK_NOCAP : c->h_bits[p];
 		t.old_count = from_empty ? 0 : c->h_count[p];
 		t.old_off = c->h_off[p];
-		t.rec_off = rec; t.m = m[p]; rec += m[p];
+		t.rec_off = rec_off ? (*rec_off)[p] : rec; t.m = m[p]; rec += m[p];
 		t.init_bits = init_bits ? (*init_bits)[p] : YK_NOCAP;
 		u32 cap0 = t.old_bits == YK_NOCAP ? 0 : 1u << t.old_bits;
 		if (cap0 == 0 && t.init_bits != YK_NOCAP) cap0 = 1u << t.init_bits;
@@ -544,6 +696,122 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	return 0;
 }
 
+/* pass_end of the fast path: level-2 partition -> exclusive LDS counting (+ bloom gate) ->
+ * per sub-table sort by insertion time -> exact layout replay */
+static int fast_finish(yakamd_ctx *c)
+{
+	const int P = c->P;
+	u64 n_total = 0;
+	for (auto &k : c->kept) n_total += k.n;
+	/* chunk table: runs of one sub-table's records, grouped by sub-table */
+	std::vector<Chunk2> chunks;
+	std::vector<u32> chunk_first(P + 1, 0);
+	std::vector<u64> bbase(P + 1, 0);
+	for (int p = 0; p < P; ++p) {
+		chunk_first[p] = (u32)chunks.size();
+		u64 np = 0;
+		for (auto &k : c->kept) {
+			const u64 a = k.bstart[p], b = k.bstart[p + 1];
+			for (u64 o = a; o < b; o += YK_CH2) {
+				Chunk2 ch;
+				ch.hash = k.d_hash + o; ch.tlo = k.d_t + o;
+				ch.n = (u32)std::min<u64>(YK_CH2, b - o); ch.bucket = (u32)p;
+				ch.tbase = (u32)(k.t0 - c->t_pass0); ch.pad = 0;
+				chunks.push_back(ch);
+			}
+			np += b - a;
+		}
+		bbase[p + 1] = bbase[p] + np;
+	}
+	chunk_first[P] = (u32)chunks.size();
+	FastParams fp;
+	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
+	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
+	int s2 = n_total ? ceil_log2_u64((n_total / (u64)P + 1023) / 1024) : 0;
+	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
+	if (s2 > 11) s2 = 11;
+	if (s2 < 0) s2 = 0;
+	if (c->bloom_mode && s2 > c->nb - 9) s2 = c->nb - 9;     /* a sub-bucket owns whole 512-bit blocks */
+	fp.s2_bits = s2;
+	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
+
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_t2 = 0, *d_segcur = 0, *d_ovf = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_h2 = 0;
+	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
+	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2) ||
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_h2, n_total) || dmalloc(&d_t2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb)) return -1;
+	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
+	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));
+	{
+		EvTimer tm(c->st);
+		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_h2, d_t2, c->st);
+		c->ms_part2 = tm.stop();
+		c->st_cur.ms_extract += c->ms_part2;
+	}
+	for (auto &k : c->kept) { dfree(k.d_hash); dfree(k.d_t); }
+	c->kept.clear(); c->kept_bytes = 0;
+	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
+	if (dmalloc(&kc[0], n_total) || dmalloc(&tt[0], n_total)) return -1;
+	u64 h_cnt[YKC_N];
+	{
+		EvTimer tm(c->st);
+		yk_launch_lds_count(fp, P, d_sbstart, d_h2, d_t2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		                    c->d_lastput, c->d_counters, d_ovf, c->st);
+		c->ms_lds = tm.stop();
+		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
+	}
+	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (h_cnt[YKC_NOVF]) {      /* sub-buckets with too many distinct k-mers for LDS: same algorithm on global scratch */
+		const u32 n_ovf = (u32)h_cnt[YKC_NOVF];
+		std::vector<u32> ovf(n_ovf);
+		std::vector<u64> sbs(n_sb + 1), off(n_ovf);
+		HIPCK(hipMemcpy(ovf.data(), d_ovf, n_ovf * 4, hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(sbs.data(), d_sbstart, (n_sb + 1) * 8, hipMemcpyDeviceToHost));
+		u64 words = 0;
+		for (u32 i = 0; i < n_ovf; ++i) {
+			const u64 n = sbs[ovf[i] + 1] - sbs[ovf[i]];
+			u64 cap = 4096; while (cap < 2 * n) cap <<= 1;
+			off[i] = words; words += 4 * cap;               /* 32 B per slot = 4 u64 */
+		}
+		u64 *d_scr = 0, *d_off = 0;
+		if (dmalloc(&d_scr, words) || dmalloc(&d_off, n_ovf)) return -1;
+		HIPCK(hipMemcpyAsync(d_off, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
+		EvTimer tm(c->st);
+		yk_launch_lds_count_ovf(fp, d_sbstart, d_h2, d_t2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		                        c->d_lastput, c->d_counters, d_ovf, n_ovf, d_off, d_scr, c->st);
+		c->st_cur.ms_insert += tm.stop();
+		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+		dfree(d_scr); dfree(d_off);
+	}
+	c->st_cur.n_distinct_seen = (int64_t)h_cnt[YKC_NDIST];
+	dfree(d_h2); dfree(d_t2); dfree(d_sbstart); dfree(d_ovf);
+	std::vector<u32> m(P);
+	HIPCK(hipMemcpy(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost));
+	if (dmalloc(&kc[1], n_total) || dmalloc(&tt[1], n_total)) return -1;
+	int cur = 0;
+	{
+		EvTimer tm(c->st);
+		const int tbits = std::max(1, ceil_log2_u64(c->t_end + 1));
+		for (int shift = 0; shift < tbits; shift += 8) {
+			yk_launch_seg_sort_pass2(d_bbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
+			cur ^= 1;
+		}
+		c->st_cur.ms_sort += tm.stop();
+	}
+	{
+		EvTimer tm(c->st);
+		std::vector<u64> ro(bbase.begin(), bbase.begin() + P);
+		if (run_replay(c, m, 0, kc[cur], tt[cur], c->d_lastput, 0, false, &ro)) return -1;
+		c->st_cur.ms_replay += tm.stop();
+	}
+	dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); dfree(d_bbase); dfree(d_segcur);
+	return 0;
+}
+
 extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 {
 	yakamd_ctx *c = ctx_of(h);
@@ -555,7 +823,13 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		c->host_valid = false;
+	} else if (c->fast && !c->acc.s) {
+		const u64 before = c->img_keys_total;
+		if (fast_finish(c)) return -1;
+		n_ins = (int64_t)(c->img_keys_total - before);
+		c->st_cur.n_new_keys = n_ins;
 	} else {
+		if (c->fast && fast_abandon(c)) return -1;          /* cannot happen today; keeps the invariant explicit */
 		const u64 before = c->img_keys_total;
 		if (c->img_keys_total) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* put-calls that hit existing keys */
 		std::vector<u32> m(P, 0);

@@ -14,5 +14,6 @@ int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, con
 int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
 u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);
 int  yk_ctx_device(yakamd_ctx *c);
+size_t yk_pool_cached_bytes(void);
 hipStream_t yk_ctx_stream(yakamd_ctx *c);
 #endif

@@ -84,24 +84,25 @@ __device__ const unsigned char d_nt4[256] = {
 #define XT_ROUNDS  (XT_TILE / XT_THREADS)
 #define XT_HALO    32
 
-__global__ __launch_bounds__(XT_THREADS)
-void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-               u64 *__restrict__ out_hash, u32 *__restrict__ out_t, u64 *cursor)
+struct XtTile {
+	u32 code[XT_TILE / 16 + 4];      /* 2 bits per base, 16 bases per word, base j of the stream at bits 2(j%16) */
+	u32 valid[XT_TILE / 32 + 4];     /* 1 bit per base: ACGT or not */
+	unsigned char lut[256];
+};
+
+__device__ __forceinline__ void xt_init(XtTile &S)
 {
-	__shared__ u32 s_code[XT_TILE / 16 + 4];
-	__shared__ u32 s_valid[XT_TILE / 32 + 4];
-	__shared__ unsigned char s_lut[256];
-	__shared__ u32 s_cnt[XT_ROUNDS * 4];
-	__shared__ u64 s_base;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int64_t tile0 = pos0 + (int64_t)blockIdx.x * XT_TILE;   /* pos0 is a multiple of 16 */
-	const int64_t origin = tile0 - XT_HALO;
-
-	if (tid < 64) ((u32*)s_lut)[tid] = ((const u32*)d_nt4)[tid];
-	if (tid < 4) { s_code[XT_TILE / 16 + tid] = 0; s_valid[XT_TILE / 32 + tid] = 0; }
+	const int tid = threadIdx.x;
+	if (tid < 64) ((u32*)S.lut)[tid] = ((const u32*)d_nt4)[tid];
+	if (tid < 4) { S.code[XT_TILE / 16 + tid] = 0; S.valid[XT_TILE / 32 + tid] = 0; }
 	__syncthreads();
+}
 
-	for (int w = tid; w < (XT_TILE + XT_HALO) / 16; w += XT_THREADS) {
+/* phase 1: translate + pack the tile [tile0 - HALO, tile0 + XT_TILE) into LDS; ends with a barrier */
+__device__ __forceinline__ void xt_load(XtTile &S, const uint8_t *__restrict__ bases, int64_t tile0, int64_t n)
+{
+	const int64_t origin = tile0 - XT_HALO;
+	for (int w = threadIdx.x; w < (XT_TILE + XT_HALO) / 16; w += XT_THREADS) {
 		const int64_t pos = origin + 16 * (int64_t)w;
 		u32 code = 0, val = 0;
 		if (pos >= 0 && pos + 16 <= n) {
@@ -109,42 +110,64 @@ void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64
 			const u32 q[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int j = 0; j < 16; ++j) {
-				const u32 c = s_lut[(q[j >> 2] >> (8 * (j & 3))) & 0xff];
+				const u32 c = S.lut[(q[j >> 2] >> (8 * (j & 3))) & 0xff];
 				if (c < 4) { code |= c << (2 * j); val |= 1u << j; }
 			}
 		} else {
 			for (int j = 0; j < 16; ++j) {
 				const int64_t x = pos + j;
 				if (x >= 0 && x < n) {
-					const u32 c = s_lut[bases[x]];
+					const u32 c = S.lut[bases[x]];
 					if (c < 4) { code |= c << (2 * j); val |= 1u << j; }
 				}
 			}
 		}
-		s_code[w] = code;
-		((unsigned short*)s_valid)[w] = (unsigned short)val;
+		S.code[w] = code;
+		((unsigned short*)S.valid)[w] = (unsigned short)val;
 	}
 	__syncthreads();
+}
 
+/* phase 2: hashed canonical k-mer ending at tile position r * XT_THREADS + tid; false if the window
+ * holds a non-ACGT byte or lies beyond n */
+__device__ __forceinline__ bool xt_kmer(const XtTile &S, int r, int k, u64 mask, u64 kones, int64_t tile0, int64_t n, u64 *h)
+{
+	const int e = XT_HALO + r * XT_THREADS + (int)threadIdx.x;      /* LDS base index of the k-mer's last base */
+	const int s = e - k + 1;
+	const u64 V = ((u64)S.valid[s >> 5] | (u64)S.valid[(s >> 5) + 1] << 32) >> (s & 31);
+	const int w0 = s >> 4, o = 2 * (s & 15);
+	const u64 lo = (u64)S.code[w0] | (u64)S.code[w0 + 1] << 32;
+	u64 W = lo >> o;
+	if (o) W |= (u64)S.code[w0 + 2] << (64 - o);
+	W &= mask;
+	const u64 rv = ~W & mask;                          /* count.c:37: base j of the window at bits 2j, complemented */
+	const u64 fw = yk_rev2(W) >> (64 - 2 * k);         /* count.c:36: first base most significant */
+	*h = yk_hash64(fw < rv ? fw : rv, mask);
+	return (V & kones) == kones && tile0 + r * XT_THREADS + threadIdx.x < n;
+}
+
+/* compacting extraction (no partition): used for the explicit extract entry point */
+__global__ __launch_bounds__(XT_THREADS)
+void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+               u64 *__restrict__ out_hash, u32 *__restrict__ out_t, u64 *cursor)
+{
+	__shared__ XtTile S;
+	__shared__ u32 s_cnt[XT_ROUNDS * 4];
+	__shared__ u64 s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t tile0 = pos0 + (int64_t)blockIdx.x * XT_TILE;   /* pos0 is a multiple of 16 */
+	xt_init(S);
+	xt_load(S, bases, tile0, n);
 	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
 	const u32 pmask = (1u << pre) - 1;
 	u64 hv[XT_ROUNDS];
 	u32 okm = 0;
 #pragma unroll
 	for (int r = 0; r < XT_ROUNDS; ++r) {
-		const int e = XT_HALO + r * XT_THREADS + tid;      /* LDS base index of the k-mer's last base */
-		const int s = e - k + 1;
-		const u64 V = ((u64)s_valid[s >> 5] | (u64)s_valid[(s >> 5) + 1] << 32) >> (s & 31);
-		const int w0 = s >> 4, o = 2 * (s & 15);
-		const u64 lo = (u64)s_code[w0] | (u64)s_code[w0 + 1] << 32;
-		u64 W = lo >> o;
-		if (o) W |= (u64)s_code[w0 + 2] << (64 - o);
-		W &= mask;
-		const u64 rv = ~W & mask;                          /* count.c:37: base j of the window at bits 2j, complemented */
-		const u64 fw = yk_rev2(W) >> (64 - 2 * k);         /* count.c:36: first base most significant */
-		const u64 h = yk_hash64(fw < rv ? fw : rv, mask);
+		u64 h;
+		bool ok = xt_kmer(S, r, k, mask, kones, tile0, n, &h);
 		const u32 p = (u32)h & pmask;
-		const bool ok = (V & kones) == kones && tile0 + r * XT_THREADS + tid < n && (int)p >= plo && (int)p < phi;
+		ok = ok && (int)p >= plo && (int)p < phi;
 		hv[r] = h;
 		okm |= (u32)ok << r;
 		const u64 b = __ballot(ok);
@@ -168,6 +191,140 @@ void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64
 			out_t[d] = (u32)(tile0 + r * XT_THREADS + tid - t_sub);
 		}
 	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K1 with radix partition: the hashed k-mers of a batch are grouped by the top `nb_bits` of their
+ * sub-table prefix, so that every later pass walks the accumulator / bloom / table image one
+ * contiguous region at a time (the regions being worked on at any moment stay cache resident).
+ * Two sweeps over the bases, no global atomics:
+ *   hist   : one workgroup = XP_T tiles; bucket counts in an LDS histogram -> one row of `rows`
+ *   scan   : rows -> exclusive offsets (per bucket across workgroups) + bucket starts
+ *   scatter: same workgroups recompute their k-mers and place them with LDS cursors
+ * The same two kernels partition already-hashed records (SRC = 1: exchanged k-mers of the
+ * multi-GPU path, yak_ch_insert_list).
+ * ------------------------------------------------------------------------------------------ */
+#define XP_T 16                                   /* tiles per workgroup: 65536 stream positions */
+
+__device__ __forceinline__ u32 bucket_of(u64 h, int pre, int nb_bits)
+{
+	const u32 p = (u32)h & ((1u << pre) - 1);
+	return nb_bits <= pre ? p >> (pre - nb_bits) : p;   /* nb_bits is clamped to pre by the host */
+}
+
+template <int MODE>   /* 0 = histogram, 1 = scatter */
+__global__ __launch_bounds__(XT_THREADS)
+void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+             int nb_bits, u32 *rows, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
+	__shared__ XtTile S;
+	const int NB = 1 << nb_bits;
+	u32 *row = rows + (size_t)blockIdx.x * NB;
+	for (int j = threadIdx.x; j < NB; j += XT_THREADS) s_bkt[j] = MODE ? row[j] : 0;
+	xt_init(S);
+	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	const u32 pmask = (1u << pre) - 1;
+	for (int t = 0; t < XP_T; ++t) {
+		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
+		if (tile0 >= n) break;
+		xt_load(S, bases, tile0, n);
+#pragma unroll 4
+		for (int r = 0; r < XT_ROUNDS; ++r) {
+			u64 h;
+			bool ok = xt_kmer(S, r, k, mask, kones, tile0, n, &h);
+			const u32 p = (u32)h & pmask;
+			ok = ok && (int)p >= plo && (int)p < phi;
+			if (ok) {
+				const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
+				if (MODE) { out_hash[d] = h; out_t[d] = (u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub); }
+			}
+		}
+		__syncthreads();
+	}
+	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += XT_THREADS) row[j] = s_bkt[j]; }
+}
+
+#define RP_CHUNK 65536
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_rpart(const u64 *__restrict__ in_hash, const u32 *__restrict__ in_t, int64_t n, int pre, int plo, int phi,
+             int nb_bits, u32 *rows, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
+	const int NB = 1 << nb_bits;
+	u32 *row = rows + (size_t)blockIdx.x * NB;
+	for (int j = threadIdx.x; j < NB; j += 256) s_bkt[j] = MODE ? row[j] : 0;
+	__syncthreads();
+	const int64_t lo = (int64_t)blockIdx.x * RP_CHUNK, hi = lo + RP_CHUNK < n ? lo + RP_CHUNK : n;
+	const u32 pmask = (1u << pre) - 1;
+	for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+		const u64 h = in_hash[i];
+		const u32 p = (u32)h & pmask;
+		if ((int)p >= plo && (int)p < phi) {
+			const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
+			if (MODE) { out_hash[d] = h; out_t[d] = in_t[i]; }
+		}
+	}
+	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += 256) row[j] = s_bkt[j]; }
+}
+
+/* rows[blk][b] (counts) -> rows[blk][b] (absolute start of that workgroup's run in bucket b);
+ * bstart[b] = first record of bucket b, bstart[NB] = total.  Rows are summed in PS_G groups so the
+ * scan is three short, wide kernels instead of one long serial one. */
+#define PS_G 64
+__global__ __launch_bounds__(256)
+void k_part_sum(const u32 *rows, int n_blk, int NB, u64 *partial)
+{
+	const int b = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+	if (b >= NB) return;
+	const int per = (n_blk + PS_G - 1) / PS_G, lo = g * per, hi = lo + per < n_blk ? lo + per : n_blk;
+	u64 acc = 0;
+	for (int i = lo; i < hi; ++i) acc += rows[(size_t)i * NB + b];
+	partial[(size_t)g * NB + b] = acc;
+}
+
+__global__ __launch_bounds__(256)
+void k_part_mid(u64 *partial, int NB, u64 *bstart)
+{
+	__shared__ u64 s_tot[256];
+	__shared__ u64 s_carry;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (int b0 = 0; b0 < NB; b0 += 256) {
+		const int b = b0 + threadIdx.x;
+		u64 run = 0;
+		if (b < NB) for (int g = 0; g < PS_G; ++g) { const u64 c = partial[(size_t)g * NB + b]; partial[(size_t)g * NB + b] = run; run += c; }
+		s_tot[threadIdx.x] = run;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			u64 acc = s_carry;
+			for (int j = 0; j < 256; ++j) { const u64 c = s_tot[j]; s_tot[j] = acc; acc += c; }
+			s_carry = acc;
+		}
+		__syncthreads();
+		if (b < NB) bstart[b] = s_tot[threadIdx.x];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) bstart[NB] = s_carry;
+}
+
+__global__ __launch_bounds__(256)
+void k_part_fin(u32 *rows, int n_blk, int NB, const u64 *partial, const u64 *bstart)
+{
+	const int b = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+	if (b >= NB) return;
+	const int per = (n_blk + PS_G - 1) / PS_G, lo = g * per, hi = lo + per < n_blk ? lo + per : n_blk;
+	u64 run = bstart[b] + partial[(size_t)g * NB + b];
+	for (int i = lo; i < hi; ++i) { const u32 c = rows[(size_t)i * NB + b]; rows[(size_t)i * NB + b] = (u32)run; run += c; }
+}
+
+static void launch_part_scan(u32 *rows, int n_blk, int nb_bits, u64 *partial, u64 *bstart, hipStream_t st)
+{
+	const int NB = 1 << nb_bits;
+	hipLaunchKernelGGL(k_part_sum, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial);
+	hipLaunchKernelGGL(k_part_mid, dim3(1), dim3(256), 0, st, partial, NB, bstart);
+	hipLaunchKernelGGL(k_part_fin, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial, bstart);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -640,13 +797,13 @@ void k_select_scatter(AccTab tab, int bloom_mode, const u64 *seg_off, u32 *seg_c
  * ------------------------------------------------------------------------------------------ */
 #define SS_E 8
 __global__ __launch_bounds__(256)
-void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
+void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ seg_len, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
                      u64 *__restrict__ dst_kc, u64 *__restrict__ dst_t, int shift)
 {
 	__shared__ u32 s_hist[256];
 	__shared__ u32 s_wc[4][256];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const u64 a = seg_off[blockIdx.x], len = seg_off[blockIdx.x + 1] - a;
+	const u64 a = seg_off[blockIdx.x], len = seg_len ? (u64)seg_len[blockIdx.x] : seg_off[blockIdx.x + 1] - a;
 	if (len == 0) return;
 	if (len == 1) { if (tid == 0) { dst_kc[a] = src_kc[a]; dst_t[a] = src_t[a]; } return; }
 	s_hist[tid] = 0;
@@ -871,6 +1028,294 @@ void k_fill_u64(u64 *p, u64 v, u64 n)
 	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+/* ==========================================================================================
+ * FAST PATH: exclusive-ownership counting.
+ * Device atomics on gfx950 execute at the memory side whatever their scope, ~10 G/s at best, and a
+ * pass needs 1-3 of them per k-mer instance.  So the instances of a pass are radix-partitioned
+ * twice -- by sub-table prefix (k_xpart / k_rpart), then into sub-buckets small enough for an
+ * LDS hash table (k_part2) -- and ONE workgroup then owns a sub-bucket outright: it counts its
+ * k-mers with LDS atomics only, owns the bloom blocks they map to (so the gate of bbf.c:25-42 /
+ * htab.c:63-65 is evaluated per 512-bit block, sequentially in stream order, exactly as the
+ * reference does), and emits just the keys that enter the table.  No global atomics per instance.
+ * ========================================================================================== */
+__device__ __forceinline__ u32 sub_of(u64 h, const FastParams &fp)
+{
+	const u64 x = h >> fp.pre;
+	if (fp.s2_bits == 0) return 0;
+	if (fp.bloom_mode) {                      /* sub-bucket = a contiguous range of bloom blocks */
+		const int bb = fp.nb - 9;
+		return (u32)((x & ((1ull << bb) - 1)) >> (bb - fp.s2_bits));
+	}
+	return (u32)((x * 0x9E3779B97F4A7C15ull) >> (64 - fp.s2_bits));
+}
+
+template <int MODE>   /* 0 = histogram, 1 = scatter */
+__global__ __launch_bounds__(256)
+void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
+	const Chunk2 c = chunks[blockIdx.x];
+	const int S2 = 1 << fp.s2_bits;
+	u32 *row = rows2 + (size_t)blockIdx.x * S2;
+	for (int j = threadIdx.x; j < S2; j += 256) s_bkt[j] = MODE ? row[j] : 0;
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < c.n; i += 256) {
+		const u64 h = c.hash[i];
+		const u32 d = atomicAdd(&s_bkt[sub_of(h, fp)], 1u);
+		if (MODE) { out_hash[d] = h; out_t[d] = c.tlo[i] + c.tbase; }
+	}
+	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += 256) row[j] = s_bkt[j]; }
+}
+
+/* one workgroup per level-1 bucket: rows2 counts -> absolute offsets; sbstart[bucket * S2 + s] */
+__global__ __launch_bounds__(256)
+void k_part2_scan(const u32 *chunk_first, const u64 *bbase, int s2_bits, u32 *rows2, u64 *sbstart, int P)
+{
+	__shared__ u64 s_tot[256];
+	__shared__ u64 s_carry;
+	const int S2 = 1 << s2_bits, b = blockIdx.x;
+	const u32 c0 = chunk_first[b], c1 = chunk_first[b + 1];
+	if (threadIdx.x == 0) s_carry = bbase[b];
+	__syncthreads();
+	for (int s0 = 0; s0 < S2; s0 += 256) {
+		const int s = s0 + threadIdx.x;
+		u64 tot = 0;
+		if (s < S2) for (u32 c = c0; c < c1; ++c) tot += rows2[(size_t)c * S2 + s];
+		s_tot[threadIdx.x] = tot;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			u64 acc = s_carry;
+			for (int j = 0; j < 256; ++j) { const u64 t = s_tot[j]; s_tot[j] = acc; acc += t; }
+			s_carry = acc;
+		}
+		__syncthreads();
+		if (s < S2) {
+			u64 run = s_tot[threadIdx.x];
+			sbstart[(size_t)b * S2 + s] = run;
+			for (u32 c = c0; c < c1; ++c) { const u32 v = rows2[(size_t)c * S2 + s]; rows2[(size_t)c * S2 + s] = (u32)run; run += v; }
+		}
+		__syncthreads();
+	}
+	if (b == P - 1 && threadIdx.x == 0) sbstart[(size_t)P * S2] = s_carry;
+}
+
+#define LC_EXIST 0x40000000u
+#define LC_FP    0x80000000u
+#define LC_CMASK 0x0fffffffu
+#define T32_INF  0xffffffffu
+
+struct LcTab { u64 *K; u32 *T1, *T2, *CN; u64 *SO; u32 *SP; u32 cap; };
+
+template <bool GLB> __device__ __forceinline__ void lc_sync() { if (GLB) block_sync_global(); else __syncthreads(); }
+
+__device__ __forceinline__ u32 lc_home(u64 key, int pre, u32 cap) { return (u32)(((key >> pre) * 0x9E3779B97F4A7C15ull) >> 24) & (cap - 1); }
+
+__device__ __forceinline__ int lc_find(const LcTab &T, u64 key, int pre)
+{
+	u32 s = lc_home(key, pre, T.cap);
+	for (u32 n = 0; n < T.cap; ++n, s = (s + 1) & (T.cap - 1)) {
+		const u64 cur = T.K[s];
+		if (cur == key) return (int)s;
+		if (cur == YK_EMPTY) return -1;
+	}
+	return -1;
+}
+
+/* body shared by the LDS kernel (GLB = false) and the global-scratch fallback for sub-buckets
+ * whose distinct k-mers do not fit the LDS table (GLB = true).  Returns false on LDS overflow. */
+template <bool GLB>
+__device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 *__restrict__ sbstart,
+                        const u64 *__restrict__ rec_hash, const u32 *__restrict__ rec_t, u32 *bloom32, const ImgView &img,
+                        const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
+                        u32 *s_misc /* [8] in LDS */)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u32 p = sb >> fp.s2_bits;
+	const u64 lo = sbstart[sb], hi = sbstart[sb + 1];
+	if (lo == hi) return true;
+	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_w = s_misc + 4;
+	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; }
+	if (tid < 4) s_misc[tid] = 0;
+	lc_sync<GLB>();
+
+	/* A: count; first / second occurrence times (same loser rule as k_acc_insert) */
+	u32 tmax = 0;
+	for (u64 i = lo + tid; i < hi; i += 256) {
+		const u64 key = rec_hash[i];
+		const u32 t = rec_t[i];
+		u32 s = lc_home(key, fp.pre, T.cap), n = 0;
+		for (; n < T.cap; ++n, s = (s + 1) & (T.cap - 1)) {
+			u64 cur = T.K[s];
+			if (cur == key) break;
+			if (cur == YK_EMPTY) {
+				cur = atomicCAS(&T.K[s], YK_EMPTY, key);
+				if (cur == YK_EMPTY) { atomicAdd(s_ndist, 1u); break; }
+				if (cur == key) break;
+			}
+		}
+		if (n == T.cap) { *s_ovf = 1; continue; }
+		atomicAdd(&T.CN[s], 1u);
+		const u32 old = atomicMin(&T.T1[s], t);
+		if (fp.bloom_mode && old != T32_INF) atomicMin(&T.T2[s], old > t ? old : t);
+		tmax = t + 1 > tmax ? t + 1 : tmax;
+	}
+	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
+	lc_sync<GLB>();
+	if (!GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3)) return false;
+
+	/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key) */
+	if (fp.img_nonempty) {
+		for (u32 s = tid; s < T.cap; s += 256) {
+			if (T.K[s] == YK_EMPTY) continue;
+			const int64_t idx = img_find(img, T.K[s]);
+			if (idx >= 0) {
+				const u64 kc = img.keys[idx], c = (kc & 1023) + (T.CN[s] & LC_CMASK);
+				img.keys[idx] = (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+				T.CN[s] |= LC_EXIST;
+			}
+		}
+		lc_sync<GLB>();
+	}
+
+	/* C: the bloom gate, block by block, in stream order (bbf.c:25-42).  This workgroup is the
+	 * only one whose k-mers map to these 512-bit blocks, so plain loads/stores suffice. */
+	if (fp.bloom_mode) {
+		const int bb = fp.nb - 9, lb = bb - fp.s2_bits;          /* log2 blocks owned by this sub-bucket */
+		const u64 xmask = (1ull << bb) - 1;
+		for (u32 s = tid; s < T.cap; s += 256) {
+			if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
+			const u64 x = T.K[s] >> fp.pre;
+			const u64 blk_local = (x & xmask) & ((1ull << lb) - 1);
+			const u32 j = atomicAdd(s_ne, 1u);
+			T.SO[j] = blk_local << 32 | T.T1[s];
+			T.SP[j] = s;
+		}
+		lc_sync<GLB>();
+		const u32 ne = *s_ne;
+		u32 m = 1; while (m < ne) m <<= 1;
+		for (u32 i = ne + tid; i < m; i += 256) { T.SO[i] = ~0ull; T.SP[i] = 0; }
+		lc_sync<GLB>();
+		for (u32 k2 = 2; k2 <= m; k2 <<= 1)
+			for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+				for (u32 i = tid; i < m; i += 256) {
+					const u32 l = i ^ j;
+					if (l > i) {
+						const u64 a = T.SO[i], b = T.SO[l];
+						if ((a > b) == ((i & k2) == 0)) {
+							T.SO[i] = b; T.SO[l] = a;
+							const u32 t = T.SP[i]; T.SP[i] = T.SP[l]; T.SP[l] = t;
+						}
+					}
+				}
+				lc_sync<GLB>();
+			}
+		for (u32 j0 = tid; j0 < ne; j0 += 256) {
+			const u64 blk_local = T.SO[j0] >> 32;
+			if (j0 && (T.SO[j0 - 1] >> 32) == blk_local) continue;      /* not the first key of its block */
+			const u64 s_idx = sb & ((1u << fp.s2_bits) - 1);
+			const u64 blk = (s_idx << lb) | blk_local;
+			u32 *w = bloom32 + (((u64)p << fp.nb | blk << 9) >> 5);
+			for (u32 j = j0; j < ne && (T.SO[j] >> 32) == blk_local; ++j) {
+				const u32 s = T.SP[j];
+				const u64 x = T.K[s] >> fp.pre;
+				const u32 h1 = (u32)(x >> bb) & 511;
+				u32 h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
+				if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
+				const u32 cyc = 512u / (h2 & (0u - h2));
+				const u32 nd = (u32)fp.n_hash < cyc ? (u32)fp.n_hash : cyc;
+				u32 hits = 0;
+				for (u32 q = 0, z = h1; q < nd; ++q, z = (z + h2) & 511) {
+					const u32 word = w[z >> 5], bit = 1u << (z & 31);
+					if (word & bit) ++hits; else w[z >> 5] = word | bit;
+				}
+				if (hits == nd) T.CN[s] |= LC_FP;                       /* yak_bf_insert() == n_hash */
+			}
+		}
+		lc_sync<GLB>();
+
+	}
+	/* D: last put-call of the sub-bucket = last instance that is not a rejected first occurrence */
+	if (fp.bloom_mode) {
+		u32 best = 0;
+		for (u64 i = lo + tid; i < hi; i += 256) {
+			const u32 t = rec_t[i];
+			if (t + 1 <= best) continue;
+			const int s = lc_find(T, rec_hash[i], fp.pre);
+			if (s < 0) continue;
+			const u32 cn = T.CN[s];
+			if ((cn & (LC_EXIST | LC_FP)) || T.T1[s] != t) best = t + 1;
+		}
+		if (best) atomicMax(s_lp, best);
+		lc_sync<GLB>();
+	}
+	if (tid == 0 && *s_lp) atomicMax(&lastput[p], fp.t_pass0 + (u64)(*s_lp - 1) + 1);
+
+	/* E: keys entering the table -> (key<<10|count, insertion time), appended to the sub-table's list */
+	for (int pass = 0; pass < 2; ++pass) {
+		u32 run = 0;                                          /* pass 0: total; pass 1: running offset */
+		u64 base = 0;
+		if (pass == 1) base = seg_base[p] + s_w[6];
+		for (u32 s0 = 0; s0 < T.cap; s0 += 256) {
+			const u32 s = s0 + tid;
+			bool sel = false; u64 kc = 0; u32 Tt = 0;
+			if (T.K[s] != YK_EMPTY && !(T.CN[s] & LC_EXIST)) {
+				u32 c = T.CN[s] & LC_CMASK;
+				if (!fp.bloom_mode || (T.CN[s] & LC_FP)) { sel = true; Tt = T.T1[s]; }
+				else if (T.T2[s] != T32_INF) { sel = true; Tt = T.T2[s]; c -= 1; }
+				if (c > 1023) c = 1023;
+				kc = (T.K[s] >> fp.pre) << 10 | c;
+			}
+			const u64 bm = __ballot(sel);
+			if (lane == 0) s_w[wave] = __popcll(bm);
+			__syncthreads();
+			u32 pre_w = 0, tot = 0;
+			for (int w = 0; w < 4; ++w) { if (w < wave) pre_w += s_w[w]; tot += s_w[w]; }
+			if (pass == 1 && sel) {
+				const u64 d = base + run + pre_w + __popcll(bm & lanemask_lt());
+				out_kc[d] = kc; out_T[d] = fp.t_pass0 + Tt;
+			}
+			run += tot;
+			__syncthreads();
+		}
+		if (pass == 0) {
+			if (tid == 0) s_w[6] = run ? atomicAdd(&seg_cur[p], run) : 0;
+			__syncthreads();
+		}
+	}
+	if (tid == 0) atomicAdd(&counters[YKC_NDIST], (u64)*s_ndist);
+	return true;
+}
+
+__global__ __launch_bounds__(256)
+void k_lds_count(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t, u32 *bloom32, ImgView img,
+                 const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters, u32 *ovf_list)
+{
+	__shared__ u64 s_K[YK_LDS_C];
+	__shared__ u64 s_SO[YK_LDS_C];
+	__shared__ u32 s_T1[YK_LDS_C], s_T2[YK_LDS_C], s_CN[YK_LDS_C], s_SP[YK_LDS_C];
+	__shared__ u32 s_misc[8];
+	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.SO = s_SO; T.SP = s_SP; T.cap = YK_LDS_C;
+	const u32 sb = blockIdx.x;
+	if (!lc_body<false>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
+		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[YKC_NOVF], 1ull)] = sb;
+}
+
+__global__ __launch_bounds__(256)
+void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t, u32 *bloom32, ImgView img,
+                     const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
+                     const u32 *ovf_list, const u64 *scr_off, u64 *scr)
+{
+	__shared__ u32 s_misc[8];
+	const u32 sb = ovf_list[blockIdx.x];
+	const u64 n = sbstart[sb + 1] - sbstart[sb];
+	u32 cap = 4096; while (cap < 2 * n) cap <<= 1;
+	u64 *base = scr + scr_off[blockIdx.x];
+	LcTab T; T.cap = cap;
+	T.K = base; T.SO = base + cap;
+	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap;
+	lc_body<true>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc);
+}
+
 /* ------------------------------------------------------------------------------------------
  * launch wrappers
  * ------------------------------------------------------------------------------------------ */
@@ -892,6 +1337,33 @@ void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_
 	if (n <= pos0) return;
 	const u64 tiles = ((u64)(n - pos0) + XT_TILE - 1) / XT_TILE;
 	hipLaunchKernelGGL(k_extract, dim3((unsigned)tiles), dim3(XT_THREADS), 0, st, bases, pos0, n, t_sub, k, pre, plo, phi, out_hash, out_t, cursor);
+}
+
+/* partitioning extraction: returns through bstart[1 << nb_bits] (device) the record count */
+void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+{
+	if (n <= pos0) return;
+	const int n_blk = (int)(((u64)(n - pos0) + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE));
+	const size_t lds = sizeof(u32) << nb_bits;
+	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
+	hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+}
+
+int yk_part_groups(void) { return PS_G; }
+int yk_xpart_blocks(int64_t n_pos) { return (int)(((u64)n_pos + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE)); }
+int yk_rpart_blocks(int64_t n_rec) { return (int)(((u64)n_rec + RP_CHUNK - 1) / RP_CHUNK); }
+
+void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+{
+	if (n <= 0) return;
+	const int n_blk = yk_rpart_blocks(n);
+	const size_t lds = sizeof(u32) << nb_bits;
+	hipLaunchKernelGGL(k_rpart<0>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
+	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out_hash, out_t);
 }
 
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st)
@@ -984,7 +1456,7 @@ void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_
 void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_off, src_kc, src_t, dst_kc, dst_t, shift);
+	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
 }
 
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
@@ -1004,6 +1476,39 @@ void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt
 void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_shrink_scatter, dim3(P), dim3(256), 0, st, img, cmin, cmax, seg_off, rec_kc);
+}
+
+void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, FastParams fp, int P,
+                     u32 *rows2, u64 *sbstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+{
+	const size_t lds = sizeof(u32) << fp.s2_bits;
+	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out_hash, out_t);
+	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
+	if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out_hash, out_t);
+}
+
+void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+                         u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
+                         u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st)
+{
+	const unsigned n_sb = (unsigned)P << fp.s2_bits;
+	hipLaunchKernelGGL(k_lds_count, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec_hash, rec_t, bloom32, img,
+	                   seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list);
+}
+
+void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+                             u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
+                             u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u64 *scr, hipStream_t st)
+{
+	if (n_ovf) hipLaunchKernelGGL(k_lds_count_ovf, dim3(n_ovf), dim3(256), 0, st, fp, sbstart, rec_hash, rec_t, bloom32, img,
+	                              seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list, scr_off, scr);
+}
+
+void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
+                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
 }
 
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st)

@@ -70,6 +70,13 @@ extern "C" {
 /* ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ---- */
 void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
                        u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
+void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st);
+void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st);
+int yk_xpart_blocks(int64_t n_pos);
+int yk_part_groups(void);
+int yk_rpart_blocks(int64_t n_rec);
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st);
 void yk_launch_acc_insert(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, AccTab tab, ImgView img,
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
@@ -110,5 +117,44 @@ void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st);
 
 /* counters[] layout (u64 each) */
 enum { YKC_NEW = 0, YKC_INST = 1, YKC_ANYMULTI = 2, YKC_NCAND = 3, YKC_NMARKED = 4, YKC_EXIST = 5, YKC_N = 8 };
+
+
+/* ---------------- fast path (exclusive-ownership LDS counting) ---------------- */
+#define YK_CH2     32768            /* records per level-2 partition chunk */
+#define YK_LDS_C   2048             /* slots of the LDS counting table */
+
+struct Chunk2 {                     /* one level-2 partition work item: a run of one level-1 bucket */
+	const u64 *hash; const u32 *tlo;
+	u32 n, bucket;
+	u32 tbase;                      /* added to tlo: time relative to the start of the pass */
+	u32 pad;
+};
+
+struct FastParams {
+	int pre, k, s2_bits;            /* sub-buckets per sub-table = 1 << s2_bits */
+	int bloom_mode, nb, n_hash;     /* nb = log2 bits per sub-table filter */
+	int img_nonempty;
+	int plo, phi;
+	u64 t_pass0;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
+                     u32 *rows2, u64 *sbstart, u64 *out_hash, u32 *out_t, hipStream_t st);
+void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+                         u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
+                         u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st);
+void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+                             u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
+                             u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u64 *scr, hipStream_t st);
+void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
+                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
+#ifdef __cplusplus
+}
+#endif
+enum { YKC_NOVF = 6, YKC_NDIST = 7 };
 
 #endif
