@@ -368,7 +368,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));
 	c->st_cur.ms_total = now_ms();
 	/* exclusive-ownership LDS counting needs level-1 buckets == sub-tables and 2-bit k-mers */
-	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && c->k < 32;
+	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && c->k < 32 && (!c->has_bloom || c->nb <= 42);
 	c->kept_bytes = 0; c->t_pass0_set = false; c->ms_part2 = c->ms_lds = 0;
 	if (c->fast) {
 		size_t fr = 0, tot = 0;
@@ -703,6 +703,20 @@ static int fast_finish(yakamd_ctx *c)
 	const int P = c->P;
 	u64 n_total = 0;
 	for (auto &k : c->kept) n_total += k.n;
+	FastParams fp;
+	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
+	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
+	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them */
+	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + 599) / 600) : 0;
+	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
+	if (s2 > 13) s2 = 13;
+	if (s2 < 0) s2 = 0;
+	if (c->bloom_mode) {
+		if (s2 > c->nb - 9) s2 = c->nb - 9;                  /* a sub-bucket owns whole 512-bit blocks ... */
+		if (s2 < c->nb - 9 - 20) s2 = c->nb - 9 - 20;        /* ... and at most 2^20 of them (sort-key packing) */
+	}
+	fp.s2_bits = s2;
+	const u64 ch2 = std::max<u64>(YK_CH2, (u64)32 << s2);    /* keep >= 32 records per sub-bucket run */
 	/* chunk table: runs of one sub-table's records, grouped by sub-table */
 	std::vector<Chunk2> chunks;
 	std::vector<u32> chunk_first(P + 1, 0);
@@ -712,10 +726,10 @@ static int fast_finish(yakamd_ctx *c)
 		u64 np = 0;
 		for (auto &k : c->kept) {
 			const u64 a = k.bstart[p], b = k.bstart[p + 1];
-			for (u64 o = a; o < b; o += YK_CH2) {
+			for (u64 o = a; o < b; o += ch2) {
 				Chunk2 ch;
 				ch.hash = k.d_hash + o; ch.tlo = k.d_t + o;
-				ch.n = (u32)std::min<u64>(YK_CH2, b - o); ch.bucket = (u32)p;
+				ch.n = (u32)std::min<u64>(ch2, b - o); ch.bucket = (u32)p;
 				ch.tbase = (u32)(k.t0 - c->t_pass0); ch.pad = 0;
 				chunks.push_back(ch);
 			}
@@ -724,15 +738,6 @@ static int fast_finish(yakamd_ctx *c)
 		bbase[p + 1] = bbase[p] + np;
 	}
 	chunk_first[P] = (u32)chunks.size();
-	FastParams fp;
-	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
-	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
-	int s2 = n_total ? ceil_log2_u64((n_total / (u64)P + 1023) / 1024) : 0;
-	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
-	if (s2 > 11) s2 = 11;
-	if (s2 < 0) s2 = 0;
-	if (c->bloom_mode && s2 > c->nb - 9) s2 = c->nb - 9;     /* a sub-bucket owns whole 512-bit blocks */
-	fp.s2_bits = s2;
 	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
 
 	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_t2 = 0, *d_segcur = 0, *d_ovf = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_h2 = 0;
@@ -774,7 +779,7 @@ static int fast_finish(yakamd_ctx *c)
 		for (u32 i = 0; i < n_ovf; ++i) {
 			const u64 n = sbs[ovf[i] + 1] - sbs[ovf[i]];
 			u64 cap = 4096; while (cap < 2 * n) cap <<= 1;
-			off[i] = words; words += 4 * cap;               /* 32 B per slot = 4 u64 */
+			off[i] = words; words += 5 * cap;               /* 40 B per slot = 5 u64 */
 		}
 		u64 *d_scr = 0, *d_off = 0;
 		if (dmalloc(&d_scr, words) || dmalloc(&d_off, n_ovf)) return -1;

@@ -865,12 +865,18 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
  *   * growth happens at the next put-call once count >= 0.75 capacity (khashl.h:202), including a
  *     trailing put-call on an existing key (lastput vs. time of the last new key).
  * ------------------------------------------------------------------------------------------ */
+#define RP_LDS_WORDS 4096                                 /* doublings up to 131072 slots keep their bitmaps in LDS */
 __device__ __forceinline__ bool bm_get(const u32 *u, u32 i) { return u[i >> 5] >> (i & 31) & 1; }
 
-__device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 nbits_new)
+/* khashl's in-place doubling (khashl.h:171-189), executed literally by ONE lane because the order in
+ * which keys are re-placed is data dependent.  `cur`/`oth` are the old/new "used" bitmaps (LDS when
+ * they fit, else global).  The lane publishes its scan position so that a helper wave can run ahead
+ * and pull the cache lines the kick-out chain is about to touch (replay_prefetch). */
+__device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 nbits_new, volatile u32 *progress)
 {
 	const u32 Nmask = N - 1;
 	for (u32 jw = 0; jw < (n + 31) / 32; ++jw) {
+		*progress = jw * 32;
 		while (cur[jw]) {                                  /* next still-unmoved old slot of this word */
 			const u32 j = jw * 32 + (__ffs((int)cur[jw]) - 1);
 			if (j >= n) { cur[jw] = 0; break; }
@@ -887,6 +893,35 @@ __device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 n
 			}
 		}
 	}
+	*progress = 0xffffffffu;
+}
+
+/* helper wave of the doubling: for old slots a little ahead of the serial lane, touch the line the
+ * key will land on and, one level deeper, the line its kicked-out victim will land on */
+__device__ void replay_prefetch(const u64 *keys, u32 n, u32 nbits_new, volatile u32 *progress, u32 *sink)
+{
+	const u32 lane = threadIdx.x & 63;
+	u32 acc = 0, last = 0xfffffffeu;
+	for (;;) {
+		const u32 p = *progress;
+		if (p == 0xffffffffu) break;
+		if (p == last) { __builtin_amdgcn_s_sleep(8); continue; }
+		last = p;
+		const u32 j = p + 48 + lane;                       /* window [p+48, p+112) */
+		if (j < n) {
+			const u64 key = keys[j];
+			if (key != YK_EMPTY) {
+				const u32 i = yk_h2b((u32)(key >> 10), nbits_new);
+				const u64 v = *(volatile const u64*)&keys[i];
+				acc ^= (u32)v;
+				if (i < n && v != YK_EMPTY) {
+					const u32 i2 = yk_h2b((u32)(v >> 10), nbits_new);
+					acc ^= (u32)*(volatile const u64*)&keys[i2];
+				}
+			}
+		}
+	}
+	if (acc == 0x5a5a5a5au) *sink = acc;                   /* keeps the touches alive */
 }
 
 __global__ __launch_bounds__(256)
@@ -894,6 +929,8 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
               u32 *scr_used, u32 *scr_owner, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
               u32 *out_bits, u32 *out_count)
 {
+	__shared__ u32 s_bm[RP_LDS_WORDS * 3 / 2];            /* new bitmap (N bits) + old bitmap (n bits) of a doubling */
+	__shared__ u32 s_progress;
 	const ReplayTask T = tasks[blockIdx.x];
 	const int tid = threadIdx.x;
 	u64 *keys = new_keys + T.new_off;
@@ -926,10 +963,16 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		}
 		if (grow) {
 			const u32 N = n ? n << 1 : 4, nb = n ? bits + 1 : 2;
-			for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = 0;
+			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS;
+			u32 *wo = in_lds ? s_bm : oth, *wc = in_lds ? s_bm + RP_LDS_WORDS : cur;
+			for (u32 w = tid; w < (N + 31) / 32; w += 256) wo[w] = 0;
+			if (in_lds) for (u32 w = tid; w < (n + 31) / 32; w += 256) wc[w] = cur[w];
+			if (tid == 0) s_progress = 0;
 			block_sync_global();
-			if (tid == 0) replay_double(keys, cur, oth, n, N, nb);
+			if (tid == 0) replay_double(keys, wc, wo, n, N, nb, &s_progress);
+			else if (tid >= 64 && tid < 128) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
 			block_sync_global();
+			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = wo[w]; block_sync_global(); }
 			u32 *t = cur; cur = oth; oth = t;
 			n = N; bits = nb;
 			if (i0 == 0xffffffffu) break;
@@ -1103,42 +1146,38 @@ void k_part2_scan(const u32 *chunk_first, const u64 *bbase, int s2_bits, u32 *ro
 #define LC_FP    0x80000000u
 #define LC_CMASK 0x0fffffffu
 #define T32_INF  0xffffffffu
+#define LC_BLOOM_WORDS 2048               /* bloom range staged in LDS: up to 128 blocks of 512 bits */
 
-struct LcTab { u64 *K; u32 *T1, *T2, *CN; u64 *SO; u32 *SP; u32 cap; };
+struct LcTab { u64 *K; u32 *T1, *T2, *CN, *TM; u64 *SO; u32 *SP; u32 *BL; u32 cap; };
 
 template <bool GLB> __device__ __forceinline__ void lc_sync() { if (GLB) block_sync_global(); else __syncthreads(); }
 
 __device__ __forceinline__ u32 lc_home(u64 key, int pre, u32 cap) { return (u32)(((key >> pre) * 0x9E3779B97F4A7C15ull) >> 24) & (cap - 1); }
 
-__device__ __forceinline__ int lc_find(const LcTab &T, u64 key, int pre)
-{
-	u32 s = lc_home(key, pre, T.cap);
-	for (u32 n = 0; n < T.cap; ++n, s = (s + 1) & (T.cap - 1)) {
-		const u64 cur = T.K[s];
-		if (cur == key) return (int)s;
-		if (cur == YK_EMPTY) return -1;
-	}
-	return -1;
-}
-
 /* body shared by the LDS kernel (GLB = false) and the global-scratch fallback for sub-buckets
- * whose distinct k-mers do not fit the LDS table (GLB = true).  Returns false on LDS overflow. */
+ * whose distinct k-mers do not fit the LDS table (GLB = true).  Returns false on LDS overflow
+ * (nothing has been modified at that point). */
 template <bool GLB>
 __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 *__restrict__ sbstart,
                         const u64 *__restrict__ rec_hash, const u32 *__restrict__ rec_t, u32 *bloom32, const ImgView &img,
                         const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
                         u32 *s_misc /* [8] in LDS */)
 {
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x;
 	const u32 p = sb >> fp.s2_bits;
 	const u64 lo = sbstart[sb], hi = sbstart[sb + 1];
 	if (lo == hi) return true;
-	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_w = s_misc + 4;
-	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; }
-	if (tid < 4) s_misc[tid] = 0;
+	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_nsel = s_misc + 4, *s_base = s_misc + 5;
+	const int bb = fp.nb - 9, lb = bb - fp.s2_bits;              /* log2 bloom blocks owned by this sub-bucket */
+	const bool stage_bloom = !GLB && fp.bloom_mode && lb <= 7;
+	u32 *gw = 0;                                                   /* first word of the owned bloom range */
+	if (fp.bloom_mode) gw = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5);
+	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; T.TM[i] = 0; }
+	if (stage_bloom) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = gw[i];
+	if (tid < 8) s_misc[tid] = 0;
 	lc_sync<GLB>();
 
-	/* A: count; first / second occurrence times (same loser rule as k_acc_insert) */
+	/* A: count; first / second / last occurrence times (same loser rule as k_acc_insert) */
 	u32 tmax = 0;
 	for (u64 i = lo + tid; i < hi; i += 256) {
 		const u64 key = rec_hash[i];
@@ -1156,7 +1195,10 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 		if (n == T.cap) { *s_ovf = 1; continue; }
 		atomicAdd(&T.CN[s], 1u);
 		const u32 old = atomicMin(&T.T1[s], t);
-		if (fp.bloom_mode && old != T32_INF) atomicMin(&T.T2[s], old > t ? old : t);
+		if (fp.bloom_mode) {
+			if (old != T32_INF) atomicMin(&T.T2[s], old > t ? old : t);
+			atomicMax(&T.TM[s], t);
+		}
 		tmax = t + 1 > tmax ? t + 1 : tmax;
 	}
 	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
@@ -1178,22 +1220,20 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	}
 
 	/* C: the bloom gate, block by block, in stream order (bbf.c:25-42).  This workgroup is the
-	 * only one whose k-mers map to these 512-bit blocks, so plain loads/stores suffice. */
+	 * only one whose k-mers map to these 512-bit blocks: no atomics, LDS copy when it fits. */
 	if (fp.bloom_mode) {
-		const int bb = fp.nb - 9, lb = bb - fp.s2_bits;          /* log2 blocks owned by this sub-bucket */
-		const u64 xmask = (1ull << bb) - 1;
+		const u64 lmask = (1ull << lb) - 1;
 		for (u32 s = tid; s < T.cap; s += 256) {
 			if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
-			const u64 x = T.K[s] >> fp.pre;
-			const u64 blk_local = (x & xmask) & ((1ull << lb) - 1);
+			const u64 blk_local = (T.K[s] >> fp.pre) & lmask;
 			const u32 j = atomicAdd(s_ne, 1u);
-			T.SO[j] = blk_local << 32 | T.T1[s];
-			T.SP[j] = s;
+			if (GLB) { T.SO[j] = blk_local << 32 | T.T1[s]; T.SP[j] = s; }
+			else T.SO[j] = blk_local << 43 | (u64)T.T1[s] << 11 | s;
 		}
 		lc_sync<GLB>();
 		const u32 ne = *s_ne;
 		u32 m = 1; while (m < ne) m <<= 1;
-		for (u32 i = ne + tid; i < m; i += 256) { T.SO[i] = ~0ull; T.SP[i] = 0; }
+		for (u32 i = ne + tid; i < m; i += 256) { T.SO[i] = ~0ull; if (GLB) T.SP[i] = 0; }
 		lc_sync<GLB>();
 		for (u32 k2 = 2; k2 <= m; k2 <<= 1)
 			for (u32 j = k2 >> 1; j > 0; j >>= 1) {
@@ -1203,20 +1243,20 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 						const u64 a = T.SO[i], b = T.SO[l];
 						if ((a > b) == ((i & k2) == 0)) {
 							T.SO[i] = b; T.SO[l] = a;
-							const u32 t = T.SP[i]; T.SP[i] = T.SP[l]; T.SP[l] = t;
+							if (GLB) { const u32 t = T.SP[i]; T.SP[i] = T.SP[l]; T.SP[l] = t; }
 						}
 					}
 				}
 				lc_sync<GLB>();
 			}
+		const int bsh = GLB ? 32 : 43;
+		u32 *bw = stage_bloom ? T.BL : gw;
 		for (u32 j0 = tid; j0 < ne; j0 += 256) {
-			const u64 blk_local = T.SO[j0] >> 32;
-			if (j0 && (T.SO[j0 - 1] >> 32) == blk_local) continue;      /* not the first key of its block */
-			const u64 s_idx = sb & ((1u << fp.s2_bits) - 1);
-			const u64 blk = (s_idx << lb) | blk_local;
-			u32 *w = bloom32 + (((u64)p << fp.nb | blk << 9) >> 5);
-			for (u32 j = j0; j < ne && (T.SO[j] >> 32) == blk_local; ++j) {
-				const u32 s = T.SP[j];
+			const u64 blk_local = T.SO[j0] >> bsh;
+			if (j0 && (T.SO[j0 - 1] >> bsh) == blk_local) continue;      /* not the first key of its block */
+			u32 *w = bw + (blk_local << 4);
+			for (u32 j = j0; j < ne && (T.SO[j] >> bsh) == blk_local; ++j) {
+				const u32 s = GLB ? T.SP[j] : (u32)T.SO[j] & 2047u;
 				const u64 x = T.K[s] >> fp.pre;
 				const u32 h1 = (u32)(x >> bb) & 511;
 				u32 h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
@@ -1232,57 +1272,42 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			}
 		}
 		lc_sync<GLB>();
-
-	}
-	/* D: last put-call of the sub-bucket = last instance that is not a rejected first occurrence */
-	if (fp.bloom_mode) {
+		if (stage_bloom) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = T.BL[i];
+		/* D: last put-call = last instance that is not a rejected first occurrence (htab.c:63-65) */
 		u32 best = 0;
-		for (u64 i = lo + tid; i < hi; i += 256) {
-			const u32 t = rec_t[i];
-			if (t + 1 <= best) continue;
-			const int s = lc_find(T, rec_hash[i], fp.pre);
-			if (s < 0) continue;
+		for (u32 s = tid; s < T.cap; s += 256) {
+			if (T.K[s] == YK_EMPTY) continue;
 			const u32 cn = T.CN[s];
-			if ((cn & (LC_EXIST | LC_FP)) || T.T1[s] != t) best = t + 1;
+			if ((cn & (LC_EXIST | LC_FP)) || (cn & LC_CMASK) >= 2) best = T.TM[s] + 1 > best ? T.TM[s] + 1 : best;
 		}
 		if (best) atomicMax(s_lp, best);
 		lc_sync<GLB>();
 	}
-	if (tid == 0 && *s_lp) atomicMax(&lastput[p], fp.t_pass0 + (u64)(*s_lp - 1) + 1);
 
-	/* E: keys entering the table -> (key<<10|count, insertion time), appended to the sub-table's list */
-	for (int pass = 0; pass < 2; ++pass) {
-		u32 run = 0;                                          /* pass 0: total; pass 1: running offset */
-		u64 base = 0;
-		if (pass == 1) base = seg_base[p] + s_w[6];
-		for (u32 s0 = 0; s0 < T.cap; s0 += 256) {
-			const u32 s = s0 + tid;
-			bool sel = false; u64 kc = 0; u32 Tt = 0;
-			if (T.K[s] != YK_EMPTY && !(T.CN[s] & LC_EXIST)) {
-				u32 c = T.CN[s] & LC_CMASK;
-				if (!fp.bloom_mode || (T.CN[s] & LC_FP)) { sel = true; Tt = T.T1[s]; }
-				else if (T.T2[s] != T32_INF) { sel = true; Tt = T.T2[s]; c -= 1; }
-				if (c > 1023) c = 1023;
-				kc = (T.K[s] >> fp.pre) << 10 | c;
-			}
-			const u64 bm = __ballot(sel);
-			if (lane == 0) s_w[wave] = __popcll(bm);
-			__syncthreads();
-			u32 pre_w = 0, tot = 0;
-			for (int w = 0; w < 4; ++w) { if (w < wave) pre_w += s_w[w]; tot += s_w[w]; }
-			if (pass == 1 && sel) {
-				const u64 d = base + run + pre_w + __popcll(bm & lanemask_lt());
-				out_kc[d] = kc; out_T[d] = fp.t_pass0 + Tt;
-			}
-			run += tot;
-			__syncthreads();
-		}
-		if (pass == 0) {
-			if (tid == 0) s_w[6] = run ? atomicAdd(&seg_cur[p], run) : 0;
-			__syncthreads();
-		}
+	/* E: keys entering the table -> (key<<10|count, insertion time): staged, then appended to the
+	 * sub-table's list with one reservation per workgroup and contiguous stores */
+	for (u32 s = tid; s < T.cap; s += 256) {
+		if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
+		u32 c = T.CN[s] & LC_CMASK, Tt;
+		if (!fp.bloom_mode || (T.CN[s] & LC_FP)) Tt = T.T1[s];
+		else if (T.T2[s] != T32_INF) { Tt = T.T2[s]; c -= 1; }
+		else continue;
+		if (c > 1023) c = 1023;
+		const u32 r = atomicAdd(s_nsel, 1u);
+		T.SO[r] = (T.K[s] >> fp.pre) << 10 | c;
+		T.TM[r] = Tt;             /* TM is free again: D is behind a barrier */
 	}
-	if (tid == 0) atomicAdd(&counters[YKC_NDIST], (u64)*s_ndist);
+	lc_sync<GLB>();
+	const u32 nsel = *s_nsel;
+	if (tid == 0) {
+		u64 b = nsel ? (u64)atomicAdd(&seg_cur[p], nsel) : 0;
+		s_base[0] = (u32)b; s_base[1] = (u32)(b >> 32);
+		if (*s_lp) atomicMax(&lastput[p], fp.t_pass0 + (u64)(*s_lp - 1) + 1);
+		atomicAdd(&counters[YKC_NDIST], (u64)*s_ndist);
+	}
+	__syncthreads();
+	const u64 base = seg_base[p] + ((u64)s_base[0] | (u64)s_base[1] << 32);
+	for (u32 r = tid; r < nsel; r += 256) { out_kc[base + r] = T.SO[r]; out_T[base + r] = fp.t_pass0 + T.TM[r]; }
 	return true;
 }
 
@@ -1292,9 +1317,10 @@ void k_lds_count(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u
 {
 	__shared__ u64 s_K[YK_LDS_C];
 	__shared__ u64 s_SO[YK_LDS_C];
-	__shared__ u32 s_T1[YK_LDS_C], s_T2[YK_LDS_C], s_CN[YK_LDS_C], s_SP[YK_LDS_C];
+	__shared__ u32 s_T1[YK_LDS_C], s_T2[YK_LDS_C], s_CN[YK_LDS_C], s_TM[YK_LDS_C];
+	__shared__ u32 s_BL[LC_BLOOM_WORDS];
 	__shared__ u32 s_misc[8];
-	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.SO = s_SO; T.SP = s_SP; T.cap = YK_LDS_C;
+	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.cap = YK_LDS_C;
 	const u32 sb = blockIdx.x;
 	if (!lc_body<false>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
 		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[YKC_NOVF], 1ull)] = sb;
@@ -1309,10 +1335,10 @@ void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, con
 	const u32 sb = ovf_list[blockIdx.x];
 	const u64 n = sbstart[sb + 1] - sbstart[sb];
 	u32 cap = 4096; while (cap < 2 * n) cap <<= 1;
-	u64 *base = scr + scr_off[blockIdx.x];
-	LcTab T; T.cap = cap;
+	u64 *base = scr + scr_off[blockIdx.x];                      /* 40 B per slot = 5 u64 */
+	LcTab T; T.cap = cap; T.BL = 0;
 	T.K = base; T.SO = base + cap;
-	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap;
+	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap; T.TM = T.SP + cap;
 	lc_body<true>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc);
 }
 

@@ -121,7 +121,7 @@ enum { YKC_NEW = 0, YKC_INST = 1, YKC_ANYMULTI = 2, YKC_NCAND = 3, YKC_NMARKED =
 
 /* ---------------- fast path (exclusive-ownership LDS counting) ---------------- */
 #define YK_CH2     32768            /* records per level-2 partition chunk */
-#define YK_LDS_C   2048             /* slots of the LDS counting table */
+#define YK_LDS_C   1024             /* slots of the LDS counting table (overflow beyond 768 distinct k-mers) */
 
 struct Chunk2 {                     /* one level-2 partition work item: a run of one level-1 bucket */
 	const u64 *hash; const u32 *tlo;
