@@ -225,6 +225,7 @@ def main():
         _, tot, s1, s2 = step()
     barrier()
     dt = time.perf_counter() - t0
+    wall_timed = dict(wall)
     if world > 1:
         v = torch.tensor([dt, float(tot), float(s1["n_instances"] + (s2["n_instances"] if s2 else 0))],
                          dtype=torch.float64, device=dev)
@@ -280,7 +281,7 @@ def main():
         "final_distinct": tot_all,
         "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_")},
                                "pass2": {k: round(v, 3) for k, v in s2.items() if k.startswith("ms_")} if s2 else None},
-        "phase_wall_ms_last_step": {k: round(v, 2) for k, v in wall.items()},
+        "phase_wall_ms_last_step": {k: round(v, 2) for k, v in wall_timed.items()},
         "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
         "bloom_exact_resolutions": s1["n_bloom_candidates"],
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -170,12 +170,12 @@ struct yakamd_ctx {
 	AccTab acc; u64 acc_count;
 	u64 *d_counters, *d_lastput, *d_lpbatch;
 	u32 *d_missing, *d_nmissing;
-	u64 *d_rh; u32 *d_rt; int64_t rec_cap;
+	Rec *d_rec; int64_t rec_cap;
 	u64 *d_newlist, *d_miss, *d_cand; int64_t new_cap;
 	uint8_t *d_stage; int64_t stage_cap;
 	u32 *d_rows; u64 *d_partial, *d_bstart; int rows_blk; int nb_bits;
 	/* fast path: level-1 partitioned batches kept until pass_end */
-	struct Kept { u64 *d_hash; u32 *d_t; u64 n; u64 t0, span; std::vector<u64> bstart; };
+	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; };
 	std::vector<Kept> kept;
 	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set;
 	double ms_part2, ms_lds;
@@ -247,7 +247,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0;
 	c->in_pass = false; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
-	c->d_rh = 0; c->d_rt = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
+	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
 	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
 	c->d_rows = 0; c->d_partial = 0; c->d_bstart = 0; c->rows_blk = 0;
 	c->nb_bits = (int)std::min<int64_t>(pre, env_i64("YAKAMD_PART_BITS", 13));
@@ -284,10 +284,10 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 
 static void pass_free(yakamd_ctx *c)
 {
-	for (auto &k : c->kept) { dfree(k.d_hash); dfree(k.d_t); }
+	for (auto &k : c->kept) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(c->acc.s); c->acc_count = 0;
-	dfree(c->d_rh); dfree(c->d_rt); c->rec_cap = 0;
+	dfree(c->d_rec); c->rec_cap = 0;
 	dfree(c->d_newlist); dfree(c->d_miss); dfree(c->d_cand); c->new_cap = 0;
 	c->in_pass = false;
 }
@@ -429,13 +429,13 @@ static int lastput_phase(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64
 	HIPCK(hipMemsetAsync(c->d_lpbatch, 0, c->P * 8, c->st));
 	HIPCK(hipMemsetAsync(c->d_missing, 0, ((c->P + 31) / 32) * 4, c->st));
 	HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));
-	yk_launch_lastput(c->d_rh, c->d_rt, n_rec, t0, t_from, c->acc, img, img_nonempty, c->bloom_mode, 0, c->d_lpbatch, c->st);
+	yk_launch_lastput(c->d_rec, n_rec, t0, t_from, c->acc, img, img_nonempty, c->bloom_mode, 0, c->d_lpbatch, c->st);
 	yk_launch_lastput_merge(c->d_lastput, c->d_lpbatch, c->d_missing, c->d_nmissing, c->P, c->plo, c->phi, c->st);
 	if (t_from > batch_lo) {
 		HIPCK(hipMemcpyAsync(&n_missing, c->d_nmissing, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCK(hipStreamSynchronize(c->st));
 		if (n_missing) {    /* the tail did not reach every sub-table: scan the whole batch for those */
-			yk_launch_lastput(c->d_rh, c->d_rt, n_rec, t0, batch_lo, c->acc, img, img_nonempty, c->bloom_mode, c->d_missing, c->d_lpbatch, c->st);
+			yk_launch_lastput(c->d_rec, n_rec, t0, batch_lo, c->acc, img, img_nonempty, c->bloom_mode, c->d_missing, c->d_lpbatch, c->st);
 			HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));
 			yk_launch_lastput_merge(c->d_lastput, c->d_lpbatch, c->d_missing, c->d_nmissing, c->P, c->plo, c->phi, c->st);
 		}
@@ -446,9 +446,9 @@ static int lastput_phase(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64
 static int rec_reserve(yakamd_ctx *c, int64_t n)
 {
 	if (n <= c->rec_cap) return 0;
-	dfree(c->d_rh); dfree(c->d_rt);
+	dfree(c->d_rec);
 	c->rec_cap = n;
-	return dmalloc(&c->d_rh, (size_t)n) || dmalloc(&c->d_rt, (size_t)n) ? -1 : 0;
+	return dmalloc(&c->d_rec, (size_t)n);
 }
 
 static int part_reserve(yakamd_ctx *c, int n_blk)
@@ -479,7 +479,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	if (batch_hi > c->t_end) c->t_end = batch_hi;
 	if (!c->create_new) {
 		EvTimer tm(c->st);
-		yk_launch_img_count(c->d_rh, n_rec, img, c->st);
+		yk_launch_img_count(c->d_rec, n_rec, img, c->st);
 		const double ms = tm.stop();
 		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
 		return 0;
@@ -489,7 +489,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	u64 h_cnt[YKC_N];
 	{
 		EvTimer tm(c->st);
-		yk_launch_acc_insert(c->d_rh, c->d_rt, n_rec, t0, c->acc, img, img_nonempty, c->bloom_mode,
+		yk_launch_acc_insert(c->d_rec, n_rec, t0, c->acc, img, img_nonempty, c->bloom_mode,
 		                     c->bloom_mode ? c->d_newlist : 0, c->d_counters, c->st);
 		const double ms = tm.stop();
 		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
@@ -510,31 +510,31 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 static int fast_abandon(yakamd_ctx *c)
 {
 	c->fast = false;
-	u64 *keep_h = c->d_rh; u32 *keep_t = c->d_rt;
+	Rec *keep = c->d_rec;
 	int r = 0;
 	for (auto &k : c->kept) {
-		c->d_rh = k.d_hash; c->d_rt = k.d_t;
+		c->d_rec = k.d_rec;
 		if (!r) r = consume_records(c, (int64_t)k.n, k.t0, k.t0, k.t0 + k.span);
-		dfree(k.d_hash); dfree(k.d_t);
+		dfree(k.d_rec);
 	}
-	c->d_rh = keep_h; c->d_rt = keep_t;
+	c->d_rec = keep;
 	c->kept.clear(); c->kept_bytes = 0;
 	return r;
 }
 
 /* may this batch (n_pos stream positions starting at time t) stay on the fast path?  If so,
  * allocate its level-1 output buffers */
-static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, u64 **oh, u32 **ot)
+static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out)
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
-	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + n_cap * 12 <= c->fast_budget;
+	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + n_cap * 16 <= c->fast_budget;
 	if (!fits) { if (fast_abandon(c)) return -1; return 0; }
 	yakamd_ctx::Kept k;
-	k.d_hash = 0; k.d_t = 0; k.n = 0; k.t0 = t; k.span = n_pos;
-	if (dmalloc(&k.d_hash, (size_t)n_cap) || dmalloc(&k.d_t, (size_t)n_cap)) return -1;
-	c->kept_bytes += n_cap * 12;
+	k.d_rec = 0; k.n = 0; k.t0 = t; k.span = n_pos;
+	if (dmalloc(&k.d_rec, (size_t)n_cap)) return -1;
+	c->kept_bytes += n_cap * 16;
 	c->kept.push_back(k);
-	*oh = k.d_hash; *ot = k.d_t;
+	*out = k.d_rec;
 	return 0;
 }
 
@@ -564,14 +564,14 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
 		const int64_t end = std::min(n_bytes, pos + batch);
 		u64 n_rec = 0;
-		u64 *oh = c->d_rh; u32 *ot = c->d_rt;
+		Rec *out = c->d_rec;
 		if (c->fast) {                                   /* the batch stays resident until pass_end */
-			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &oh, &ot)) return -1;
+			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &out)) return -1;
 		}
 		{
 			EvTimer tm(c->st);
 			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
-			                c->d_rows, c->d_partial, c->d_bstart, oh, ot, c->st);
+			                c->d_rows, c->d_partial, c->d_bstart, out, c->st);
 			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 			c->st_cur.ms_extract += tm.stop();
 		}
@@ -604,10 +604,10 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	if (n <= 0) return 0;
 	if (rec_reserve(c, n) || part_reserve(c, yk_rpart_blocks(n))) return -1;
 	u64 n_rec = 0;
-	u64 *oh = c->d_rh; u32 *ot = c->d_rt;
-	if (c->fast && fast_admit(c, t0, t_span, (u64)n, &oh, &ot)) return -1;
+	Rec *out = c->d_rec;
+	if (c->fast && fast_admit(c, t0, t_span, (u64)n, &out)) return -1;
 	yk_launch_rpart((const u64*)d_hash, (const u32*)d_t, n, c->pre, c->plo, c->phi, c->nb_bits,
-	                c->d_rows, c->d_partial, c->d_bstart, oh, ot, c->st);
+	                c->d_rows, c->d_partial, c->d_bstart, out, c->st);
 	HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	if (c->fast) { if (t0 + t_span > c->t_end) c->t_end = t0 + t_span; return fast_keep(c, n_rec); }
@@ -666,7 +666,7 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 		if (cap0 == 0 && t.init_bits != YK_NOCAP) cap0 = 1u << t.init_bits;
 		const u32 capm = plan_cap(cap0, t.old_count, t.m, d_lastput != 0);
 		t.cap_max_bits = capm ? (u32)ceil_log2_u64(capm) : 0;
-		t.pad = 0;
+		t.dbg = (u32)env_i64("YAKAMD_DBG", 0);
 		new_off[p] = tot; t.new_off = tot;
 		tot += std::max<u64>(32, capm);
 	}
@@ -706,6 +706,7 @@ static int fast_finish(yakamd_ctx *c)
 	FastParams fp;
 	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
+	fp.dbg = (int)env_i64("YAKAMD_DBG", 0); fp.pad = 0;
 	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them */
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + 599) / 600) : 0;
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
@@ -728,7 +729,7 @@ static int fast_finish(yakamd_ctx *c)
 			const u64 a = k.bstart[p], b = k.bstart[p + 1];
 			for (u64 o = a; o < b; o += ch2) {
 				Chunk2 ch;
-				ch.hash = k.d_hash + o; ch.tlo = k.d_t + o;
+				ch.rec = k.d_rec + o; ch.spare = 0;
 				ch.n = (u32)std::min<u64>(ch2, b - o); ch.bucket = (u32)p;
 				ch.tbase = (u32)(k.t0 - c->t_pass0); ch.pad = 0;
 				chunks.push_back(ch);
@@ -740,10 +741,10 @@ static int fast_finish(yakamd_ctx *c)
 	chunk_first[P] = (u32)chunks.size();
 	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
 
-	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_t2 = 0, *d_segcur = 0, *d_ovf = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_h2 = 0;
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0; u64 *d_bbase = 0, *d_sbstart = 0; Rec *d_r2 = 0;
 	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
 	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2) ||
-	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_h2, n_total) || dmalloc(&d_t2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb)) return -1;
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb)) return -1;
 	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
@@ -751,18 +752,18 @@ static int fast_finish(yakamd_ctx *c)
 	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));
 	{
 		EvTimer tm(c->st);
-		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_h2, d_t2, c->st);
+		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2;
 	}
-	for (auto &k : c->kept) { dfree(k.d_hash); dfree(k.d_t); }
+	for (auto &k : c->kept) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
 	if (dmalloc(&kc[0], n_total) || dmalloc(&tt[0], n_total)) return -1;
 	u64 h_cnt[YKC_N];
 	{
 		EvTimer tm(c->st);
-		yk_launch_lds_count(fp, P, d_sbstart, d_h2, d_t2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		yk_launch_lds_count(fp, P, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
 		                    c->d_lastput, c->d_counters, d_ovf, c->st);
 		c->ms_lds = tm.stop();
 		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
@@ -785,7 +786,7 @@ static int fast_finish(yakamd_ctx *c)
 		if (dmalloc(&d_scr, words) || dmalloc(&d_off, n_ovf)) return -1;
 		HIPCK(hipMemcpyAsync(d_off, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
 		EvTimer tm(c->st);
-		yk_launch_lds_count_ovf(fp, d_sbstart, d_h2, d_t2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
 		                        c->d_lastput, c->d_counters, d_ovf, n_ovf, d_off, d_scr, c->st);
 		c->st_cur.ms_insert += tm.stop();
 		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
@@ -793,7 +794,7 @@ static int fast_finish(yakamd_ctx *c)
 		dfree(d_scr); dfree(d_off);
 	}
 	c->st_cur.n_distinct_seen = (int64_t)h_cnt[YKC_NDIST];
-	dfree(d_h2); dfree(d_t2); dfree(d_sbstart); dfree(d_ovf);
+	dfree(d_r2); dfree(d_sbstart); dfree(d_ovf);
 	std::vector<u32> m(P);
 	HIPCK(hipMemcpy(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost));
 	if (dmalloc(&kc[1], n_total) || dmalloc(&tt[1], n_total)) return -1;

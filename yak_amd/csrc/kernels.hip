@@ -215,7 +215,7 @@ __device__ __forceinline__ u32 bucket_of(u64 h, int pre, int nb_bits)
 template <int MODE>   /* 0 = histogram, 1 = scatter */
 __global__ __launch_bounds__(XT_THREADS)
 void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-             int nb_bits, u32 *rows, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+             int nb_bits, u32 *rows, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
 	__shared__ XtTile S;
@@ -237,7 +237,7 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 			ok = ok && (int)p >= plo && (int)p < phi;
 			if (ok) {
 				const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
-				if (MODE) { out_hash[d] = h; out_t[d] = (u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub); }
+				if (MODE) out[d] = make_ulonglong2(h, (u64)(u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub));
 			}
 		}
 		__syncthreads();
@@ -249,7 +249,7 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 template <int MODE>
 __global__ __launch_bounds__(256)
 void k_rpart(const u64 *__restrict__ in_hash, const u32 *__restrict__ in_t, int64_t n, int pre, int plo, int phi,
-             int nb_bits, u32 *rows, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+             int nb_bits, u32 *rows, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
 	const int NB = 1 << nb_bits;
@@ -263,7 +263,7 @@ void k_rpart(const u64 *__restrict__ in_hash, const u32 *__restrict__ in_t, int6
 		const u32 p = (u32)h & pmask;
 		if ((int)p >= plo && (int)p < phi) {
 			const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
-			if (MODE) { out_hash[d] = h; out_t[d] = in_t[i]; }
+			if (MODE) out[d] = make_ulonglong2(h, (u64)in_t[i]);
 		}
 	}
 	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += 256) row[j] = s_bkt[j]; }
@@ -407,7 +407,7 @@ void k_acc_init(AccSlot *s, u64 n)
  * key, atomicMin on t1/t2 only when the instance can still lower them (both only ever decrease,
  * so a stale read errs on the safe side), one fire-and-forget count increment. */
 __global__ __launch_bounds__(256)
-void k_acc_insert(const u64 *__restrict__ hash, const u32 *__restrict__ tlo, int64_t n, u64 t0,
+void k_acc_insert(const Rec *__restrict__ rec, int64_t n, u64 t0,
                   AccTab tab, ImgView img, int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters)
 {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -418,7 +418,8 @@ void k_acc_insert(const u64 *__restrict__ hash, const u32 *__restrict__ tlo, int
 		bool created = false;
 		AccSlot *s = 0;
 		if (i < n) {
-			const u64 key = hash[i], t = t0 + tlo[i];
+			const Rec rc = rec[i];
+			const u64 key = rc.x, t = t0 + (u32)rc.y;
 			int64_t hit = -1;
 			if (img_nonempty) hit = img_find(img, key);
 			if (hit >= 0) {
@@ -470,11 +471,11 @@ void k_acc_rehash(AccTab oldt, AccTab newt)
 /* K4: create_new == 0 (reference htab.c:71-75): look the key up in the existing table image and
  * count the hit; the saturating fold into the 10 count bits happens once at the end of the pass */
 __global__ __launch_bounds__(256)
-void k_img_count(const u64 *__restrict__ hash, int64_t n, ImgView img)
+void k_img_count(const Rec *__restrict__ rec, int64_t n, ImgView img)
 {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-		const int64_t hit = img_find(img, hash[i]);
+		const int64_t hit = img_find(img, rec[i].x);
 		if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
 	}
 }
@@ -509,15 +510,16 @@ void k_img_clear(ImgView img, u64 n_slots)                   /* reference htab.c
  * scans the tail first and the whole batch only for sub-tables the tail did not reach.
  * ------------------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256)
-void k_lastput(const u64 *__restrict__ hash, const u32 *__restrict__ tlo, int64_t n, u64 t0, u64 t_from,
+void k_lastput(const Rec *__restrict__ rec, int64_t n, u64 t0, u64 t_from,
                AccTab tab, ImgView img, int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch)
 {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	const u32 pmask = (1u << tab.pre) - 1;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-		const u64 t = t0 + tlo[i];
+		const Rec rc = rec[i];
+		const u64 t = t0 + (u32)rc.y;
 		if (t < t_from) continue;
-		const u64 key = hash[i];
+		const u64 key = rc.x;
 		const u32 p = (u32)key & pmask;
 		if (only_missing && !(only_missing[p >> 5] >> (p & 31) & 1)) continue;
 		bool put = true;
@@ -884,11 +886,16 @@ __device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 n
 			cur[jw] &= cur[jw] - 1;
 			for (;;) {
 				u32 i = yk_h2b((u32)(key >> 10), nbits_new);
-				while (bm_get(oth, i)) i = (i + 1) & Nmask;
-				oth[i >> 5] |= 1u << (i & 31);
-				if (i < n && bm_get(cur, i)) {
+				u32 wo = oth[i >> 5], wc = i < n ? cur[i >> 5] : 0;     /* both words in flight together */
+				while (wo >> (i & 31) & 1) {
+					i = (i + 1) & Nmask;
+					if ((i & 31) == 0) { wo = oth[i >> 5]; }
+					if ((i & 31) == 0 || i == n) wc = i < n ? cur[i >> 5] : 0;
+				}
+				oth[i >> 5] = wo | 1u << (i & 31);
+				if (i < n && (wc >> (i & 31) & 1)) {
 					const u64 tmp = keys[i]; keys[i] = key; key = tmp;
-					cur[i >> 5] &= ~(1u << (i & 31));
+					cur[i >> 5] = wc & ~(1u << (i & 31));
 				} else { keys[i] = key; break; }
 			}
 		}
@@ -969,8 +976,9 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 			if (in_lds) for (u32 w = tid; w < (n + 31) / 32; w += 256) wc[w] = cur[w];
 			if (tid == 0) s_progress = 0;
 			block_sync_global();
-			if (tid == 0) replay_double(keys, wc, wo, n, N, nb, &s_progress);
-			else if (tid >= 64 && tid < 128) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
+			if (T.dbg & 1) { if (tid == 0) s_progress = 0xffffffffu; }
+			else if (tid == 0) replay_double(keys, wc, wo, n, N, nb, &s_progress);
+			else if (tid >= 64 && tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
 			block_sync_global();
 			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = wo[w]; block_sync_global(); }
 			u32 *t = cur; cur = oth; oth = t;
@@ -981,6 +989,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		/* FCFS placement of the next keys, up to the growth threshold */
 		const u32 batch = (T.m - i0 < thr - cnt) ? T.m - i0 : thr - cnt;
 		const u32 nmask = n - 1;
+		if (T.dbg & 2) { cnt += batch; i0 += batch; continue; }
 		for (u32 i = tid; i < n; i += 256) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
 		block_sync_global();
 		for (u32 q = tid; q < batch; q += 256) {
@@ -1094,7 +1103,7 @@ __device__ __forceinline__ u32 sub_of(u64 h, const FastParams &fp)
 
 template <int MODE>   /* 0 = histogram, 1 = scatter */
 __global__ __launch_bounds__(256)
-void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, u64 *__restrict__ out_hash, u32 *__restrict__ out_t)
+void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
 	const Chunk2 c = chunks[blockIdx.x];
@@ -1103,9 +1112,9 @@ void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, u64 *__restrict__ 
 	for (int j = threadIdx.x; j < S2; j += 256) s_bkt[j] = MODE ? row[j] : 0;
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < c.n; i += 256) {
-		const u64 h = c.hash[i];
-		const u32 d = atomicAdd(&s_bkt[sub_of(h, fp)], 1u);
-		if (MODE) { out_hash[d] = h; out_t[d] = c.tlo[i] + c.tbase; }
+		const Rec rc = c.rec[i];
+		const u32 d = atomicAdd(&s_bkt[sub_of(rc.x, fp)], 1u);
+		if (MODE) out[d] = make_ulonglong2(rc.x, (u64)((u32)rc.y + c.tbase));
 	}
 	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += 256) row[j] = s_bkt[j]; }
 }
@@ -1144,11 +1153,11 @@ void k_part2_scan(const u32 *chunk_first, const u64 *bbase, int s2_bits, u32 *ro
 
 #define LC_EXIST 0x40000000u
 #define LC_FP    0x80000000u
-#define LC_CMASK 0x0fffffffu
+#define LC_CMASK 0x000fffffu              /* occurrences, clamped; bits 29:20 = rank inside a bloom block */
 #define T32_INF  0xffffffffu
 #define LC_BLOOM_WORDS 2048               /* bloom range staged in LDS: up to 128 blocks of 512 bits */
 
-struct LcTab { u64 *K; u32 *T1, *T2, *CN, *TM; u64 *SO; u32 *SP; u32 *BL; u32 cap; };
+struct LcTab { u64 *K; u32 *T1, *T2, *CN, *TM; u64 *SO; u32 *SP; u32 *BL; u32 *GC; u32 cap; };
 
 template <bool GLB> __device__ __forceinline__ void lc_sync() { if (GLB) block_sync_global(); else __syncthreads(); }
 
@@ -1159,7 +1168,7 @@ __device__ __forceinline__ u32 lc_home(u64 key, int pre, u32 cap) { return (u32)
  * (nothing has been modified at that point). */
 template <bool GLB>
 __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 *__restrict__ sbstart,
-                        const u64 *__restrict__ rec_hash, const u32 *__restrict__ rec_t, u32 *bloom32, const ImgView &img,
+                        const Rec *__restrict__ rec, u32 *bloom32, const ImgView &img,
                         const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
                         u32 *s_misc /* [8] in LDS */)
 {
@@ -1173,15 +1182,16 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	u32 *gw = 0;                                                   /* first word of the owned bloom range */
 	if (fp.bloom_mode) gw = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5);
 	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; T.TM[i] = 0; }
-	if (stage_bloom) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = gw[i];
+	if (stage_bloom) { if (!(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = gw[i]; T.GC[tid] = 0; }
 	if (tid < 8) s_misc[tid] = 0;
 	lc_sync<GLB>();
 
 	/* A: count; first / second / last occurrence times (same loser rule as k_acc_insert) */
 	u32 tmax = 0;
 	for (u64 i = lo + tid; i < hi; i += 256) {
-		const u64 key = rec_hash[i];
-		const u32 t = rec_t[i];
+		const Rec rc = rec[i];
+		const u64 key = rc.x;
+		const u32 t = (u32)rc.y;
 		u32 s = lc_home(key, fp.pre, T.cap), n = 0;
 		for (; n < T.cap; ++n, s = (s + 1) & (T.cap - 1)) {
 			u64 cur = T.K[s];
@@ -1193,7 +1203,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			}
 		}
 		if (n == T.cap) { *s_ovf = 1; continue; }
-		atomicAdd(&T.CN[s], 1u);
+		if ((T.CN[s] & LC_CMASK) < 0x80000u) atomicAdd(&T.CN[s], 1u);   /* only min(count, 1023) is ever used */
 		const u32 old = atomicMin(&T.T1[s], t);
 		if (fp.bloom_mode) {
 			if (old != T32_INF) atomicMin(&T.T2[s], old > t ? old : t);
@@ -1204,6 +1214,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
 	lc_sync<GLB>();
 	if (!GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3)) return false;
+	if (fp.dbg & 16) return true;
 
 	/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key) */
 	if (fp.img_nonempty) {
@@ -1221,8 +1232,67 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 
 	/* C: the bloom gate, block by block, in stream order (bbf.c:25-42).  This workgroup is the
 	 * only one whose k-mers map to these 512-bit blocks: no atomics, LDS copy when it fits. */
-	if (fp.bloom_mode) {
+	if (fp.bloom_mode && !(fp.dbg & 32)) {
 		const u64 lmask = (1ull << lb) - 1;
+		u32 *bw = stage_bloom ? T.BL : gw;
+		bool grouped = false;
+		if (stage_bloom) {
+			/* few keys per 512-bit block: group them with LDS counters (rank kept in CN[29:20]),
+			 * then one lane per block applies its keys in increasing first-occurrence time */
+			u32 *s_gc = T.GC, *s_go = T.GC + 128;
+			unsigned short *G = (unsigned short*)T.SO;
+			for (u32 s = tid; s < T.cap; s += 256) {
+				if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
+				const u32 r = atomicAdd(&s_gc[(T.K[s] >> fp.pre) & lmask], 1u);
+				T.CN[s] |= (r & 1023u) << 20;
+				atomicMax(s_ne, r + 1);
+			}
+			lc_sync<GLB>();
+			grouped = *s_ne <= 16;
+			if (grouped) {
+				if (tid < 64) {                                       /* exclusive scan of the 128 counters */
+					const u32 a = s_gc[2 * tid], b = s_gc[2 * tid + 1];
+					u32 v = a + b;
+					for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(v, o); if (tid >= o) v += t; }
+					s_go[2 * tid] = v - a - b; s_go[2 * tid + 1] = v - b;
+				}
+				lc_sync<GLB>();
+				for (u32 s = tid; s < T.cap; s += 256) {
+					if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
+					G[s_go[(T.K[s] >> fp.pre) & lmask] + (T.CN[s] >> 20 & 1023u)] = (unsigned short)s;
+				}
+				lc_sync<GLB>();
+				for (u32 b = tid; b < (1u << lb); b += 256) {
+					const u32 g = s_gc[b], g0 = s_go[b];
+					u32 *w = bw + (b << 4);
+					u32 last = 0; bool first = true;
+					for (u32 it = 0; it < g; ++it) {
+						u32 best = T32_INF, bs = 0;                       /* smallest T1 above the last one applied */
+						for (u32 e = 0; e < g; ++e) {
+							const u32 s = G[g0 + e], t1 = T.T1[s];
+							if ((first || t1 > last) && t1 < best) { best = t1; bs = s; }
+						}
+						first = false; last = best;
+						const u64 x = T.K[bs] >> fp.pre;
+						const u32 h1 = (u32)(x >> bb) & 511;
+						u32 h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
+						if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
+						const u32 cyc = 512u / (h2 & (0u - h2));
+						const u32 nd = (u32)fp.n_hash < cyc ? (u32)fp.n_hash : cyc;
+						u32 hits = 0;
+						for (u32 q = 0, z = h1; q < nd; ++q, z = (z + h2) & 511) {
+							const u32 word = w[z >> 5], bit = 1u << (z & 31);
+							if (word & bit) ++hits; else w[z >> 5] = word | bit;
+						}
+						if (hits == nd) T.CN[bs] |= LC_FP;
+					}
+				}
+			}
+			lc_sync<GLB>();
+			if (tid == 0) *s_ne = 0;
+			lc_sync<GLB>();
+		}
+		if (!grouped) {
 		for (u32 s = tid; s < T.cap; s += 256) {
 			if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
 			const u64 blk_local = (T.K[s] >> fp.pre) & lmask;
@@ -1250,7 +1320,6 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 				lc_sync<GLB>();
 			}
 		const int bsh = GLB ? 32 : 43;
-		u32 *bw = stage_bloom ? T.BL : gw;
 		for (u32 j0 = tid; j0 < ne; j0 += 256) {
 			const u64 blk_local = T.SO[j0] >> bsh;
 			if (j0 && (T.SO[j0 - 1] >> bsh) == blk_local) continue;      /* not the first key of its block */
@@ -1271,8 +1340,9 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 				if (hits == nd) T.CN[s] |= LC_FP;                       /* yak_bf_insert() == n_hash */
 			}
 		}
+		}
 		lc_sync<GLB>();
-		if (stage_bloom) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = T.BL[i];
+		if (stage_bloom && !(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = T.BL[i];
 		/* D: last put-call = last instance that is not a rejected first occurrence (htab.c:63-65) */
 		u32 best = 0;
 		for (u32 s = tid; s < T.cap; s += 256) {
@@ -1312,22 +1382,23 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 }
 
 __global__ __launch_bounds__(256)
-void k_lds_count(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t, u32 *bloom32, ImgView img,
+void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
                  const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters, u32 *ovf_list)
 {
 	__shared__ u64 s_K[YK_LDS_C];
 	__shared__ u64 s_SO[YK_LDS_C];
 	__shared__ u32 s_T1[YK_LDS_C], s_T2[YK_LDS_C], s_CN[YK_LDS_C], s_TM[YK_LDS_C];
 	__shared__ u32 s_BL[LC_BLOOM_WORDS];
+	__shared__ u32 s_GC[256];
 	__shared__ u32 s_misc[8];
-	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.cap = YK_LDS_C;
+	LcTab T; T.GC = s_GC; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.cap = YK_LDS_C;
 	const u32 sb = blockIdx.x;
-	if (!lc_body<false>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
+	if (!lc_body<false>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
 		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[YKC_NOVF], 1ull)] = sb;
 }
 
 __global__ __launch_bounds__(256)
-void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t, u32 *bloom32, ImgView img,
+void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
                      const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
                      const u32 *ovf_list, const u64 *scr_off, u64 *scr)
 {
@@ -1336,10 +1407,10 @@ void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, con
 	const u64 n = sbstart[sb + 1] - sbstart[sb];
 	u32 cap = 4096; while (cap < 2 * n) cap <<= 1;
 	u64 *base = scr + scr_off[blockIdx.x];                      /* 40 B per slot = 5 u64 */
-	LcTab T; T.cap = cap; T.BL = 0;
+	LcTab T; T.cap = cap; T.BL = 0; T.GC = 0;
 	T.K = base; T.SO = base + cap;
 	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap; T.TM = T.SP + cap;
-	lc_body<true>(fp, T, sb, sbstart, rec_hash, rec_t, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc);
+	lc_body<true>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1367,14 +1438,14 @@ void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_
 
 /* partitioning extraction: returns through bstart[1 << nb_bits] (device) the record count */
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st)
 {
 	if (n <= pos0) return;
 	const int n_blk = (int)(((u64)(n - pos0) + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE));
 	const size_t lds = sizeof(u32) << nb_bits;
-	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
-	hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 }
 
 int yk_part_groups(void) { return PS_G; }
@@ -1382,14 +1453,14 @@ int yk_xpart_blocks(int64_t n_pos) { return (int)(((u64)n_pos + (u64)XP_T * XT_T
 int yk_rpart_blocks(int64_t n_rec) { return (int)(((u64)n_rec + RP_CHUNK - 1) / RP_CHUNK); }
 
 void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st)
 {
 	if (n <= 0) return;
 	const int n_blk = yk_rpart_blocks(n);
 	const size_t lds = sizeof(u32) << nb_bits;
-	hipLaunchKernelGGL(k_rpart<0>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	hipLaunchKernelGGL(k_rpart<0>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
-	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out_hash, out_t);
+	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
 }
 
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st)
@@ -1397,11 +1468,11 @@ void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st)
 	hipLaunchKernelGGL(k_acc_init, dim3(grid_for(n)), dim3(256), 0, st, s, n);
 }
 
-void yk_launch_acc_insert(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, AccTab tab, ImgView img,
+void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView img,
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(k_acc_insert, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, tlo, n, t0, tab, img, img_nonempty, bloom_mode, newlist, counters);
+	hipLaunchKernelGGL(k_acc_insert, dim3(grid_for((u64)n)), dim3(256), 0, st, rec, n, t0, tab, img, img_nonempty, bloom_mode, newlist, counters);
 }
 
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st)
@@ -1409,10 +1480,10 @@ void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st)
 	hipLaunchKernelGGL(k_acc_rehash, dim3(grid_for(oldt.mask + 1)), dim3(256), 0, st, oldt, newt);
 }
 
-void yk_launch_img_count(const u64 *hash, int64_t n, ImgView img, hipStream_t st)
+void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(k_img_count, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, n, img);
+	hipLaunchKernelGGL(k_img_count, dim3(grid_for((u64)n)), dim3(256), 0, st, rec, n, img);
 }
 
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st)
@@ -1425,11 +1496,11 @@ void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st)
 	if (n_slots) hipLaunchKernelGGL(k_img_clear, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots);
 }
 
-void yk_launch_lastput(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
+void yk_launch_lastput(const Rec *rec, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
                        int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch, hipStream_t st)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(k_lastput, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, tlo, n, t0, t_from, tab, img, img_nonempty, bloom_mode, only_missing, lp_batch);
+	hipLaunchKernelGGL(k_lastput, dim3(grid_for((u64)n)), dim3(256), 0, st, rec, n, t0, t_from, tab, img, img_nonempty, bloom_mode, only_missing, lp_batch);
 }
 
 void yk_launch_lastput_merge(u64 *lastput, const u64 *lp_batch, u32 *missing, u32 *n_missing, int P, int plo, int phi, hipStream_t st)
@@ -1505,29 +1576,29 @@ void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 
 }
 
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, FastParams fp, int P,
-                     u32 *rows2, u64 *sbstart, u64 *out_hash, u32 *out_t, hipStream_t st)
+                     u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st)
 {
 	const size_t lds = sizeof(u32) << fp.s2_bits;
-	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out_hash, out_t);
+	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
-	if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out_hash, out_t);
+	if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 }
 
-void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const Rec *rec,
                          u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
                          u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st)
 {
 	const unsigned n_sb = (unsigned)P << fp.s2_bits;
-	hipLaunchKernelGGL(k_lds_count, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec_hash, rec_t, bloom32, img,
+	hipLaunchKernelGGL(k_lds_count, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
 	                   seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list);
 }
 
-void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
                              u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st)
 {
-	if (n_ovf) hipLaunchKernelGGL(k_lds_count_ovf, dim3(n_ovf), dim3(256), 0, st, fp, sbstart, rec_hash, rec_t, bloom32, img,
+	if (n_ovf) hipLaunchKernelGGL(k_lds_count_ovf, dim3(n_ovf), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
 	                              seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list, scr_off, scr);
 }
 

@@ -10,6 +10,7 @@
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef ulonglong2 Rec;                  /* one k-mer instance: .x = yak_hash64 value, .y = stream position (32 bits used) */
 
 #define YK_EMPTY   0xFFFFFFFFFFFFFFFFull     /* unclaimed slot (accumulator and table image) */
 #define YK_TINF    0xFFFFFFFFFFFFFFFFull     /* "never" */
@@ -60,7 +61,7 @@ struct ReplayTask {
 	u32 m;              /* number of new keys */
 	u32 init_bits;      /* pre-sized empty table (shrink), YK_NOCAP otherwise */
 	u32 cap_max_bits;   /* room reserved in the new arena */
-	u32 pad;
+	u32 dbg;
 };
 
 #ifdef __cplusplus
@@ -71,20 +72,20 @@ extern "C" {
 void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
                        u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st);
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
 void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, u64 *out_hash, u32 *out_t, hipStream_t st);
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
 int yk_xpart_blocks(int64_t n_pos);
 int yk_part_groups(void);
 int yk_rpart_blocks(int64_t n_rec);
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st);
-void yk_launch_acc_insert(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, AccTab tab, ImgView img,
+void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView img,
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
-void yk_launch_img_count(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
+void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
-void yk_launch_lastput(const u64 *hash, const u32 *tlo, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
+void yk_launch_lastput(const Rec *rec, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
                        int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch, hipStream_t st);
 void yk_launch_lastput_merge(u64 *lastput, const u64 *lp_batch, u32 *missing, u32 *n_missing, int P, int plo, int phi, hipStream_t st);
 
@@ -124,7 +125,8 @@ enum { YKC_NEW = 0, YKC_INST = 1, YKC_ANYMULTI = 2, YKC_NCAND = 3, YKC_NMARKED =
 #define YK_LDS_C   1024             /* slots of the LDS counting table (overflow beyond 768 distinct k-mers) */
 
 struct Chunk2 {                     /* one level-2 partition work item: a run of one level-1 bucket */
-	const u64 *hash; const u32 *tlo;
+	const Rec *rec;
+	u64 spare;
 	u32 n, bucket;
 	u32 tbase;                      /* added to tlo: time relative to the start of the pass */
 	u32 pad;
@@ -135,6 +137,7 @@ struct FastParams {
 	int bloom_mode, nb, n_hash;     /* nb = log2 bits per sub-table filter */
 	int img_nonempty;
 	int plo, phi;
+	int dbg, pad;                   /* timing ablations only (YAKAMD_DBG), results are wrong when non-zero */
 	u64 t_pass0;
 };
 
@@ -142,11 +145,11 @@ struct FastParams {
 extern "C" {
 #endif
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
-                     u32 *rows2, u64 *sbstart, u64 *out_hash, u32 *out_t, hipStream_t st);
-void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+                     u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
+void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const Rec *rec,
                          u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
                          u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st);
-void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const u64 *rec_hash, const u32 *rec_t,
+void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
                              u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st);
