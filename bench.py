@@ -137,26 +137,18 @@ def main():
 
     def exchange(with_t):
         """extract per destination, all-to-all the hashed k-mers to their owner (RCCL over xGMI)"""
+        from yak_amd import shard
         send_counts, off = [], 0
         for d in range(world):
-            n = L.yakamd_extract_dev(K, d_reads.data_ptr(), n_bytes, x_hash.data_ptr(), x_t.data_ptr(),
-                                     PRE, d * P // world, (d + 1) * P // world, None)
+            dlo, dhi = shard.owner_range(d, world, P)
+            n = L.yakamd_extract_dev(K, d_reads.data_ptr(), n_bytes, x_hash.data_ptr(), x_t.data_ptr(), PRE, dlo, dhi, None)
             if n < 0:
                 raise RuntimeError("extract failed")
             s_hash[off:off + n].copy_(x_hash[:n])
             if with_t:
                 s_t[off:off + n].copy_(x_t[:n])
             send_counts.append(n); off += n
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc)
-        recv_counts = rc.tolist()
-        r_hash = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(r_hash, s_hash[:off], recv_counts, send_counts)
-        r_t = None
-        if with_t:
-            r_t = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
-            dist.all_to_all_single(r_t, s_t[:off], recv_counts, send_counts)
+        r_hash, r_t, recv_counts = shard.exchange(s_hash, s_t if with_t else None, send_counts)
         torch.cuda.synchronize()
         return r_hash, r_t, recv_counts
 
@@ -167,13 +159,11 @@ def main():
         r_hash, r_t, recv_counts = exchange(bool(create_new))
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
-        off = 0
-        for s, n in enumerate(recv_counts):       # segments by source rank = stream order of the job
-            if n:
-                tp = r_t[off:off + n].data_ptr() if r_t is not None else x_t.data_ptr()
-                if L.yakamd_feed_hashed_dev(t.h, r_hash[off:off + n].data_ptr(), tp, n, s * n_bytes, n_bytes) != 0:
-                    raise RuntimeError("feed_hashed")
-            off += n
+        from yak_amd import shard
+        for src, off, n, t0 in shard.segments(recv_counts, n_bytes):   # by source rank = stream order of the job
+            tp = r_t[off:off + n].data_ptr() if r_t is not None else x_t.data_ptr()
+            if L.yakamd_feed_hashed_dev(t.h, r_hash[off:off + n].data_ptr(), tp, n, t0, n_bytes) != 0:
+                raise RuntimeError("feed_hashed")
         n_ins = L.yakamd_pass_end(t.h)
         if n_ins < 0:
             raise RuntimeError("pass_end")

@@ -57,6 +57,12 @@ int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
                            void *d_hash_u64_out, void *d_t_u32_out,
                            int pre, int prefix_lo, int prefix_hi, void *stream);
 
+/* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
+void *yakamd_dev_alloc(size_t bytes);
+void yakamd_dev_free(void *p);
+int yakamd_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int yakamd_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
 

@@ -61,6 +61,8 @@ def lib():
         L.yko_ch_restore.restype = P(Ch); L.yko_ch_restore.argtypes = [C.c_char_p]
         L.yko_ch_dump_mem.restype = C.c_size_t; L.yko_ch_dump_mem.argtypes = [P(Ch), P(P(C.c_uint8))]
         L.yko_ch_subtable.argtypes = [P(Ch), C.c_int, P(C.c_uint32), P(C.c_uint32)]
+        L.yko_extract_pos.restype = C.c_int64
+        L.yko_extract_pos.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.yko_count_mem.restype = P(Ch)
         L.yko_count_mem.argtypes = [C.c_char_p, C.c_int64, P(Copt), P(Ch)]
         L.yko_count_protocol_mem.restype = P(Ch)

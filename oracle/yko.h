@@ -92,6 +92,8 @@ void      yko_ch_subtable(const yko_ch_t *h, int i, uint32_t *cap, uint32_t *siz
 typedef struct { int64_t n, m; uint64_t *a; } yko_kbuf_t;
 void yko_extract(yko_kbuf_t *buf, int k, int pre, int64_t len, const char *seq);
 
+int64_t yko_extract_pos(int k, const uint8_t *bases, int64_t n, uint64_t *out_hash, uint32_t *out_t);
+
 yko_ch_t *yko_count_file(const char *fn, const yko_copt_t *opt, yko_ch_t *h0);
 /* same, but the "file" is a memory image of sequences separated by any non-ACGT byte */
 yko_ch_t *yko_count_mem(const uint8_t *bases, int64_t n, const yko_copt_t *opt, yko_ch_t *h0);

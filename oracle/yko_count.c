@@ -69,6 +69,25 @@ void yko_extract(yko_kbuf_t *buf, int k, int pre, int64_t len, const char *seq)
 	else extract_long(buf, k, pre, len, seq);
 }
 
+/* flat variant for tests of the sharded path: every k-mer of a memory image with its stream
+ * position (index of its last base), in stream order.  k < 32 only.  Returns the count. */
+int64_t yko_extract_pos(int k, const uint8_t *bases, int64_t n, uint64_t *out_hash, uint32_t *out_t)
+{
+	const uint64_t mask = (1ULL << 2 * k) - 1;
+	const int shift = 2 * (k - 1);
+	uint64_t fw = 0, rv = 0;
+	int64_t i, m = 0;
+	int run = 0;
+	for (i = 0; i < n; ++i) {
+		int c = yko_nt4[bases[i]];
+		if (c >= 4) { run = 0; fw = rv = 0; continue; }
+		fw = (fw << 2 | (uint64_t)c) & mask;
+		rv = rv >> 2 | (uint64_t)(3 - c) << shift;
+		if (++run >= k) { out_hash[m] = yko_hash64(fw < rv ? fw : rv, mask); out_t[m++] = (uint32_t)i; }
+	}
+	return m;
+}
+
 /* ------------------------------------------------------------------ FASTA/FASTQ reader
  * Record grammar followed (kseq.h:192-232): skip to a line starting with '>' or '@'; name = up
  * to the first white space, rest of the line ignored; sequence = concatenation of the following

@@ -131,3 +131,66 @@ def test_cli_drop_in(ya, oracle, tmp_path):
         subprocess.run([os.path.join(ROOT, "yak_amd", "yak-amd"), "count"] + args + ["-o", a, inp], check=True, stderr=subprocess.DEVNULL)
         subprocess.run([os.path.join(ROOT, "oracle", "yko"), "count"] + args + ["-o", b, inp], check=True, stderr=subprocess.DEVNULL)
         assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("bf", [0, 23])
+def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
+    """the multi-GPU data path with virtual ranks on one device: per-destination extraction
+    (yakamd_extract_dev), owner-side yakamd_set_shard + yakamd_feed_hashed_dev with source-rank
+    stream times; the concatenation of the ranks' sub-tables must equal the whole-input result"""
+    from yak_amd import shard
+    L = ya.lib()
+    world, P = 4, 1024
+    slices = [synth(1200, g=12000, s=5, first=r * 1200) for r in range(world)]
+    nb = len(slices[0])
+    d = []
+    for x in slices:
+        p = L.yakamd_dev_alloc(nb)
+        assert p and L.yakamd_memcpy_h2d(p, x, nb) == 0
+        d.append(p)
+    xh, xt = L.yakamd_dev_alloc(nb * 8), L.yakamd_dev_alloc(nb * 4)
+    parts, tot = [], 0
+    for r in range(world):
+        lo, hi = shard.owner_range(r, world, P)
+        t = ya.Table(31, 10, 4, bf)
+        assert L.yakamd_set_shard(t.h, lo, hi) == 0
+
+        def one_pass(create_new):
+            assert L.yakamd_pass_begin(t.h, create_new) == 0
+            for src in range(world):
+                n = L.yakamd_extract_dev(31, d[src], nb, xh, xt, 10, lo, hi, None)
+                assert n >= 0
+                if n:
+                    assert L.yakamd_feed_hashed_dev(t.h, xh, xt, n, src * nb, nb) == 0
+            n_ins = L.yakamd_pass_end(t.h)
+            assert n_ins >= 0
+            t.h.contents.tot += n_ins
+        one_pass(1)
+        if bf:
+            t.destroy_bf(); t.clear(); one_pass(0); t.shrink(2, 1023)
+        data = t.dump_bytes(); tot += t.tot; t.close()
+        off = 16
+        for p in range(P):
+            cap, n = struct.unpack_from("<II", data, off)
+            if lo <= p < hi:
+                parts.append(data[off:off + 8 + 8 * n])
+            off += 8 + 8 * n
+    for p in d + [xh, xt]:
+        L.yakamd_dev_free(p)
+    want, wtot = oracle.count_protocol_mem(b"".join(slices), k=31, bf_shift=bf)
+    assert want[:16] + b"".join(parts) == want and tot == wtot
+
+
+@pytest.mark.parametrize("env", [dict(YAKAMD_FAST="0"), dict(YAKAMD_S2_BITS="0"), dict(YAKAMD_FAST_BUDGET="100000"),
+                                 dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6")],
+                         ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general"])
+def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
+    """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
+    and the mid-pass switch between them all give the reference bytes"""
+    img = synth(20000, g=90000, s=21)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for opt in (dict(k=31), dict(k=31, bf_shift=22), dict(k=31, bf_shift=28), dict(k=21, bf_shift=20)):
+        got, tot = ya.count_protocol_host(img, **opt)
+        want, wtot = oracle.count_protocol_mem(img, **opt)
+        assert (got == want, tot) == (True, wtot), opt

@@ -5,6 +5,9 @@ C-ABI shared library ``yak_amd/libyak_amd.so`` (hand-written gfx950 HIP kernels 
 ``yak.h`` surface declared in ``include/yak.h`` / ``include/yak_amd.h``).  There is no Python or
 CPU implementation of the counting path here: if the library is missing, importing :func:`lib`
 raises; if no MI355X is visible, ``yak_ch_init`` / ``yak_count`` return NULL and the wrappers raise.
+
+Note for processes that also use PyTorch-ROCm: import torch BEFORE calling :func:`lib` (torch ships
+its own copy of the HIP runtime; whichever is loaded first serves both).
 """
 import ctypes as C
 import os
@@ -23,7 +26,8 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
     "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
-    "yakamd_get_stats", "yakamd_trim",
+    "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
+    "yakamd_memcpy_d2h",
 ]
 
 
@@ -96,6 +100,10 @@ def lib():
     L.yakamd_subtable.restype = C.c_int
     L.yakamd_subtable.argtypes = [P(ChT), C.c_int, P(C.c_uint32), P(C.c_uint32)]
     L.yakamd_get_stats.restype = C.c_int; L.yakamd_get_stats.argtypes = [P(ChT), P(StatsT)]
+    L.yakamd_dev_alloc.restype = C.c_void_p; L.yakamd_dev_alloc.argtypes = [C.c_size_t]
+    L.yakamd_dev_free.argtypes = [C.c_void_p]
+    L.yakamd_memcpy_h2d.restype = C.c_int; L.yakamd_memcpy_h2d.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.yakamd_memcpy_d2h.restype = C.c_int; L.yakamd_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 

@@ -889,6 +889,11 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 	return n_ins;
 }
 
+extern "C" void *yakamd_dev_alloc(size_t bytes) { void *p = 0; return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : 0; }
+extern "C" void yakamd_dev_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int yakamd_memcpy_h2d(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+extern "C" int yakamd_memcpy_d2h(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+
 extern "C" int yakamd_get_stats(yak_ch_t *h, yakamd_stats_t *st)
 {
 	yakamd_ctx *c = ctx_of(h);

@@ -1,0 +1,80 @@
+"""Prefix sharding of the 1<<pre sub-tables over the GPUs of one node.
+
+Sub-table p is touched only by k-mers whose hash has prefix p (reference count.c:19, htab.c:56),
+so rank r of `world` owns the contiguous prefixes [r*P/world, (r+1)*P/world) and the job needs
+exactly one exchange per pass: every hashed k-mer travels to the owner of its prefix together with
+its position in the logical input stream.  The logical stream of the whole job is rank 0's reads,
+then rank 1's, ...; a k-mer at local position t of rank s therefore has stream time
+s * slice_bytes + t, which is all the owner needs to reproduce the reference's insertion order.
+
+This module is pure plumbing (torch.distributed tensors in, tensors out): the same code drives
+RCCL on GPUs (bench.py) and gloo on CPU (tests/test_shard_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def owner_range(rank, world, n_prefix):
+    """prefixes [lo, hi) owned by `rank`"""
+    if n_prefix % world:
+        raise ValueError("the number of ranks must divide the number of sub-tables")
+    return rank * n_prefix // world, (rank + 1) * n_prefix // world
+
+
+def owner_of(prefix, world, n_prefix):
+    return prefix // (n_prefix // world)
+
+
+def _a2a(recv, send, recv_counts, send_counts):
+    """all_to_all_single on backends that have it (nccl == RCCL); send/recv pairs on gloo"""
+    if dist.get_backend() != "gloo":
+        dist.all_to_all_single(recv, send, recv_counts, send_counts)
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    so = [0]
+    for c in send_counts:
+        so.append(so[-1] + c)
+    ro = [0]
+    for c in recv_counts:
+        ro.append(ro[-1] + c)
+    recv[ro[rank]:ro[rank + 1]] = send[so[rank]:so[rank + 1]]
+    reqs = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        if send_counts[peer]:
+            reqs.append(dist.isend(send[so[peer]:so[peer + 1]].contiguous(), peer))
+        if recv_counts[peer]:
+            reqs.append(dist.irecv(recv[ro[peer]:ro[peer + 1]], peer))
+    for r in reqs:
+        r.wait()
+
+
+def exchange(send_hash, send_t, send_counts):
+    """send_hash (int64) / send_t (int32, may be None) are grouped by destination rank with
+    `send_counts[d]` entries for rank d.  Returns (recv_hash, recv_t, recv_counts) grouped by
+    SOURCE rank -- i.e. in the stream order of the whole job."""
+    world = dist.get_world_size()
+    dev = send_hash.device
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    rc = torch.empty_like(sc)
+    _a2a(rc, sc, [1] * world, [1] * world)
+    recv_counts = [int(x) for x in rc.tolist()]
+    n_send, n_recv = sum(send_counts), sum(recv_counts)
+    recv_hash = torch.empty(n_recv, dtype=send_hash.dtype, device=dev)
+    _a2a(recv_hash, send_hash[:n_send], recv_counts, list(send_counts))
+    recv_t = None
+    if send_t is not None:
+        recv_t = torch.empty(n_recv, dtype=send_t.dtype, device=dev)
+        _a2a(recv_t, send_t[:n_send], recv_counts, list(send_counts))
+    return recv_hash, recv_t, recv_counts
+
+
+def segments(recv_counts, slice_bytes):
+    """(source rank, offset, n, t0) of each received segment, in stream order: t0 is the stream
+    time of the first byte of that source rank's slice"""
+    off = 0
+    for src, n in enumerate(recv_counts):
+        if n:
+            yield src, off, n, src * slice_bytes
+        off += n
