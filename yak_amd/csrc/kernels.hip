@@ -903,6 +903,146 @@ __device__ void replay_double(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 n
 	*progress = 0xffffffffu;
 }
 
+/* The same doubling, wave-cooperative.  The ORDER of placements is untouched (lane L of a round
+ * commits only after lanes 0..L-1, rounds follow the scan order), but the global-memory latency is
+ * taken off the serial path: a round picks the next 64 unmoved slots from the bitmap, all 64 lanes
+ * load their key and the 4 slots at its new home at once (an unmoved slot's key never changes before
+ * it is moved, so the loads stay valid), then the lanes commit one after the other against the
+ * authoritative LDS bitmaps, falling back to a real load only for kicks beyond the first. */
+__device__ void replay_double_wave(u64 *keys, u32 *cur, u32 *oth, u32 n, u32 N, u32 nbits_new, volatile u32 *progress, u32 *s_sel)
+{
+	const u32 lane = threadIdx.x & 63, Nmask = N - 1, nwords = (n + 31) / 32;
+	u32 pos = 0;
+	while (pos < nwords) {
+		if (lane == 0) *progress = pos * 32;
+		const u32 w = pos + lane;
+		const u32 cw = w < nwords ? cur[w] : 0;
+		const u32 c = __popc(cw);
+		u32 incl = c;
+		for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
+		const u32 total = __shfl(incl, 63), excl = incl - c;
+		if (total == 0) { pos += 64; continue; }
+		s_sel[lane] = 0xffffffffu;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		if (excl < 64) {
+			u32 bits = cw, r = excl;
+			while (bits && r < 64) { s_sel[r++] = w * 32 + (__ffs((int)bits) - 1); bits &= bits - 1; }
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		const u32 j = s_sel[lane];
+		const u32 nsel = total < 64 ? total : 64;
+		const u32 last = s_sel[nsel - 1];
+		pos = total <= 64 ? pos + 64 : last / 32;          /* leftovers of that word are rescanned next round */
+		/* speculative loads: own key, then the old keys sitting where it is going to land */
+		u64 key0 = 0, win[4] = { 0, 0, 0, 0 };
+		u32 h0 = 0;
+		if (j != 0xffffffffu) {
+			key0 = keys[j];
+			h0 = yk_h2b((u32)(key0 >> 10), nbits_new);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const u32 x = (h0 + q) & Nmask; if (x < n) win[q] = keys[x]; }
+		}
+		for (u32 L = 0; L < nsel; ++L) {
+			if (lane == L && (cur[j >> 5] >> (j & 31) & 1)) {      /* still unmoved: its turn in the scan */
+				cur[j >> 5] &= ~(1u << (j & 31));
+				u64 key = key0;
+				bool first = true;
+				for (;;) {
+					u32 i = yk_h2b((u32)(key >> 10), nbits_new);
+					u32 wo = oth[i >> 5], wc = i < n ? cur[i >> 5] : 0;
+					while (wo >> (i & 31) & 1) {
+						i = (i + 1) & Nmask;
+						if ((i & 31) == 0) wo = oth[i >> 5];
+						if ((i & 31) == 0 || i == n) wc = i < n ? cur[i >> 5] : 0;
+					}
+					oth[i >> 5] = wo | 1u << (i & 31);
+					if (i < n && (wc >> (i & 31) & 1)) {
+						const u32 d = (i - h0) & Nmask;
+						u64 kicked;
+						if (first && d < 4) kicked = d == 0 ? win[0] : d == 1 ? win[1] : d == 2 ? win[2] : win[3];
+						else kicked = keys[i];
+						keys[i] = key; key = kicked;
+						cur[i >> 5] = wc & ~(1u << (i & 31));
+						first = false;
+					} else { keys[i] = key; break; }
+				}
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+	}
+	if (lane == 0) *progress = 0xffffffffu;
+}
+
+/* LDS variant with the two bitmaps interleaved: bm[w] = old "used" word w (high half) | new "used"
+ * word w (low half), so that a placement costs one LDS read and one LDS write on its serial path */
+__device__ void replay_double_wave64(u64 *keys, u64 *bm, u32 n, u32 N, u32 nbits_new, volatile u32 *progress, u32 *s_sel)
+{
+	const u32 lane = threadIdx.x & 63, Nmask = N - 1, nwords = (n + 31) / 32;
+	u32 pos = 0;
+	while (pos < nwords) {
+		if (lane == 0) *progress = pos * 32;
+		const u32 w = pos + lane;
+		const u32 cw = w < nwords ? (u32)(bm[w] >> 32) : 0;
+		const u32 c = __popc(cw);
+		u32 incl = c;
+		for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
+		const u32 total = __shfl(incl, 63), excl = incl - c;
+		if (total == 0) { pos += 64; continue; }
+		s_sel[lane] = 0xffffffffu;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		if (excl < 64) {
+			u32 bits = cw, r = excl;
+			while (bits && r < 64) { s_sel[r++] = w * 32 + (__ffs((int)bits) - 1); bits &= bits - 1; }
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		const u32 j = s_sel[lane];
+		const u32 nsel = total < 64 ? total : 64;
+		const u32 last = s_sel[nsel - 1];
+		pos = total <= 64 ? pos + 64 : last / 32;
+		u64 key0 = 0, win[4] = { 0, 0, 0, 0 };
+		u32 h0 = 0;
+		if (j != 0xffffffffu) {
+			key0 = keys[j];
+			h0 = yk_h2b((u32)(key0 >> 10), nbits_new);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const u32 x = (h0 + q) & Nmask; if (x < n) win[q] = keys[x]; }
+		}
+		for (u32 L = 0; L < nsel; ++L) {
+			if (lane == L) {
+				u64 b = bm[j >> 5];
+				if (b >> (32 + (j & 31)) & 1) {                  /* still unmoved: its turn in the scan */
+					u64 key = key0;
+					bool first = true;
+					u32 i = h0, iw = i >> 5;
+					if (iw == (j >> 5)) b &= ~(1ull << (32 + (j & 31)));
+					else { bm[j >> 5] = b & ~(1ull << (32 + (j & 31))); b = bm[iw]; }
+					for (;;) {
+						while (b >> (i & 31) & 1) {                /* linear probing on the new bitmap */
+							i = (i + 1) & Nmask;
+							if ((i & 31) == 0) { bm[iw] = b; iw = i >> 5; b = bm[iw]; }
+						}
+						b |= 1ull << (i & 31);
+						if (b >> (32 + (i & 31)) & 1) {           /* an unmoved old key sits there: kick it out */
+							const u32 d = (i - h0) & Nmask;
+							u64 kicked;
+							if (first && d < 4) kicked = d == 0 ? win[0] : d == 1 ? win[1] : d == 2 ? win[2] : win[3];
+							else kicked = keys[i];
+							keys[i] = key; key = kicked;
+							b &= ~(1ull << (32 + (i & 31)));
+							first = false;
+							const u32 i2 = yk_h2b((u32)(key >> 10), nbits_new);
+							if ((i2 >> 5) != iw) { bm[iw] = b; iw = i2 >> 5; b = bm[iw]; }
+							i = i2;
+						} else { keys[i] = key; bm[iw] = b; break; }
+					}
+				}
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+	}
+	if (lane == 0) *progress = 0xffffffffu;
+}
+
 /* helper wave of the doubling: for old slots a little ahead of the serial lane, touch the line the
  * key will land on and, one level deeper, the line its kicked-out victim will land on */
 __device__ void replay_prefetch(const u64 *keys, u32 n, u32 nbits_new, volatile u32 *progress, u32 *sink)
@@ -936,8 +1076,9 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
               u32 *scr_used, u32 *scr_owner, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
               u32 *out_bits, u32 *out_count)
 {
-	__shared__ u32 s_bm[RP_LDS_WORDS * 3 / 2];            /* new bitmap (N bits) + old bitmap (n bits) of a doubling */
+	__shared__ u64 s_bm[RP_LDS_WORDS];                    /* doubling: old (high) and new (low) bitmap words, interleaved */
 	__shared__ u32 s_progress;
+	__shared__ u32 s_sel[64];
 	const ReplayTask T = tasks[blockIdx.x];
 	const int tid = threadIdx.x;
 	u64 *keys = new_keys + T.new_off;
@@ -970,17 +1111,21 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		}
 		if (grow) {
 			const u32 N = n ? n << 1 : 4, nb = n ? bits + 1 : 2;
-			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS;
-			u32 *wo = in_lds ? s_bm : oth, *wc = in_lds ? s_bm + RP_LDS_WORDS : cur;
-			for (u32 w = tid; w < (N + 31) / 32; w += 256) wo[w] = 0;
-			if (in_lds) for (u32 w = tid; w < (n + 31) / 32; w += 256) wc[w] = cur[w];
+			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS && !(T.dbg & 8);
+			if (in_lds) {
+				for (u32 w = tid; w < (N + 31) / 32; w += 256) s_bm[w] = w < (n + 31) / 32 ? (u64)cur[w] << 32 : 0ull;
+			} else {
+				for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = 0;
+			}
 			if (tid == 0) s_progress = 0;
 			block_sync_global();
 			if (T.dbg & 1) { if (tid == 0) s_progress = 0xffffffffu; }
-			else if (tid == 0) replay_double(keys, wc, wo, n, N, nb, &s_progress);
-			else if (tid >= 64 && tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
+			else if (tid < 64) {
+				if (in_lds) replay_double_wave64(keys, s_bm, n, N, nb, &s_progress, s_sel);
+				else replay_double_wave(keys, cur, oth, n, N, nb, &s_progress, s_sel);
+			} else if (tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
 			block_sync_global();
-			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = wo[w]; block_sync_global(); }
+			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = (u32)s_bm[w]; block_sync_global(); }
 			u32 *t = cur; cur = oth; oth = t;
 			n = N; bits = nb;
 			if (i0 == 0xffffffffu) break;
