@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
     a = ap.parse_args()
 
     import torch
@@ -111,7 +112,11 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    sharded = world > 1 or a.force_exchange
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     L = yak_amd.lib()
     if L.yakamd_device_count() < 1:
@@ -128,8 +133,8 @@ def main():
     torch.cuda.synchronize()
     n_bytes = d_reads.numel()
 
-    # exchange buffers (multi-GPU only)
-    if world > 1:
+    # exchange buffers (sharded path only)
+    if sharded:
         x_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # extraction scratch
         x_t = torch.empty(n_bytes, dtype=torch.int32, device=dev)
         s_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # send, grouped by destination
@@ -153,7 +158,7 @@ def main():
         return r_hash, r_t, recv_counts
 
     def one_pass(t, create_new):
-        if world == 1:
+        if not sharded:
             t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
         r_hash, r_t, recv_counts = exchange(bool(create_new))
@@ -179,7 +184,7 @@ def main():
             return t1
         tp = time.perf_counter()
         t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
-        if world > 1:
+        if sharded:
             L.yakamd_set_shard(t.h, lo, hi)
         tp = tick("init", tp)
         one_pass(t, 1)
@@ -203,7 +208,7 @@ def main():
         return None, tot, s1, s2
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +221,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     wall_timed = dict(wall)
-    if world > 1:
+    if sharded:
         v = torch.tensor([dt, float(tot), float(s1["n_instances"] + (s2["n_instances"] if s2 else 0))],
                          dtype=torch.float64, device=dev)
         vmax = v.clone(); dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
@@ -227,7 +232,7 @@ def main():
     ms_step = dt / a.steps * 1e3
 
     verify = None
-    if not a.no_verify and world == 1:
+    if not a.no_verify and not sharded:
         # full-size property: the .yak bytes do not depend on how the stream is cut into device
         # batches (the reference's independence of -K / -t)
         t_a, _, _, _ = step(keep=True)
@@ -244,8 +249,7 @@ def main():
         ge.smoke()
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # roofline of the dominant kernel (HIP-event timed inside the library, per launch)
@@ -266,7 +270,7 @@ def main():
         "config": {"workload": f"yak count -k{K} -b{a.bf_shift} on {a.reads} x {READ_LEN} bp synthetic reads per GPU "
                                f"(G={genome}, e=0.5%, N=0.05%), 30x, bloom prefilter on, both passes + shrink",
                    "reads_per_gpu": a.reads, "k": K, "pre": PRE, "bf_shift": a.bf_shift,
-                   "sharding": "prefix-sharded sub-tables, RCCL all-to-all of hashed k-mers" if world > 1 else "1 GPU"},
+                   "sharding": "prefix-sharded sub-tables, RCCL all-to-all of hashed k-mers" if sharded else "1 GPU"},
         "kmer_instances_per_s": inst_all / (dt / a.steps),
         "final_distinct": tot_all,
         "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_")},
@@ -283,7 +287,7 @@ def main():
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, min(os.cpu_count() or 8, 32))
     print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -36,6 +36,9 @@ CASES = {
     "b19_H7":      (dict(n=600, l=150, g=2500, s=6),              ["-k31", "-b19", "-H7"], True),
     "b22_H40":     (dict(n=600, l=150, g=2500, s=6),              ["-k31", "-b22", "-H40"], True),
     "b15_nobf":    (dict(n=600, l=150, g=2500, s=6),              ["-k31", "-b15"], True),   # pre < b < pre+9: no filter, still two passes
+    "nb_k32":      (dict(n=600, l=150, g=5000, s=8),              ["-k32"], True),            # long k-mer path (count.c:45-60)
+    "nb_k41":      (dict(n=600, l=150, g=5000, s=8),              ["-k41"], True),
+    "b24_k63_fa":  (dict(n=20, l=4000, g=30000, s=9, a=1, N=0.002), ["-k63", "-b24"], True),
     "edge_fx":     ("inputs/edge.fx",                              ["-k5"], True),
     "one_read":    ("inputs/one3000.fa",                           ["-k31"], True),
     "one_read_x2": ("inputs/one3000x2.fa",                         ["-k31"], True),           # grow-on-existing-key

@@ -27,8 +27,6 @@ def ya():
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors(name, ya, synth, manifest):
     desc = manifest[name]
-    if any(a.startswith("-k") and int(a[2:]) >= 32 for a in desc["args"]):
-        pytest.skip("k >= 32 not on the device yet")
     img = image_for_case(desc, synth)
     data, _ = ya.count_protocol_host(img, **args_to_opts(desc["args"]))
     assert len(data) == desc["size"]
@@ -37,7 +35,7 @@ def test_golden_vectors(name, ya, synth, manifest):
         assert data == open(os.path.join(GOLD, name + ".yak"), "rb").read()
 
 
-OPTS = [dict(k=31), dict(k=21), dict(k=11), dict(k=5), dict(k=31, pre=12), dict(k=31, pre=14, bf_shift=27),
+OPTS = [dict(k=32), dict(k=33), dict(k=47), dict(k=63), dict(k=63, bf_shift=22), dict(k=40, pre=12, bf_shift=25), dict(k=31), dict(k=21), dict(k=11), dict(k=5), dict(k=31, pre=12), dict(k=31, pre=14, bf_shift=27),
         dict(k=31, bf_shift=19), dict(k=31, bf_shift=21), dict(k=31, bf_shift=26), dict(k=25, bf_shift=20, n_hash=9),
         dict(k=31, bf_shift=22, n_hash=70), dict(k=31, bf_shift=12), dict(k=31, bf_shift=10), dict(k=31, bf_shift=24, n_hash=1)]
 
@@ -53,7 +51,7 @@ def test_vs_oracle_short_reads(opt, ya, oracle, synth):
 
 def test_vs_oracle_long_contigs_with_n(ya, oracle, synth):
     img = synth(40, l=30000, g=400000, s=3, N=0.001)        # long-sequence path (SURVEY section 5, config 4 shape)
-    for opt in (dict(k=21), dict(k=31, bf_shift=25)):
+    for opt in (dict(k=21), dict(k=31, bf_shift=25), dict(k=55), dict(k=36, bf_shift=24)):
         assert ya.count_protocol_host(img, **opt)[0] == oracle.count_protocol_mem(img, **opt)[0]
 
 
@@ -76,11 +74,12 @@ EDGE = {
     "palindromes": b"ACGT" * 60 + b"\n" + b"AATT" * 60 + b"\n",
     "saturation": b"A" * 2500 + b"\n" + b"T" * 900 + b"\n" + b"ACGTTGCA" * 300 + b"\n",
     "no_trailing_separator": b"ACGTTGCAAGGCTTAACCGGTTAACCGGATCGGATTACAGGATTTACA",
+    "long_read_one_n": b"ACGTTGCAAGGCTTAACCGGTTAACCGGATCGGATTACAGGATTTACAGGCATCGATCGGGATATCGCGCTAGCTAGGCTAN" + b"GATTACA" * 30 + b"\n",
 }
 
 
 @pytest.mark.parametrize("name", sorted(EDGE))
-@pytest.mark.parametrize("opt", [dict(k=31), dict(k=7), dict(k=31, bf_shift=20)], ids=["k31", "k7", "k31b20"])
+@pytest.mark.parametrize("opt", [dict(k=31), dict(k=7), dict(k=31, bf_shift=20), dict(k=45)], ids=["k31", "k7", "k31b20", "k45"])
 def test_edge_inputs(name, opt, ya, oracle):
     img = EDGE[name]
     got, tot = ya.count_protocol_host(img, **opt)

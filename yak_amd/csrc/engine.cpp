@@ -368,7 +368,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));
 	c->st_cur.ms_total = now_ms();
 	/* exclusive-ownership LDS counting needs level-1 buckets == sub-tables and 2-bit k-mers */
-	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && c->k < 32 && (!c->has_bloom || c->nb <= 42);
+	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && (!c->has_bloom || c->nb <= 42);
 	c->kept_bytes = 0; c->t_pass0_set = false; c->ms_part2 = c->ms_lds = 0;
 	if (c->fast) {
 		size_t fr = 0, tot = 0;
@@ -554,7 +554,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("feed outside a pass");
-	if (c->k >= 32) return fail("k >= 32 is not implemented on the device yet");
+	if (c->k >= 64 || c->k < 1) return fail("k must be in [1, 63]");
 	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
 	HIPCK(hipSetDevice(c->dev));
 	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 27);
@@ -617,7 +617,7 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
                                       int pre, int plo, int phi, void *stream)
 {
-	if (k >= 32 || k < 1) { fail("extract: unsupported k"); return -1; }
+	if (k >= 64 || k < 1) { fail("extract: unsupported k"); return -1; }
 	u64 *d_cur = 0, n = 0;
 	hipStream_t st = (hipStream_t)stream;
 	if (hipMalloc((void**)&d_cur, 8) != hipSuccess) { fail("hipMalloc"); return -1; }
@@ -825,6 +825,7 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 	HIPCK(hipSetDevice(c->dev));
 	const int P = c->P;
 	int64_t n_ins = 0;
+	if (c->k >= 32 && yk_bad_hash_seen(c->st)) { pass_free(c); return fail("a 64-bit k-mer hash equals the empty-slot pattern: unsupported input for k >= 32"); }
 	if (!c->create_new) {
 		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
 		HIPCK(hipStreamSynchronize(c->st));

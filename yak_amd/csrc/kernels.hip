@@ -82,11 +82,11 @@ __device__ const unsigned char d_nt4[256] = {
 #define XT_TILE    4096
 #define XT_THREADS 256
 #define XT_ROUNDS  (XT_TILE / XT_THREADS)
-#define XT_HALO    32
+#define XT_HALO    64          /* left context: k - 1 <= 62 bases */
 
 struct XtTile {
-	u32 code[XT_TILE / 16 + 4];      /* 2 bits per base, 16 bases per word, base j of the stream at bits 2(j%16) */
-	u32 valid[XT_TILE / 32 + 4];     /* 1 bit per base: ACGT or not */
+	u32 code[(XT_TILE + XT_HALO) / 16 + 4];      /* 2 bits per base, 16 bases per word, base j of the stream at bits 2(j%16) */
+	u32 valid[(XT_TILE + XT_HALO) / 32 + 4];     /* 1 bit per base: ACGT or not */
 	unsigned char lut[256];
 };
 
@@ -94,7 +94,7 @@ __device__ __forceinline__ void xt_init(XtTile &S)
 {
 	const int tid = threadIdx.x;
 	if (tid < 64) ((u32*)S.lut)[tid] = ((const u32*)d_nt4)[tid];
-	if (tid < 4) { S.code[XT_TILE / 16 + tid] = 0; S.valid[XT_TILE / 32 + tid] = 0; }
+	if (tid < 4) { S.code[(XT_TILE + XT_HALO) / 16 + tid] = 0; S.valid[(XT_TILE + XT_HALO) / 32 + tid] = 0; }
 	__syncthreads();
 }
 
@@ -128,6 +128,57 @@ __device__ __forceinline__ void xt_load(XtTile &S, const uint8_t *__restrict__ b
 	__syncthreads();
 }
 
+__device__ __forceinline__ u64 yk_hash64_64(u64 x)                   /* reference yak-priv.h:23-33 */
+{
+	x = ~x + (x << 21);
+	x ^= x >> 24;
+	x = x + (x << 3) + (x << 8);
+	x ^= x >> 14;
+	x = x + (x << 2) + (x << 4);
+	x ^= x >> 28;
+	x = x + (x << 31);
+	return x;
+}
+
+/* even bits of a 64-bit word packed into the low 32 bits */
+__device__ __forceinline__ u64 yk_even_bits(u64 x)
+{
+	x &= 0x5555555555555555ull;
+	x = (x | x >> 1) & 0x3333333333333333ull;
+	x = (x | x >> 2) & 0x0f0f0f0f0f0f0f0full;
+	x = (x | x >> 4) & 0x00ff00ff00ff00ffull;
+	x = (x | x >> 8) & 0x0000ffff0000ffffull;
+	return (x | x >> 16) & 0xffffffffull;
+}
+
+__device__ u32 d_bad_hash;       /* k >= 32 only: a 64-bit hash equal to a table sentinel was met */
+
+/* k in [32, 63] (reference count.c:45-60 + yak-priv.h:35-39): the four k-bit planes are the low / high
+ * bits of the forward strand (first base most significant) and the complemented low / high bits of
+ * the reverse strand; the strand is chosen on the high planes, the hash is the sum of two 64-bit mixes */
+__device__ __forceinline__ bool xt_kmer_long(const XtTile &S, int r, int k, int pre, int64_t tile0, int64_t n, u64 *h)
+{
+	const int e = XT_HALO + r * XT_THREADS + (int)threadIdx.x;
+	const int s = e - k + 1;
+	const int v0 = s >> 5, vo = s & 31;
+	const u64 va = (u64)S.valid[v0] | (u64)S.valid[v0 + 1] << 32, vb = S.valid[v0 + 2];
+	u64 V = va >> vo;
+	if (vo) V |= vb << (64 - vo);
+	const u64 kones = (1ull << k) - 1;
+	const int w0 = s >> 4, o = 2 * (s & 15);
+	const u64 a = (u64)S.code[w0] | (u64)S.code[w0 + 1] << 32, b = (u64)S.code[w0 + 2] | (u64)S.code[w0 + 3] << 32;
+	u64 lo = a >> o, hi = b >> o;
+	if (o) { lo |= b << (64 - o); hi |= (u64)S.code[w0 + 4] << (64 - o); }
+	const u64 L = (yk_even_bits(lo) | yk_even_bits(hi) << 32) & kones;
+	const u64 H = (yk_even_bits(lo >> 1) | yk_even_bits(hi >> 1) << 32) & kones;
+	const u64 x0 = __brevll(L) >> (64 - k), x1 = __brevll(H) >> (64 - k), x2 = ~L & kones, x3 = ~H & kones;
+	const u64 hv = x1 < x3 ? yk_hash64_64(x0) + yk_hash64_64(x1) : yk_hash64_64(x2) + yk_hash64_64(x3);
+	*h = hv;
+	const bool ok = (V & kones) == kones && tile0 + r * XT_THREADS + threadIdx.x < n;
+	if (ok && (hv >> pre) == (~0ull >> pre)) d_bad_hash = 1;       /* would collide with the EMPTY slot pattern */
+	return ok;
+}
+
 /* phase 2: hashed canonical k-mer ending at tile position r * XT_THREADS + tid; false if the window
  * holds a non-ACGT byte or lies beyond n */
 __device__ __forceinline__ bool xt_kmer(const XtTile &S, int r, int k, u64 mask, u64 kones, int64_t tile0, int64_t n, u64 *h)
@@ -158,14 +209,14 @@ void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64
 	const int64_t tile0 = pos0 + (int64_t)blockIdx.x * XT_TILE;   /* pos0 is a multiple of 16 */
 	xt_init(S);
 	xt_load(S, bases, tile0, n);
-	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	const u64 mask = k < 32 ? (1ull << (2 * k)) - 1 : ~0ull, kones = (1ull << k) - 1;
 	const u32 pmask = (1u << pre) - 1;
 	u64 hv[XT_ROUNDS];
 	u32 okm = 0;
 #pragma unroll
 	for (int r = 0; r < XT_ROUNDS; ++r) {
 		u64 h;
-		bool ok = xt_kmer(S, r, k, mask, kones, tile0, n, &h);
+		bool ok = k < 32 ? xt_kmer(S, r, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, r, k, pre, tile0, n, &h);
 		const u32 p = (u32)h & pmask;
 		ok = ok && (int)p >= plo && (int)p < phi;
 		hv[r] = h;
@@ -223,7 +274,7 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 	u32 *row = rows + (size_t)blockIdx.x * NB;
 	for (int j = threadIdx.x; j < NB; j += XT_THREADS) s_bkt[j] = MODE ? row[j] : 0;
 	xt_init(S);
-	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	const u64 mask = k < 32 ? (1ull << (2 * k)) - 1 : ~0ull, kones = (1ull << k) - 1;
 	const u32 pmask = (1u << pre) - 1;
 	for (int t = 0; t < XP_T; ++t) {
 		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
@@ -232,7 +283,7 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 #pragma unroll 4
 		for (int r = 0; r < XT_ROUNDS; ++r) {
 			u64 h;
-			bool ok = xt_kmer(S, r, k, mask, kones, tile0, n, &h);
+			bool ok = k < 32 ? xt_kmer(S, r, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, r, k, pre, tile0, n, &h);
 			const u32 p = (u32)h & pmask;
 			ok = ok && (int)p >= plo && (int)p < phi;
 			if (ok) {
@@ -1606,6 +1657,14 @@ void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, in
 	hipLaunchKernelGGL(k_rpart<0>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
 	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
+}
+
+int yk_bad_hash_seen(hipStream_t st)
+{
+	u32 v = 0;
+	(void)hipStreamSynchronize(st);
+	(void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(d_bad_hash), 4);
+	return (int)v;
 }
 
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st)

@@ -78,6 +78,7 @@ void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, in
 int yk_xpart_blocks(int64_t n_pos);
 int yk_part_groups(void);
 int yk_rpart_blocks(int64_t n_rec);
+int yk_bad_hash_seen(hipStream_t st);
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st);
 void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView img,
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
