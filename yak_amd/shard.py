@@ -50,6 +50,39 @@ def _a2a(recv, send, recv_counts, send_counts):
         r.wait()
 
 
+MAX_MSG_ELEMS = 1 << 26      # per-peer message size cap (elements): RCCL/torch mis-handle messages of several GB
+
+
+def _a2a_rounds(recv, send, recv_counts, send_counts):
+    """all-to-all of variable-size segments in rounds of at most MAX_MSG_ELEMS elements per peer;
+    every round writes straight into its final place (views), so `recv` ends up grouped by source"""
+    world = dist.get_world_size()
+    so, ro = [0], [0]
+    for c in send_counts:
+        so.append(so[-1] + c)
+    for c in recv_counts:
+        ro.append(ro[-1] + c)
+    biggest = torch.tensor([max(list(send_counts) + list(recv_counts) + [0])], dtype=torch.int64, device=send.device)
+    if world > 1:
+        dist.all_reduce(biggest, op=dist.ReduceOp.MAX)           # every rank must run the same number of rounds
+    rounds = (int(biggest.item()) + MAX_MSG_ELEMS - 1) // MAX_MSG_ELEMS
+    for r in range(rounds):
+        a, b = r * MAX_MSG_ELEMS, (r + 1) * MAX_MSG_ELEMS
+        sc = [max(0, min(c, b) - a) if c > a else 0 for c in send_counts]
+        rc = [max(0, min(c, b) - a) if c > a else 0 for c in recv_counts]
+        if dist.get_backend() == "gloo":
+            ins = torch.cat([send[so[d] + a:so[d] + a + sc[d]] for d in range(world)]) if sum(sc) else send[:0]
+            out = torch.empty(sum(rc), dtype=recv.dtype, device=recv.device)
+            _a2a(out, ins, rc, sc)
+            o = 0
+            for s_ in range(world):
+                recv[ro[s_] + a:ro[s_] + a + rc[s_]] = out[o:o + rc[s_]]
+                o += rc[s_]
+        else:
+            dist.all_to_all([recv[ro[s_] + a:ro[s_] + a + rc[s_]] for s_ in range(world)],
+                            [send[so[d] + a:so[d] + a + sc[d]] for d in range(world)])
+
+
 def exchange(send_hash, send_t, send_counts):
     """send_hash (int64) / send_t (int32, may be None) are grouped by destination rank with
     `send_counts[d]` entries for rank d.  Returns (recv_hash, recv_t, recv_counts) grouped by
@@ -60,13 +93,13 @@ def exchange(send_hash, send_t, send_counts):
     rc = torch.empty_like(sc)
     _a2a(rc, sc, [1] * world, [1] * world)
     recv_counts = [int(x) for x in rc.tolist()]
-    n_send, n_recv = sum(send_counts), sum(recv_counts)
+    n_recv = sum(recv_counts)
     recv_hash = torch.empty(n_recv, dtype=send_hash.dtype, device=dev)
-    _a2a(recv_hash, send_hash[:n_send], recv_counts, list(send_counts))
+    _a2a_rounds(recv_hash, send_hash, recv_counts, list(send_counts))
     recv_t = None
     if send_t is not None:
         recv_t = torch.empty(n_recv, dtype=send_t.dtype, device=dev)
-        _a2a(recv_t, send_t[:n_send], recv_counts, list(send_counts))
+        _a2a_rounds(recv_t, send_t, recv_counts, list(send_counts))
     return recv_hash, recv_t, recv_counts
 
 
