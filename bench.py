@@ -133,42 +133,34 @@ def main():
     torch.cuda.synchronize()
     n_bytes = d_reads.numel()
 
-    # exchange buffers (sharded path only)
+    # exchange buffers (sharded path only): 16-byte records {hash, position} grouped by prefix
     if sharded:
-        x_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # extraction scratch
-        x_t = torch.empty(n_bytes, dtype=torch.int32, device=dev)
-        s_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)     # send, grouped by destination
-        s_t = torch.empty(n_bytes, dtype=torch.int32, device=dev)
+        s_rec = torch.empty((n_bytes, 2), dtype=torch.int64, device=dev)
+        h_bstart = (C.c_uint64 * (P + 1))()
 
-    def exchange(with_t):
-        """extract per destination, all-to-all the hashed k-mers to their owner (RCCL over xGMI)"""
+    def exchange():
+        """partition this rank's k-mers by sub-table prefix once, then one all-to-all per pass moves
+        every record to the owner of its prefix (RCCL over xGMI)"""
         from yak_amd import shard
-        send_counts, off = [], 0
-        for d in range(world):
-            dlo, dhi = shard.owner_range(d, world, P)
-            n = L.yakamd_extract_dev(K, d_reads.data_ptr(), n_bytes, x_hash.data_ptr(), x_t.data_ptr(), PRE, dlo, dhi, None)
-            if n < 0:
-                raise RuntimeError("extract failed")
-            s_hash[off:off + n].copy_(x_hash[:n])
-            if with_t:
-                s_t[off:off + n].copy_(x_t[:n])
-            send_counts.append(n); off += n
-        r_hash, r_t, recv_counts = shard.exchange(s_hash, s_t if with_t else None, send_counts)
+        n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+        if n < 0:
+            raise RuntimeError("partition failed")
+        segs = shard.exchange_partitioned(s_rec[:n], list(h_bstart), P)
         torch.cuda.synchronize()
-        return r_hash, r_t, recv_counts
+        return segs
 
     def one_pass(t, create_new):
         if not sharded:
             t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
-        r_hash, r_t, recv_counts = exchange(bool(create_new))
+        segs = exchange()
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
-        from yak_amd import shard
-        for src, off, n, t0 in shard.segments(recv_counts, n_bytes):   # by source rank = stream order of the job
-            tp = r_t[off:off + n].data_ptr() if r_t is not None else x_t.data_ptr()
-            if L.yakamd_feed_hashed_dev(t.h, r_hash[off:off + n].data_ptr(), tp, n, t0, n_bytes) != 0:
-                raise RuntimeError("feed_hashed")
+        for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job
+            if rec.shape[0]:
+                ob = (C.c_uint64 * (P + 1))(*offs)
+                if L.yakamd_feed_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob, src * n_bytes, n_bytes) != 0:
+                    raise RuntimeError("feed_partitioned")
         n_ins = L.yakamd_pass_end(t.h)
         if n_ins < 0:
             raise RuntimeError("pass_end")

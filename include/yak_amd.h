@@ -57,6 +57,16 @@ int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
                            void *d_hash_u64_out, void *d_t_u32_out,
                            int pre, int prefix_lo, int prefix_hi, void *stream);
 
+/* Sharded exchange without re-extraction.  yakamd_partition_dev() turns a device-resident base
+ * image into 16-byte records {yak_hash64, position} grouped by sub-table prefix (ascending), and
+ * returns the 1<<pre + 1 group offsets in h_bstart; prefixes owned by one rank are contiguous, so a
+ * rank's send buffer per destination is a slice.  The receiver hands every source's slice to
+ * yakamd_feed_partitioned_dev() together with that slice's own offsets (h_bstart[p] = first record
+ * of prefix p inside d_rec, entries outside the shard equal their neighbours). */
+int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart);
+int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart,
+                                uint64_t t0, uint64_t t_span);
+
 /* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
 void *yakamd_dev_alloc(size_t bytes);
 void yakamd_dev_free(void *p);

@@ -133,6 +133,56 @@ def test_cli_drop_in(ya, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("bf", [0, 23])
+def test_partitioned_exchange_path_on_one_gpu(bf, ya, oracle, synth):
+    """same with the production exchange format: yakamd_partition_dev once per source, the owner
+    receives per-source slices + per-prefix offsets through yakamd_feed_partitioned_dev"""
+    L = ya.lib()
+    world, P = 4, 1024
+    per = P // world
+    slices = [synth(1200, g=12000, s=5, first=r * 1200) for r in range(world)]
+    nb = len(slices[0])
+    parts_by_src = []
+    for x in slices:                                     # what every source rank prepares
+        d = L.yakamd_dev_alloc(nb); rec = L.yakamd_dev_alloc(nb * 16)
+        assert L.yakamd_memcpy_h2d(d, x, nb) == 0
+        bst = (C.c_uint64 * (P + 1))()
+        n = L.yakamd_partition_dev(31, 10, d, nb, rec, bst)
+        assert n == bst[P] and n > 0
+        parts_by_src.append((rec, list(bst)))
+        L.yakamd_dev_free(d)
+    parts, tot = [], 0
+    for r in range(world):
+        lo, hi = r * per, (r + 1) * per
+        t = ya.Table(31, 10, 4, bf)
+        assert L.yakamd_set_shard(t.h, lo, hi) == 0
+
+        def one_pass(create_new):
+            assert L.yakamd_pass_begin(t.h, create_new) == 0
+            for src, (rec, bst) in enumerate(parts_by_src):
+                m = bst[hi] - bst[lo]
+                offs = [0] * lo + [b - bst[lo] for b in bst[lo:hi + 1]] + [m] * (P - hi)
+                ob = (C.c_uint64 * (P + 1))(*offs)
+                assert L.yakamd_feed_partitioned_dev(t.h, rec + 16 * bst[lo], m, ob, src * nb, nb) == 0
+            n_ins = L.yakamd_pass_end(t.h)
+            assert n_ins >= 0
+            t.h.contents.tot += n_ins
+        one_pass(1)
+        if bf:
+            t.destroy_bf(); t.clear(); one_pass(0); t.shrink(2, 1023)
+        data = t.dump_bytes(); tot += t.tot; t.close()
+        off = 16
+        for p in range(P):
+            cap, n = struct.unpack_from("<II", data, off)
+            if lo <= p < hi:
+                parts.append(data[off:off + 8 + 8 * n])
+            off += 8 + 8 * n
+    for rec, _ in parts_by_src:
+        L.yakamd_dev_free(rec)
+    want, wtot = oracle.count_protocol_mem(b"".join(slices), k=31, bf_shift=bf)
+    assert want[:16] + b"".join(parts) == want and tot == wtot
+
+
+@pytest.mark.parametrize("bf", [0, 23])
 def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
     """the multi-GPU data path with virtual ranks on one device: per-destination extraction
     (yakamd_extract_dev), owner-side yakamd_set_shard + yakamd_feed_hashed_dev with source-rank

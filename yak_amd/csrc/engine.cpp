@@ -614,6 +614,49 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	return consume_records(c, (int64_t)n_rec, t0, t0, t0 + t_span);
 }
 
+extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart)
+{
+	if (k < 1 || k > 63 || pre < 3 || pre > 13) { fail("partition: unsupported k / pre"); return -1; }
+	if (((uintptr_t)d_bases & 15) != 0 || n_bytes >= ((int64_t)1 << 32)) { fail("partition: base image must be 16-byte aligned and < 4 GiB"); return -1; }
+	const size_t NB = (size_t)1 << pre;
+	const int n_blk = yk_xpart_blocks(n_bytes);
+	u32 *d_rows = 0; u64 *d_partial = 0, *d_bstart = 0;
+	if (dmalloc(&d_rows, NB * (size_t)n_blk) || dmalloc(&d_partial, NB * yk_part_groups()) || dmalloc(&d_bstart, NB + 1)) return -1;
+	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_rec_out, 0);
+	const hipError_t e = hipMemcpy(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost);
+	dfree(d_rows); dfree(d_partial); dfree(d_bstart);
+	if (e != hipSuccess) { fail("partition: %s", hipGetErrorString(e)); return -1; }
+	return (int64_t)h_bstart[NB];
+}
+
+extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	if (c->nb_bits != c->pre) return fail("feed_partitioned needs pre <= 13");
+	HIPCK(hipSetDevice(c->dev));
+	if (n <= 0) return 0;
+	const size_t NB = (size_t)1 << c->nb_bits;
+	if (c->fast) {
+		Rec *out = 0;
+		if (fast_admit(c, t0, t_span, (u64)n, &out)) return -1;
+		if (c->fast) {                                       /* admitted: keep a private copy, already grouped by prefix */
+			HIPCK(hipMemcpyAsync(out, d_rec, (size_t)n * sizeof(Rec), hipMemcpyDeviceToDevice, c->st));
+			yakamd_ctx::Kept &k = c->kept.back();
+			k.bstart.assign(h_bstart, h_bstart + NB + 1);
+			k.n = (u64)n;
+			c->st_cur.n_instances += n;
+			if (t0 + t_span > c->t_end) c->t_end = t0 + t_span;
+			return 0;
+		}
+	}
+	Rec *keep = c->d_rec;                                    /* general path / pass 2: consume in place */
+	c->d_rec = (Rec*)d_rec;
+	const int r = consume_records(c, n, t0, t0, t0 + t_span);
+	c->d_rec = keep;
+	return r;
+}
+
 extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
                                       int pre, int plo, int phi, void *stream)
 {

@@ -111,3 +111,33 @@ def segments(recv_counts, slice_bytes):
         if n:
             yield src, off, n, src * slice_bytes
         off += n
+
+
+def exchange_partitioned(send_rec, bstart, n_prefix):
+    """send_rec: int64 tensor [n, 2] of records grouped by sub-table prefix (ascending), `bstart` the
+    n_prefix + 1 group offsets (yakamd_partition_dev).  Owners are contiguous prefix ranges, so the
+    per-destination send buffers are slices.  Returns a list, in source-rank order, of
+    (recv_slice [m, 2], offsets[n_prefix + 1] of that slice) ready for yakamd_feed_partitioned_dev."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = send_rec.device
+    per = n_prefix // world
+    send_counts = [int(bstart[(d + 1) * per] - bstart[d * per]) for d in range(world)]
+    # relative offsets of the owned prefixes inside each destination's slice
+    rel = torch.tensor([[int(bstart[d * per + j] - bstart[d * per]) for j in range(per + 1)] for d in range(world)],
+                       dtype=torch.int64, device=dev).reshape(-1)
+    rel_in = torch.empty_like(rel)
+    _a2a(rel_in, rel, [per + 1] * world, [per + 1] * world)
+    rel_in = rel_in.reshape(world, per + 1).tolist()
+    recv_counts = [r[-1] for r in rel_in]
+    flat = send_rec.reshape(-1)
+    recv = torch.empty(2 * sum(recv_counts), dtype=torch.int64, device=dev)
+    _a2a_rounds(recv, flat, [2 * c for c in recv_counts], [2 * c for c in send_counts])
+    recv = recv.reshape(-1, 2)
+    lo = rank * per
+    out, off = [], 0
+    for src in range(world):
+        m = recv_counts[src]
+        offs = [0] * lo + rel_in[src] + [m] * (n_prefix - lo - per)
+        out.append((recv[off:off + m], offs))
+        off += m
+    return out
