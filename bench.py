@@ -244,6 +244,8 @@ def main():
         dist.destroy_process_group()
         return
 
+    dbgc = (C.c_uint32 * 4)()
+    L.yakamd_debug_counters(dbgc)
     # roofline of the dominant kernel (HIP-event timed inside the library, per launch)
     kern = [("k_acc_insert", s1, B_INSERT)]
     if s2:
@@ -275,6 +277,7 @@ def main():
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_instance": bpi, "instances_per_launch": st["n_instances"] / launches},
         "verify": verify,
+        "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, min(os.cpu_count() or 8, 32))

@@ -73,6 +73,9 @@ void yakamd_dev_free(void *p);
 int yakamd_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int yakamd_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 
+/* diagnostics: [0] doublings done by the parallel replay routine, [1] sent back to the serial one */
+void yakamd_debug_counters(uint32_t *out4);
+
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
 

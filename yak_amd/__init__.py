@@ -27,7 +27,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
-    "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev",
+    "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters",
 ]
 
 

@@ -714,19 +714,20 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 		tot += std::max<u64>(32, capm);
 	}
 	(void)d_seg_off;
-	u64 *nk = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0;
+	u64 *nk = 0, *sp = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0;
 	ReplayTask *d_tasks = 0;
-	if (dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) || dmalloc(&nd, tot) ||
+	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
+	if ((par && dmalloc(&sp, 2 * tot)) || dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) || dmalloc(&nd, tot) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
 	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
 	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
 	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
-	yk_launch_replay(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, so, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
+	yk_launch_replay(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
 	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	dfree(su); dfree(so); dfree(d_tasks); dfree(d_ob); dfree(d_oc);
+	dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc);
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
 	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
 	c->h_off = new_off;
@@ -931,6 +932,12 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 	c->st_cur.ms_total = now_ms() - c->st_cur.ms_total;
 	c->st_last = c->st_cur;
 	return n_ins;
+}
+
+extern "C" void yakamd_debug_counters(uint32_t *out4)
+{
+	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	yk_par_counters(&out4[0], &out4[1]);
 }
 
 extern "C" void *yakamd_dev_alloc(size_t bytes) { void *p = 0; return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : 0; }

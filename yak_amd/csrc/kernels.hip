@@ -918,6 +918,7 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
  *   * growth happens at the next put-call once count >= 0.75 capacity (khashl.h:202), including a
  *     trailing put-call on an existing key (lastput vs. time of the last new key).
  * ------------------------------------------------------------------------------------------ */
+#define RP_PAR_MIN  8192                                 /* doublings from this size on try the exact parallel routine */
 #define RP_LDS_WORDS 4096                                 /* doublings up to 131072 slots keep their bitmaps in LDS */
 __device__ __forceinline__ bool bm_get(const u32 *u, u32 i) { return u[i >> 5] >> (i & 31) & 1; }
 
@@ -1122,14 +1123,183 @@ __device__ void replay_prefetch(const u64 *keys, u32 n, u32 nbits_new, volatile 
 	if (acc == 0x5a5a5a5au) *sink = acc;                   /* keeps the touches alive */
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Exact PARALLEL doubling.
+ * The serial loop above defines, for every key, a processing time sigma = (c, d): c = old slot at
+ * which the scan started the kick-out chain that moved the key, d = its depth in that chain; the
+ * final layout is first-come-first-served linear probing in sigma order.  Two facts make it
+ * parallel:  (1) FCFS in sigma order == ordered probing with priority sigma (atomicMin per slot);
+ * (2) the key at old slot s is kicked by the key x that lands on physical slot s iff c(x) < s, and
+ * x comes from an old slot <= s/2 + D1 (new home = 2 * old home + 1 bit, D1 = largest old
+ * displacement).  So sigma and landing slot become final front to back: once all old slots < F are
+ * final, sigma is known up to ~2F and landings up to ~2F - 4 D1.  Each round is a handful of
+ * workgroup-wide passes; the first ~8 D1 slots are done by the literal serial rule.
+ * The result is VERIFIED against the defining fixed point (sigma of every key follows from its
+ * lander; every key sits at the first slot from its home not held by an earlier key).  That fixed
+ * point is unique, so a verified layout is the reference's; on any doubt the caller falls back to
+ * the serial routine (nothing has been modified until the commit).
+ * ------------------------------------------------------------------------------------------ */
+__device__ u32 d_par_ok, d_par_fail;      /* doublings done by the parallel routine / sent back to the serial one */
+#define PD_EMPTY  0xffffffffffffffffull
+#define PD_FINAL  0x8000000000000000ull
+#define PD_PACK(c, d, s) ((u64)(c) << 40 | (u64)(d) << 24 | (u64)(s))
+#define PD_C(o) ((u32)((o) >> 40) & 0x7fffffu)
+#define PD_D(o) ((u32)((o) >> 24) & 0xffffu)
+#define PD_S(o) ((u32)(o) & 0xffffffu)
+
+/* one workgroup on one CU: its waves share the L1, so a workgroup barrier (which carries the
+ * workgroup-scope fence) orders its own global traffic; the agent-scope write-back + invalidate of
+ * block_sync_global() is only needed once, before the result is handed to the rest of the kernel */
+__device__ __forceinline__ void pd_sync() { __syncthreads(); }
+
+__device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u32 N, u32 nb_new,
+                                  u64 *OWN, u64 *SIG, u64 *TMP, u32 *s_par /* LDS [8] */)
+{
+	const u32 tid = threadIdx.x, Nmask = N - 1, nmask = n - 1;
+	u32 *s_fail = s_par, *s_d1 = s_par + 1, *s_cnt = s_par + 2;
+	if (tid < 8) s_par[tid] = 0;
+	__syncthreads();
+	/* 0. copies, largest old displacement */
+	u32 d1 = 0, nused = 0;
+	for (u32 s = tid; s < n; s += 256) {
+		const u64 k = keys[s];
+		TMP[s] = k; SIG[s] = PD_EMPTY;
+		if (bm_get(cur, s)) { const u32 h = yk_h2b((u32)(k >> 10), nb_new - 1); const u32 d = (s - h) & nmask; d1 = d > d1 ? d : d1; ++nused; }
+	}
+	for (u32 i = tid; i < N; i += 256) OWN[i] = PD_EMPTY;
+	atomicMax(s_d1, d1); atomicAdd(s_cnt, nused);
+	pd_sync();
+	const u32 D1 = *s_d1, n_used = *s_cnt;
+	const u32 F0 = 5 * D1 + 16, B0 = F0 + 2 * D1 + 4;               /* final after the base phase / simulated by it */
+	if (B0 * 4 > n || n > (1u << 23)) return false;                        /* too clustered / too large: serial */
+	/* 1. the literal rule for scan positions below B0; a chain is followed only while it stays below
+	 * B0 (what it kicks further up lands beyond anything the first F0 slots can reach, and gets its
+	 * sigma from the lander rule later); only slots < F0 are kept, the rest is margin */
+	if (tid == 0) {
+		for (u32 j = 0; j < B0; ++j) {
+			if (!bm_get(cur, j) || SIG[j] != PD_EMPTY) continue;
+			u32 s = j, d = 0;
+			for (;;) {
+				const u64 me = PD_PACK(j, d, s);
+				SIG[s] = me | PD_FINAL;
+				u32 i = yk_h2b((u32)(TMP[s] >> 10), nb_new);
+				while (OWN[i] != PD_EMPTY) i = (i + 1) & Nmask;
+				OWN[i] = me;
+				if (i < B0 && bm_get(cur, i) && SIG[i] == PD_EMPTY) { s = i; ++d; } else break;
+			}
+		}
+	}
+	pd_sync();
+	{
+		const u32 hi0 = 2 * B0 + 4 * D1 + 16, hi = hi0 < N ? hi0 : N;
+		for (u32 i = tid; i < hi; i += 256) {
+			const u64 o = OWN[i];
+			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
+		}
+		for (u32 i = N - (4 * D1 + 16) + tid; i < N; i += 256) {             /* landings that wrapped are near the end */
+			const u64 o = OWN[i];
+			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
+		}
+		pd_sync();
+		for (u32 s = F0 + tid; s < B0; s += 256) SIG[s] = PD_EMPTY;
+		pd_sync();
+	}
+	/* 2. rounds */
+	u32 F = F0;
+	while (F < n) {
+		u32 S1 = 2 * (F - D1) - 1;
+		if (S1 > n) S1 = n;
+		const u32 S2 = S1 == n ? n : S1 - (2 * D1 + 3);
+		if (S2 <= F) { return false; }
+		/* A: sigma of the keys whose possible landers are all final */
+		for (u32 s = F + tid; s < S1; s += 256) {
+			if (!bm_get(cur, s) || SIG[s] != PD_EMPTY) continue;
+			const u64 o = OWN[s];
+			SIG[s] = (o != PD_EMPTY && PD_S(o) != s && PD_C(o) < s) ? PD_PACK(PD_C(o), PD_D(o) + 1, s) : PD_PACK(s, 0, s);
+		}
+		pd_sync();
+		/* B: ordered probing of those keys on top of the final ones */
+		for (u32 s = F + tid; s < S1; s += 256) {
+			if (!bm_get(cur, s)) continue;
+			u64 cand = SIG[s];
+			if (cand & PD_FINAL) continue;
+			u32 i = yk_h2b((u32)(TMP[s] >> 10), nb_new);
+			for (u32 guard = 0; guard < N; ++guard) {
+				const u64 old = atomicMin(&OWN[i], cand);
+				if (old == PD_EMPTY) break;
+				if (old > cand) {
+					if (__hip_atomic_load(&SIG[PD_S(old)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PD_FINAL) { *s_fail = 1; break; }
+					cand = old;
+				}
+				i = (i + 1) & Nmask;
+			}
+		}
+		pd_sync();
+		if (*s_fail) return false;
+		/* C: finalise [F, S2); take the not yet final participants [S2, S1) out again */
+		for (u32 s = F + tid; s < S2; s += 256) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] |= PD_FINAL;
+		if (S2 < S1) {
+			const u32 lo = 2 * (S2 > D1 ? S2 - D1 : 0), hi0 = 2 * S1 + 4 * D1 + 16, hi = hi0 < N ? hi0 : N;
+			for (u32 i = (lo > 2 ? lo - 2 : 0) + tid; i < hi; i += 256) {
+				const u64 o = OWN[i];
+				if (o != PD_EMPTY && PD_S(o) >= S2 && PD_S(o) < S1 && !(SIG[PD_S(o)] & PD_FINAL)) OWN[i] = PD_EMPTY;
+			}
+			pd_sync();
+			for (u32 s = S2 + tid; s < S1; s += 256) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] = PD_EMPTY;
+		}
+		pd_sync();
+		F = S2;
+	}
+	/* 3. verification of the fixed point */
+	if (tid < 8 && tid >= 2) s_par[tid] = 0;
+	__syncthreads();
+	u32 placed = 0, bad = 0;
+	for (u32 i = tid; i < N; i += 256) {
+		const u64 o = OWN[i];
+		if (o == PD_EMPTY) continue;
+		++placed;
+		const u32 so = PD_S(o);
+		if ((SIG[so] & ~PD_FINAL) != o) { bad = 1; continue; }
+		u32 q = yk_h2b((u32)(TMP[so] >> 10), nb_new), steps = 0;
+		while (q != i) {                                              /* every slot before it holds an earlier key */
+			const u64 p = OWN[q];
+			if (p == PD_EMPTY || p > o || ++steps > 4 * D1 + 64) { bad = 1; break; }
+			q = (q + 1) & Nmask;
+		}
+	}
+	for (u32 s = tid; s < n; s += 256) {
+		if (!bm_get(cur, s)) continue;
+		const u64 g = SIG[s], o = OWN[s];
+		if (g == PD_EMPTY || !(g & PD_FINAL)) { bad = 1; continue; }
+		const u64 want = (o != PD_EMPTY && PD_S(o) != s && PD_C(o) < s) ? PD_PACK(PD_C(o), PD_D(o) + 1, s) : PD_PACK(s, 0, s);
+		if ((g & ~PD_FINAL) != want) bad = 1;
+	}
+	atomicAdd(s_par + 3, placed);
+	if (bad) *s_fail = 1;
+	__syncthreads();
+	if (*s_fail || s_par[3] != n_used) return false;
+	/* 4. commit: move the keys, publish the new bitmap */
+	for (u32 w = tid; w < (N + 31) / 32; w += 256) {
+		u32 bits = 0;
+		for (u32 b = 0; b < 32 && w * 32 + b < N; ++b) {
+			const u64 o = OWN[w * 32 + b];
+			if (o != PD_EMPTY) { bits |= 1u << b; keys[w * 32 + b] = TMP[PD_S(o)]; }
+		}
+		oth[w] = bits;
+	}
+	__syncthreads();
+	return true;
+}
+
 __global__ __launch_bounds__(256)
 void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used,
-              u32 *scr_used, u32 *scr_owner, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
+              u32 *scr_used, u32 *scr_owner, u64 *scr_par, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
               u32 *out_bits, u32 *out_count)
 {
 	__shared__ u64 s_bm[RP_LDS_WORDS];                    /* doubling: old (high) and new (low) bitmap words, interleaved */
 	__shared__ u32 s_progress;
 	__shared__ u32 s_sel[64];
+	__shared__ u32 s_par[8];
 	const ReplayTask T = tasks[blockIdx.x];
 	const int tid = threadIdx.x;
 	u64 *keys = new_keys + T.new_off;
@@ -1145,7 +1315,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		bits = T.init_bits; n = 1u << bits;
 		for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = 0;
 	}
-	block_sync_global();
+	__syncthreads();
 
 	u32 i0 = 0;
 	for (;;) {
@@ -1162,6 +1332,13 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		}
 		if (grow) {
 			const u32 N = n ? n << 1 : 4, nb = n ? bits + 1 : 2;
+			bool done = false;
+			if (scr_par && n >= RP_PAR_MIN && !(T.dbg & 16)) {
+				u64 *pb = scr_par + 2 * T.new_off;
+				done = replay_double_par(keys, cur, oth, n, N, nb, pb, pb + N, pb + N + n, s_par);
+				if (tid == 0) atomicAdd(done ? &d_par_ok : &d_par_fail, 1u);
+			}
+			if (!done) {
 			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS && !(T.dbg & 8);
 			if (in_lds) {
 				for (u32 w = tid; w < (N + 31) / 32; w += 256) s_bm[w] = w < (n + 31) / 32 ? (u64)cur[w] << 32 : 0ull;
@@ -1169,14 +1346,15 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 				for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = 0;
 			}
 			if (tid == 0) s_progress = 0;
-			block_sync_global();
+			__syncthreads();
 			if (T.dbg & 1) { if (tid == 0) s_progress = 0xffffffffu; }
 			else if (tid < 64) {
 				if (in_lds) replay_double_wave64(keys, s_bm, n, N, nb, &s_progress, s_sel);
 				else replay_double_wave(keys, cur, oth, n, N, nb, &s_progress, s_sel);
 			} else if (tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
-			block_sync_global();
-			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = (u32)s_bm[w]; block_sync_global(); }
+			__syncthreads();
+			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = (u32)s_bm[w]; __syncthreads(); }
+			}
 			u32 *t = cur; cur = oth; oth = t;
 			n = N; bits = nb;
 			if (i0 == 0xffffffffu) break;
@@ -1187,7 +1365,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		const u32 nmask = n - 1;
 		if (T.dbg & 2) { cnt += batch; i0 += batch; continue; }
 		for (u32 i = tid; i < n; i += 256) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
-		block_sync_global();
+		__syncthreads();
 		for (u32 q = tid; q < batch; q += 256) {
 			u32 r = q + 1;
 			u32 slot = yk_h2b((u32)(rec_kc[T.rec_off + i0 + q] >> 10), bits);
@@ -1200,18 +1378,20 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 				slot = (slot + 1) & nmask;
 			}
 		}
-		block_sync_global();
-		for (u32 i = tid; i < n; i += 256) {
-			const u32 o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (o != 0 && o != 0xffffffffu) {
-				keys[i] = rec_kc[T.rec_off + i0 + o - 1];
-				atomicOr(&cur[i >> 5], 1u << (i & 31));
+		__syncthreads();
+		for (u32 w = tid; w < (n + 31) / 32; w += 256) {          /* one lane per bitmap word: no atomics on the bitmap */
+			u32 bits = cur[w];
+			for (u32 b = 0; b < 32 && w * 32 + b < n; ++b) {
+				const u32 i = w * 32 + b;
+				const u32 o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (o != 0 && o != 0xffffffffu) { keys[i] = rec_kc[T.rec_off + i0 + o - 1]; bits |= 1u << b; }
 			}
+			cur[w] = bits;
 		}
-		block_sync_global();
+		__syncthreads();
 		cnt += batch; i0 += batch;
 	}
-	block_sync_global();
+	__syncthreads();
 	/* publish: bitmap in the arena, unused slots normalised to YK_EMPTY */
 	if (cur != UA) for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = cur[w];
 	for (u32 i = tid; i < n; i += 256) if (!bm_get(cur, i)) keys[i] = YK_EMPTY;
@@ -1659,6 +1839,13 @@ void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, in
 	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
 }
 
+void yk_par_counters(u32 *ok, u32 *fail)
+{
+	(void)hipDeviceSynchronize();
+	(void)hipMemcpyFromSymbol(ok, HIP_SYMBOL(d_par_ok), 4);
+	(void)hipMemcpyFromSymbol(fail, HIP_SYMBOL(d_par_fail), 4);
+}
+
 int yk_bad_hash_seen(hipStream_t st)
 {
 	u32 v = 0;
@@ -1761,12 +1948,12 @@ void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const
 }
 
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
-                      u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner,
+                      u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
                       u32 *out_bits, u32 *out_count, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(256), 0, st, tasks, old_keys, old_used, new_keys, new_used,
-	                   scr_used, scr_owner, rec_kc, rec_t, lastput, out_bits, out_count);
+	                   scr_used, scr_owner, scr_par, rec_kc, rec_t, lastput, out_bits, out_count);
 }
 
 void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st)
