@@ -723,7 +723,10 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
 	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
-	yk_launch_replay(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
+	/* few, large sub-tables (a shard of a multi-GPU job): more lanes per sub-table */
+	const int n_active = c->phi - c->plo;
+	const int n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256);
+	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
 	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));

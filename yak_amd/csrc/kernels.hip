@@ -1161,12 +1161,12 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	__syncthreads();
 	/* 0. copies, largest old displacement */
 	u32 d1 = 0, nused = 0;
-	for (u32 s = tid; s < n; s += 256) {
+	for (u32 s = tid; s < n; s += blockDim.x) {
 		const u64 k = keys[s];
 		TMP[s] = k; SIG[s] = PD_EMPTY;
 		if (bm_get(cur, s)) { const u32 h = yk_h2b((u32)(k >> 10), nb_new - 1); const u32 d = (s - h) & nmask; d1 = d > d1 ? d : d1; ++nused; }
 	}
-	for (u32 i = tid; i < N; i += 256) OWN[i] = PD_EMPTY;
+	for (u32 i = tid; i < N; i += blockDim.x) OWN[i] = PD_EMPTY;
 	atomicMax(s_d1, d1); atomicAdd(s_cnt, nused);
 	pd_sync();
 	const u32 D1 = *s_d1, n_used = *s_cnt;
@@ -1192,16 +1192,16 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	pd_sync();
 	{
 		const u32 hi0 = 2 * B0 + 4 * D1 + 16, hi = hi0 < N ? hi0 : N;
-		for (u32 i = tid; i < hi; i += 256) {
+		for (u32 i = tid; i < hi; i += blockDim.x) {
 			const u64 o = OWN[i];
 			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
 		}
-		for (u32 i = N - (4 * D1 + 16) + tid; i < N; i += 256) {             /* landings that wrapped are near the end */
+		for (u32 i = N - (4 * D1 + 16) + tid; i < N; i += blockDim.x) {             /* landings that wrapped are near the end */
 			const u64 o = OWN[i];
 			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
 		}
 		pd_sync();
-		for (u32 s = F0 + tid; s < B0; s += 256) SIG[s] = PD_EMPTY;
+		for (u32 s = F0 + tid; s < B0; s += blockDim.x) SIG[s] = PD_EMPTY;
 		pd_sync();
 	}
 	/* 2. rounds */
@@ -1212,14 +1212,14 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 		const u32 S2 = S1 == n ? n : S1 - (2 * D1 + 3);
 		if (S2 <= F) { return false; }
 		/* A: sigma of the keys whose possible landers are all final */
-		for (u32 s = F + tid; s < S1; s += 256) {
+		for (u32 s = F + tid; s < S1; s += blockDim.x) {
 			if (!bm_get(cur, s) || SIG[s] != PD_EMPTY) continue;
 			const u64 o = OWN[s];
 			SIG[s] = (o != PD_EMPTY && PD_S(o) != s && PD_C(o) < s) ? PD_PACK(PD_C(o), PD_D(o) + 1, s) : PD_PACK(s, 0, s);
 		}
 		pd_sync();
 		/* B: ordered probing of those keys on top of the final ones */
-		for (u32 s = F + tid; s < S1; s += 256) {
+		for (u32 s = F + tid; s < S1; s += blockDim.x) {
 			if (!bm_get(cur, s)) continue;
 			u64 cand = SIG[s];
 			if (cand & PD_FINAL) continue;
@@ -1237,15 +1237,15 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 		pd_sync();
 		if (*s_fail) return false;
 		/* C: finalise [F, S2); take the not yet final participants [S2, S1) out again */
-		for (u32 s = F + tid; s < S2; s += 256) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] |= PD_FINAL;
+		for (u32 s = F + tid; s < S2; s += blockDim.x) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] |= PD_FINAL;
 		if (S2 < S1) {
 			const u32 lo = 2 * (S2 > D1 ? S2 - D1 : 0), hi0 = 2 * S1 + 4 * D1 + 16, hi = hi0 < N ? hi0 : N;
-			for (u32 i = (lo > 2 ? lo - 2 : 0) + tid; i < hi; i += 256) {
+			for (u32 i = (lo > 2 ? lo - 2 : 0) + tid; i < hi; i += blockDim.x) {
 				const u64 o = OWN[i];
 				if (o != PD_EMPTY && PD_S(o) >= S2 && PD_S(o) < S1 && !(SIG[PD_S(o)] & PD_FINAL)) OWN[i] = PD_EMPTY;
 			}
 			pd_sync();
-			for (u32 s = S2 + tid; s < S1; s += 256) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] = PD_EMPTY;
+			for (u32 s = S2 + tid; s < S1; s += blockDim.x) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] = PD_EMPTY;
 		}
 		pd_sync();
 		F = S2;
@@ -1254,7 +1254,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	if (tid < 8 && tid >= 2) s_par[tid] = 0;
 	__syncthreads();
 	u32 placed = 0, bad = 0;
-	for (u32 i = tid; i < N; i += 256) {
+	for (u32 i = tid; i < N; i += blockDim.x) {
 		const u64 o = OWN[i];
 		if (o == PD_EMPTY) continue;
 		++placed;
@@ -1267,7 +1267,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 			q = (q + 1) & Nmask;
 		}
 	}
-	for (u32 s = tid; s < n; s += 256) {
+	for (u32 s = tid; s < n; s += blockDim.x) {
 		if (!bm_get(cur, s)) continue;
 		const u64 g = SIG[s], o = OWN[s];
 		if (g == PD_EMPTY || !(g & PD_FINAL)) { bad = 1; continue; }
@@ -1279,7 +1279,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	__syncthreads();
 	if (*s_fail || s_par[3] != n_used) return false;
 	/* 4. commit: move the keys, publish the new bitmap */
-	for (u32 w = tid; w < (N + 31) / 32; w += 256) {
+	for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) {
 		u32 bits = 0;
 		for (u32 b = 0; b < 32 && w * 32 + b < N; ++b) {
 			const u64 o = OWN[w * 32 + b];
@@ -1291,7 +1291,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	return true;
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used,
               u32 *scr_used, u32 *scr_owner, u64 *scr_par, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
               u32 *out_bits, u32 *out_count)
@@ -1309,11 +1309,11 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 	u32 n = T.old_bits == YK_NOCAP ? 0 : 1u << T.old_bits, bits = T.old_bits == YK_NOCAP ? 0 : T.old_bits;
 	u32 cnt = T.old_count;
 
-	for (u32 i = tid; i < n; i += 256) keys[i] = old_keys[T.old_off + i];
-	for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = old_used[(T.old_off >> 5) + w];
+	for (u32 i = tid; i < n; i += blockDim.x) keys[i] = old_keys[T.old_off + i];
+	for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) UA[w] = old_used[(T.old_off >> 5) + w];
 	if (n == 0 && T.init_bits != YK_NOCAP) {                 /* yak_ht_resize(f, size) on an empty set (htab.c:186) */
 		bits = T.init_bits; n = 1u << bits;
-		for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = 0;
+		for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) UA[w] = 0;
 	}
 	__syncthreads();
 
@@ -1341,9 +1341,9 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 			if (!done) {
 			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS && !(T.dbg & 8);
 			if (in_lds) {
-				for (u32 w = tid; w < (N + 31) / 32; w += 256) s_bm[w] = w < (n + 31) / 32 ? (u64)cur[w] << 32 : 0ull;
+				for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) s_bm[w] = w < (n + 31) / 32 ? (u64)cur[w] << 32 : 0ull;
 			} else {
-				for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = 0;
+				for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) oth[w] = 0;
 			}
 			if (tid == 0) s_progress = 0;
 			__syncthreads();
@@ -1353,7 +1353,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 				else replay_double_wave(keys, cur, oth, n, N, nb, &s_progress, s_sel);
 			} else if (tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
 			__syncthreads();
-			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += 256) oth[w] = (u32)s_bm[w]; __syncthreads(); }
+			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) oth[w] = (u32)s_bm[w]; __syncthreads(); }
 			}
 			u32 *t = cur; cur = oth; oth = t;
 			n = N; bits = nb;
@@ -1364,9 +1364,9 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 		const u32 batch = (T.m - i0 < thr - cnt) ? T.m - i0 : thr - cnt;
 		const u32 nmask = n - 1;
 		if (T.dbg & 2) { cnt += batch; i0 += batch; continue; }
-		for (u32 i = tid; i < n; i += 256) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
+		for (u32 i = tid; i < n; i += blockDim.x) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
 		__syncthreads();
-		for (u32 q = tid; q < batch; q += 256) {
+		for (u32 q = tid; q < batch; q += blockDim.x) {
 			u32 r = q + 1;
 			u32 slot = yk_h2b((u32)(rec_kc[T.rec_off + i0 + q] >> 10), bits);
 			for (;;) {
@@ -1379,7 +1379,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 			}
 		}
 		__syncthreads();
-		for (u32 w = tid; w < (n + 31) / 32; w += 256) {          /* one lane per bitmap word: no atomics on the bitmap */
+		for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) {          /* one lane per bitmap word: no atomics on the bitmap */
 			u32 bits = cur[w];
 			for (u32 b = 0; b < 32 && w * 32 + b < n; ++b) {
 				const u32 i = w * 32 + b;
@@ -1393,8 +1393,8 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 	}
 	__syncthreads();
 	/* publish: bitmap in the arena, unused slots normalised to YK_EMPTY */
-	if (cur != UA) for (u32 w = tid; w < (n + 31) / 32; w += 256) UA[w] = cur[w];
-	for (u32 i = tid; i < n; i += 256) if (!bm_get(cur, i)) keys[i] = YK_EMPTY;
+	if (cur != UA) for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) UA[w] = cur[w];
+	for (u32 i = tid; i < n; i += blockDim.x) if (!bm_get(cur, i)) keys[i] = YK_EMPTY;
 	if (tid == 0) { out_bits[blockIdx.x] = n ? bits : YK_NOCAP; out_count[blockIdx.x] = cnt; }
 }
 
@@ -1947,12 +1947,12 @@ void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const
 	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
 }
 
-void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
+void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
                       u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
                       u32 *out_bits, u32 *out_count, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(256), 0, st, tasks, old_keys, old_used, new_keys, new_used,
+	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(n_threads), 0, st, tasks, old_keys, old_used, new_keys, new_used,
 	                   scr_used, scr_owner, scr_par, rec_kc, rec_t, lastput, out_bits, out_count);
 }
 

@@ -106,7 +106,7 @@ void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_
                               u64 *rec_kc, u64 *rec_t, hipStream_t st);
 void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
-void yk_launch_replay(const ReplayTask *tasks, int n_tasks, const u64 *old_keys, const u32 *old_used,
+void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
                       u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
                       u32 *out_bits, u32 *out_count, hipStream_t st);
