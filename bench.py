@@ -138,24 +138,31 @@ def main():
         s_rec = torch.empty((n_bytes, 2), dtype=torch.int64, device=dev)
         h_bstart = (C.c_uint64 * (P + 1))()
 
-    def exchange():
+    def exchange(create_new):
         """partition this rank's k-mers by sub-table prefix once, then one all-to-all per pass moves
-        every record to the owner of its prefix (RCCL over xGMI)"""
+        every record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI)"""
         from yak_amd import shard
         n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
         if n < 0:
             raise RuntimeError("partition failed")
-        segs = shard.exchange_partitioned(s_rec[:n], list(h_bstart), P)
+        if create_new:
+            out = shard.exchange_partitioned(s_rec[:n], list(h_bstart), P)
+        else:
+            out = shard.exchange_hashes(s_rec[:n], list(h_bstart), P)
         torch.cuda.synchronize()
-        return segs
+        return out
 
     def one_pass(t, create_new):
         if not sharded:
             t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
-        segs = exchange()
+        segs = exchange(create_new)
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
+        if not create_new:
+            if L.yakamd_count_hashes_dev(t.h, segs.data_ptr(), segs.shape[0]) != 0:
+                raise RuntimeError("count_hashes")
+            segs = []
         for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job
             if rec.shape[0]:
                 ob = (C.c_uint64 * (P + 1))(*offs)

@@ -67,6 +67,9 @@ int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_byte
 int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart,
                                 uint64_t t0, uint64_t t_span);
 
+/* create_new = 0 pass on bare yak_hash64 values (any order): count the ones present in the table */
+int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n);
+
 /* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
 void *yakamd_dev_alloc(size_t bytes);
 void yakamd_dev_free(void *p);

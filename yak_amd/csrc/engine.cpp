@@ -657,6 +657,20 @@ extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64
 	return r;
 }
 
+extern "C" int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass || c->create_new) return fail("count_hashes needs an open create_new = 0 pass");
+	HIPCK(hipSetDevice(c->dev));
+	if (n <= 0) return 0;
+	EvTimer tm(c->st);
+	yk_launch_img_count_h((const u64*)d_hash_u64, n, img_view(c), c->st);
+	const double ms = tm.stop();
+	c->st_cur.n_instances += n;
+	c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+	return 0;
+}
+
 extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
                                       int pre, int plo, int phi, void *stream)
 {

@@ -531,6 +531,17 @@ void k_img_count(const Rec *__restrict__ rec, int64_t n, ImgView img)
 	}
 }
 
+/* same on bare hash values (pass 2 of the sharded path ships 8 bytes per instance) */
+__global__ __launch_bounds__(256)
+void k_img_count_h(const u64 *__restrict__ hash, int64_t n, ImgView img)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const int64_t hit = img_find(img, hash[i]);
+		if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
+	}
+}
+
 __global__ __launch_bounds__(256)
 void k_img_fold(ImgView img, u64 n_slots)                    /* htab.c:68-69,73-74: saturate at 1023 */
 {
@@ -1768,7 +1779,7 @@ void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32
 	__shared__ u32 s_GC[256];
 	__shared__ u32 s_misc[8];
 	LcTab T; T.GC = s_GC; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.cap = YK_LDS_C;
-	const u32 sb = blockIdx.x;
+	const u32 sb = ((u32)fp.plo << fp.s2_bits) + blockIdx.x;             /* only the sub-tables of this shard */
 	if (!lc_body<false>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
 		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[YKC_NOVF], 1ull)] = sb;
 }
@@ -1877,6 +1888,12 @@ void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st)
 	hipLaunchKernelGGL(k_img_count, dim3(grid_for((u64)n)), dim3(256), 0, st, rec, n, img);
 }
 
+void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_img_count_h, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, n, img);
+}
+
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st)
 {
 	if (n_slots) hipLaunchKernelGGL(k_img_fold, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots);
@@ -1979,7 +1996,8 @@ void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const Rec *re
                          u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
                          u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st)
 {
-	const unsigned n_sb = (unsigned)P << fp.s2_bits;
+	(void)P;
+	const unsigned n_sb = (unsigned)(fp.phi - fp.plo) << fp.s2_bits;
 	hipLaunchKernelGGL(k_lds_count, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
 	                   seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list);
 }

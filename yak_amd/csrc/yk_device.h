@@ -85,6 +85,7 @@ void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
 void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st);
+void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_lastput(const Rec *rec, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,

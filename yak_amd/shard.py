@@ -113,6 +113,17 @@ def segments(recv_counts, slice_bytes):
         off += n
 
 
+def exchange_hashes(send_rec, bstart, n_prefix):
+    """pass 2 (count existing only): ship just the 8-byte hash of every record to its owner; order and
+    grouping no longer matter.  Returns one int64 tensor of received hashes."""
+    world = dist.get_world_size()
+    per = n_prefix // world
+    send_counts = [int(bstart[(d + 1) * per] - bstart[d * per]) for d in range(world)]
+    h = send_rec[:, 0].contiguous()
+    recv_hash, _, _ = exchange(h, None, send_counts)
+    return recv_hash
+
+
 def exchange_partitioned(send_rec, bstart, n_prefix):
     """send_rec: int64 tensor [n, 2] of records grouped by sub-table prefix (ascending), `bstart` the
     n_prefix + 1 group offsets (yakamd_partition_dev).  Owners are contiguous prefix ranges, so the
