@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--bf-shift", type=int, default=37)
-    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
@@ -174,6 +174,7 @@ def main():
         t.h.contents.tot += n_ins
 
     wall = {}
+    last_stats = [None]
 
     def step(keep=False):
         def tick(name, t0):
@@ -197,6 +198,7 @@ def main():
             s2 = t.stats()
             t.shrink(2, 1023)
             tp = tick("shrink", tp)
+            last_stats[0] = t.stats()
         else:
             s2 = None
         tot = t.tot
@@ -253,15 +255,33 @@ def main():
 
     dbgc = (C.c_uint32 * 4)()
     L.yakamd_debug_counters(dbgc)
-    # roofline of the dominant kernel (HIP-event timed inside the library, per launch)
-    kern = [("k_acc_insert", s1, B_INSERT)]
+    # per-kernel view of the last step (HIP events on the engine's stream, inside the library); the
+    # dominant kernel is the one with the largest accumulated time.  Algorithmic bytes per unit
+    # (DESIGN.md section 4): partition sweeps 8 B/instance, insert/count 24 B/instance, pass-2 lookup
+    # 16 + 8 f_hit, layout replay 16 B per key placed.
+    n1, n2 = s1["n_instances"], (s2["n_instances"] if s2 else 0)
+    kern = [
+        {"kernel": "k_xpart (extract + level-1 partition, both passes)", "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),
+         "launches": 2 * (-(-n_bytes // (1 << 27))) * (2 if s2 else 1), "bytes": 8.0 * (n1 + n2)},
+        {"kernel": "k_part2 (level-2 partition)", "ms": s1["ms_part2"], "launches": 2, "bytes": 8.0 * n1},
+        {"kernel": "k_lds_count (insert + bloom gate)" if s1["ms_part2"] > 0 else "k_acc_insert", "ms": s1["ms_insert"],
+         "launches": max(1, s1["n_dominant_launches"]), "bytes": B_INSERT * n1},
+    ]
     if s2:
-        f_hit = 0.9
-        kern.append(("k_img_count", s2, B_LOOKUP + 8.0 * f_hit))
-    name, st, bpi = max(kern, key=lambda x: x[1]["ms_dominant_kernel"])
-    launches = max(1, st["n_dominant_launches"])
-    avg_ms = st["ms_dominant_kernel"] / launches
-    ach = bpi * st["n_instances"] / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        st_after = last_stats[0]
+        kern.append({"kernel": "k_img_count (pass 2 lookup)", "ms": s2["ms_insert"], "launches": max(1, s2["n_dominant_launches"]),
+                     "bytes": (B_LOOKUP + 8.0 * 0.9) * n2})
+        kern.append({"kernel": "k_replay (exact khashl layout: pass 1 + shrink)", "ms": s1["ms_replay"] + st_after["ms_shrink"],
+                     "launches": 2, "bytes": 16.0 * (s1["n_new_keys"] + tot_all / max(1, world))})
+    else:
+        kern.append({"kernel": "k_replay (exact khashl layout)", "ms": s1["ms_replay"], "launches": 1, "bytes": 16.0 * s1["n_new_keys"]})
+    for k_ in kern:
+        k_["avg_launch_ms"] = k_["ms"] / k_["launches"]
+        k_["achieved_GBs"] = k_["bytes"] / (k_["ms"] * 1e-3) / 1e9 if k_["ms"] > 0 else 0.0
+        k_["frac"] = k_["achieved_GBs"] / HBM_PEAK_GBS
+    dom = max(kern, key=lambda x: x["ms"])
+    name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
+    bpi, st = dom["bytes"] / max(1, n1), s1
     out = {
         "metric": "distinct k-mers counted/sec (k=31), yak count -b37 two-pass protocol, .yak bit-exact",
         "value": tot_all / (dt / a.steps), "unit": "distinct k-mers/s",
@@ -282,7 +302,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": avg_ms, "launches": launches,
-                     "algorithmic_bytes_per_instance": bpi, "instances_per_launch": st["n_instances"] / launches},
+                     "algorithmic_bytes_per_launch": dom["bytes"] / launches,
+                     "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
         "verify": verify,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }

@@ -99,6 +99,8 @@ typedef struct {
 	int64_t n_distinct_seen;        /* distinct k-mers observed by the pass (create_new only) */
 	int64_t n_new_keys;             /* keys that entered the table */
 	int64_t n_bloom_candidates;     /* keys that needed exact in-batch bloom resolution */
+	double ms_part2;                /* level-2 partition (part of ms_extract) */
+	double ms_shrink;               /* last yak_ch_shrink on this table: compaction + layout replay */
 } yakamd_stats_t;
 int yakamd_get_stats(yak_ch_t *h, yakamd_stats_t *st);
 

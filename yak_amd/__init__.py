@@ -47,7 +47,7 @@ class StatsT(C.Structure):                     # yakamd_stats_t
                 ("ms_total", C.c_double), ("ms_dominant_kernel", C.c_double),
                 ("n_dominant_launches", C.c_int64), ("n_instances", C.c_int64),
                 ("n_distinct_seen", C.c_int64), ("n_new_keys", C.c_int64),
-                ("n_bloom_candidates", C.c_int64)]
+                ("n_bloom_candidates", C.c_int64), ("ms_part2", C.c_double), ("ms_shrink", C.c_double)]
 
 
 _lib = None

@@ -815,7 +815,7 @@ static int fast_finish(yakamd_ctx *c)
 		EvTimer tm(c->st);
 		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
 		c->ms_part2 = tm.stop();
-		c->st_cur.ms_extract += c->ms_part2;
+		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 = c->ms_part2;
 	}
 	for (auto &k : c->kept) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
@@ -995,7 +995,9 @@ int yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot)
 	if (dmalloc(&d_kc, seg_off[P])) return -1;
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, d_segoff, d_kc, c->st);
+	EvTimer tm(c->st);
 	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
+	c->st_last.ms_shrink = tm.stop();
 	dfree(d_segcnt); dfree(d_segoff); dfree(d_kc);
 	if (r) return r;
 	*tot = c->img_keys_total;
