@@ -163,6 +163,7 @@ struct yakamd_ctx {
 
 	/* bloom */
 	u32 *d_bf; size_t bf_words;
+	bool bf_virgin;                    /* allocated but never written: logically all zero */
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
@@ -244,7 +245,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->k = k; c->pre = pre; c->P = 1 << pre; c->plo = 0; c->phi = c->P;
 	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
 	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
-	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0;
+	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false;
 	c->in_pass = false; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
@@ -272,7 +273,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	if (c->has_bloom) {
 		c->bf_words = (size_t)c->P << (c->nb - 5);
 		if (dmalloc(&c->d_bf, c->bf_words)) { yk_ctx_destroy(c); return 0; }
-		if (hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st) != hipSuccess) { yk_ctx_destroy(c); return 0; }
+		c->bf_virgin = true;               /* zero-filled lazily: the first counting pass writes every block anyway */
 		c->multi_bits = (int)env_i64("YAKAMD_MULTI_BITS", 30);
 		if (c->multi_bits < 10) c->multi_bits = 10;
 		if (dmalloc(&c->d_multi, (size_t)1 << (c->multi_bits - 5))) { yk_ctx_destroy(c); return 0; }
@@ -378,6 +379,8 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	return 0;
 }
 
+static int bloom_materialise(yakamd_ctx *c);
+
 struct EvTimer {
 	hipEvent_t a, b; hipStream_t st;
 	EvTimer(hipStream_t s) : st(s) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
@@ -471,7 +474,7 @@ static int new_reserve(yakamd_ctx *c, int64_t n)
 }
 
 /* records [0, n_rec) of d_rh/d_rt (times = t0 + d_rt[i], all within [batch_lo, batch_hi)) -> table */
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi)
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart)
 {
 	if (n_rec <= 0) return 0;
 	const ImgView img = img_view(c);
@@ -479,12 +482,22 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	if (batch_hi > c->t_end) c->t_end = batch_hi;
 	if (!c->create_new) {
 		EvTimer tm(c->st);
-		yk_launch_img_count(c->d_rec, n_rec, img, c->st);
+		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
+		 * exclusive-ownership counting, no global atomics */
+		size_t lds = 0;
+		if (d_bstart && c->nb_bits == c->pre && env_i64("YAKAMD_COUNT_LDS", 1) != 0) {
+			for (int p = c->plo; p < c->phi; ++p)
+				if (c->h_bits[p] != YK_NOCAP) lds = std::max(lds, yk_img_count_lds_bytes(1u << c->h_bits[p], c->h_count[p]));
+			if (lds > 150 * 1024) lds = 0;
+		}
+		if (!lds || yk_launch_img_count_lds(c->d_rec, d_bstart, img, c->plo, c->phi, lds, c->st) != 0)
+			yk_launch_img_count(c->d_rec, n_rec, img, c->st);
 		const double ms = tm.stop();
 		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
 		return 0;
 	}
 	const int img_nonempty = c->img_keys_total > 0;
+	if (c->bloom_mode && bloom_materialise(c)) return -1;
 	if (acc_reserve(c, (u64)n_rec) || new_reserve(c, n_rec)) return -1;
 	u64 h_cnt[YKC_N];
 	{
@@ -503,8 +516,18 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	return lastput_phase(c, n_rec, t0, batch_lo, batch_hi, img_nonempty);
 }
 
+/* give a never-written bloom array its zeros (paths that read-modify-write it in place) */
+static int bloom_materialise(yakamd_ctx *c)
+{
+	if (c->d_bf && c->bf_virgin) {
+		HIPCK(hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st));
+		c->bf_virgin = false;
+	}
+	return 0;
+}
+
 /* ---- fast path bookkeeping ---- */
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi);
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart = 0);
 
 /* leave the fast path: push every kept batch through the accumulator path, in stream order */
 static int fast_abandon(yakamd_ctx *c)
@@ -557,7 +580,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	if (c->k >= 64 || c->k < 1) return fail("k must be in [1, 63]");
 	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
 	HIPCK(hipSetDevice(c->dev));
-	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 27);
+	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 30);
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
 	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
 	if (rec_reserve(c, bmax) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;
@@ -576,7 +599,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 			c->st_cur.ms_extract += tm.stop();
 		}
 		if (c->fast) { if (fast_keep(c, n_rec)) return -1; if (t0 + (u64)end > c->t_end) c->t_end = t0 + (u64)end; continue; }
-		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end)) return -1;
+		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart)) return -1;
 	}
 	return 0;
 }
@@ -611,7 +634,7 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	if (c->fast) { if (t0 + t_span > c->t_end) c->t_end = t0 + t_span; return fast_keep(c, n_rec); }
-	return consume_records(c, (int64_t)n_rec, t0, t0, t0 + t_span);
+	return consume_records(c, (int64_t)n_rec, t0, t0, t0 + t_span, c->d_bstart);
 }
 
 extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart)
@@ -767,7 +790,7 @@ static int fast_finish(yakamd_ctx *c)
 	FastParams fp;
 	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
-	fp.dbg = (int)env_i64("YAKAMD_DBG", 0); fp.pad = 0;
+	fp.dbg = (int)env_i64("YAKAMD_DBG", 0);
 	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them */
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + 599) / 600) : 0;
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
@@ -778,6 +801,12 @@ static int fast_finish(yakamd_ctx *c)
 		if (s2 < c->nb - 9 - 20) s2 = c->nb - 9 - 20;        /* ... and at most 2^20 of them (sort-key packing) */
 	}
 	fp.s2_bits = s2;
+	fp.bf_virgin = 0;
+	if (c->bloom_mode) {
+		if (c->bf_virgin && c->nb - 9 - s2 <= 7 && c->plo == 0 && c->phi == P) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block */
+		else if (bloom_materialise(c)) return -1;
+		c->bf_virgin = false;
+	}
 	const u64 ch2 = std::max<u64>(YK_CH2, (u64)32 << s2);    /* keep >= 32 records per sub-bucket run */
 	/* chunk table: runs of one sub-table's records, grouped by sub-table */
 	std::vector<Chunk2> chunks;

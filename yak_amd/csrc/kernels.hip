@@ -531,6 +531,77 @@ void k_img_count(const Rec *__restrict__ rec, int64_t n, ImgView img)
 	}
 }
 
+/* K4 with exclusive ownership (records grouped by sub-table prefix): ONE workgroup counts all
+ * instances of one sub-table.  The sub-table's `used` bitmap and a per-word rank table live in LDS,
+ * so a hit is turned into the rank of its slot among the used slots and counted in a 16-bit LDS
+ * counter -- no global atomics; only the key compare reads HBM/L2.  The counters are flushed into
+ * the per-slot delta array with plain read-modify-writes (nobody else touches this sub-table). */
+__global__ __launch_bounds__(1024)
+void k_img_count_lds(const Rec *__restrict__ rec, const u64 *__restrict__ bstart, ImgView img, int plo)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ u32 s_wsum[16];
+	const u32 p = (u32)plo + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u32 bits = img.bits[p];
+	const u64 lo = bstart[p], hi = bstart[p + 1];
+	if (bits == YK_NOCAP || lo == hi) return;
+	const u32 cap = 1u << bits, nw = (cap + 31) / 32;
+	const u64 off = img.off[p];
+	u32 *s_bm = s_dyn, *s_rk = s_dyn + nw, *s_ct = s_dyn + 2 * nw;      /* bitmap | rank of each word's first slot | 16-bit counters */
+	/* bitmap + exclusive popcount scan (every thread owns a contiguous run of words) */
+	const u32 per = (nw + 1023) / 1024;
+	u32 mine = 0;
+	for (u32 j = 0; j < per; ++j) {
+		const u32 w = tid * per + j;
+		if (w < nw) { const u32 x = img.used[(off >> 5) + w]; s_bm[w] = x; mine += __popc(x); }
+	}
+	u32 incl = mine;
+	for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
+	if (lane == 63) s_wsum[wave] = incl;
+	__syncthreads();
+	u32 base = incl - mine;
+	for (u32 w2 = 0; w2 < wave; ++w2) base += s_wsum[w2];
+	u32 total = 0;
+	for (u32 w2 = 0; w2 < 16; ++w2) total += s_wsum[w2];
+	for (u32 j = 0; j < per; ++j) {
+		const u32 w = tid * per + j;
+		if (w < nw) { s_rk[w] = base; base += __popc(s_bm[w]); }
+	}
+	for (u32 i = tid; i < (total + 1) / 2; i += 1024) s_ct[i] = 0;
+	__syncthreads();
+	const u32 nmask = cap - 1;
+	for (u64 i = lo + tid; i < hi; i += 1024) {
+		const u64 kid = rec[i].x >> img.pre;
+		u32 s = yk_h2b((u32)kid, bits);
+		const u32 first = s;
+		for (;;) {
+			const u32 word = s_bm[s >> 5];
+			if (!(word >> (s & 31) & 1)) break;                           /* khashl get: stop at the first unused slot */
+			if (img.keys[off + s] >> 10 == kid) {
+				const u32 r = s_rk[s >> 5] + __popc(word & ((1u << (s & 31)) - 1));
+				const u32 sh = 16 * (r & 1);
+				if ((s_ct[r >> 1] >> sh & 0xffffu) < 4096u) atomicAdd(&s_ct[r >> 1], 1u << sh);   /* only min(count, 1023) matters */
+				break;
+			}
+			s = (s + 1) & nmask;
+			if (s == first) break;
+		}
+	}
+	__syncthreads();
+	for (u32 j = 0; j < per; ++j) {
+		const u32 w = tid * per + j;
+		if (w >= nw) break;
+		u32 x = s_bm[w], r = s_rk[w];
+		while (x) {
+			const u32 b = __ffs((int)x) - 1;
+			x &= x - 1;
+			const u32 c = s_ct[r >> 1] >> (16 * (r & 1)) & 0xffffu;
+			if (c) img.delta[off + w * 32 + b] += c;
+			++r;
+		}
+	}
+}
+
 /* same on bare hash values (pass 2 of the sharded path ships 8 bytes per instance) */
 __global__ __launch_bounds__(256)
 void k_img_count_h(const u64 *__restrict__ hash, int64_t n, ImgView img)
@@ -1562,14 +1633,21 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	const int tid = threadIdx.x;
 	const u32 p = sb >> fp.s2_bits;
 	const u64 lo = sbstart[sb], hi = sbstart[sb + 1];
-	if (lo == hi) return true;
+	if (lo == hi) {
+		if (!GLB && fp.bloom_mode && fp.bf_virgin) {                      /* nothing maps here: the owned blocks become zeros */
+			const int lb0 = fp.nb - 9 - fp.s2_bits;
+			u32 *g0 = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb0 + 9))) >> 5);
+			for (u32 i = threadIdx.x; i < (16u << lb0); i += 256) g0[i] = 0;
+		}
+		return true;
+	}
 	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_nsel = s_misc + 4, *s_base = s_misc + 5;
 	const int bb = fp.nb - 9, lb = bb - fp.s2_bits;              /* log2 bloom blocks owned by this sub-bucket */
 	const bool stage_bloom = !GLB && fp.bloom_mode && lb <= 7;
 	u32 *gw = 0;                                                   /* first word of the owned bloom range */
 	if (fp.bloom_mode) gw = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5);
 	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; T.TM[i] = 0; }
-	if (stage_bloom) { if (!(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = gw[i]; T.GC[tid] = 0; }
+	if (stage_bloom) { if (!(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = fp.bf_virgin ? 0u : gw[i]; T.GC[tid] = 0; }
 	if (tid < 8) s_misc[tid] = 0;
 	lc_sync<GLB>();
 
@@ -1600,7 +1678,10 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	}
 	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
 	lc_sync<GLB>();
-	if (!GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3)) return false;
+	if (!GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3)) {
+		if (stage_bloom && fp.bf_virgin) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = 0;   /* the fallback kernel expects real zeros */
+		return false;
+	}
 	if (fp.dbg & 16) return true;
 
 	/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key) */
@@ -1886,6 +1967,20 @@ void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st)
 {
 	if (n <= 0) return;
 	hipLaunchKernelGGL(k_img_count, dim3(grid_for((u64)n)), dim3(256), 0, st, rec, n, img);
+}
+
+/* LDS needed by k_img_count_lds for a sub-table of `cap` slots holding `count` keys */
+size_t yk_img_count_lds_bytes(u32 cap, u32 count) { return (size_t)((cap + 31) / 32) * 8 + (size_t)(count + 1) / 2 * 4 + 16; }
+
+int yk_launch_img_count_lds(const Rec *rec, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st)
+{
+	static bool attr = false;
+	if (!attr) {
+		if (hipFuncSetAttribute((const void*)k_img_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		attr = true;
+	}
+	hipLaunchKernelGGL(k_img_count_lds, dim3(phi - plo), dim3(1024), lds, st, rec, bstart, img, plo);
+	return 0;
 }
 
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st)

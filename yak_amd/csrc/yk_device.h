@@ -85,6 +85,8 @@ void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
 void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st);
+size_t yk_img_count_lds_bytes(u32 cap, u32 count);
+int yk_launch_img_count_lds(const Rec *rec, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
@@ -140,7 +142,7 @@ struct FastParams {
 	int bloom_mode, nb, n_hash;     /* nb = log2 bits per sub-table filter */
 	int img_nonempty;
 	int plo, phi;
-	int dbg, pad;                   /* timing ablations only (YAKAMD_DBG), results are wrong when non-zero */
+	int dbg, bf_virgin;             /* dbg: timing ablations only (YAKAMD_DBG); bf_virgin: filter never written (all zero) */
 	u64 t_pass0;
 };
 
