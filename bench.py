@@ -279,6 +279,17 @@ def main():
         k_["avg_launch_ms"] = k_["ms"] / k_["launches"]
         k_["achieved_GBs"] = k_["bytes"] / (k_["ms"] * 1e-3) / 1e9 if k_["ms"] > 0 else 0.0
         k_["frac"] = k_["achieved_GBs"] / HBM_PEAK_GBS
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (profiles/r01e_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+    except Exception:
+        pass
+    for k_ in kern:
+        key = k_["kernel"].split(" ")[0]
+        cand = [v for n_, v in pmc.items() if n_.startswith(key)] if a.reads == 10_000_000 and world == 1 else []
+        k_["traffic_bytes"] = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
     dom = max(kern, key=lambda x: x["ms"])
     name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
     bpi, st = dom["bytes"] / max(1, n1), s1
@@ -300,7 +311,9 @@ def main():
         "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
         "bloom_exact_resolutions": s1["n_bloom_candidates"],
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "frac": ach / HBM_PEAK_GBS,
+                     "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
+                     "traffic_source": "profiles/r01e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
