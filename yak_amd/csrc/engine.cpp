@@ -839,7 +839,7 @@ static int fast_finish(yakamd_ctx *c)
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
-	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));
+	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));   /* NOVF, NOVF2 */
 	{
 		EvTimer tm(c->st);
 		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
@@ -851,20 +851,32 @@ static int fast_finish(yakamd_ctx *c)
 	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
 	if (dmalloc(&kc[0], n_total) || dmalloc(&tt[0], n_total)) return -1;
 	u64 h_cnt[YKC_N];
+	u32 *d_ovf2 = 0, *d_ndist = 0;
+	if (dmalloc(&d_ovf2, n_sb) || dmalloc(&d_ndist, P)) return -1;
+	HIPCK(hipMemsetAsync(d_ndist, 0, P * 4, c->st));
 	{
 		EvTimer tm(c->st);
-		yk_launch_lds_count(fp, P, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
-		                    c->d_lastput, c->d_counters, d_ovf, c->st);
+		yk_launch_lds_count(0, fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		                    c->d_lastput, d_ndist, c->d_counters, 0, 0, d_ovf, c->st);
 		c->ms_lds = tm.stop();
 		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
 	}
 	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	if (h_cnt[YKC_NOVF]) {      /* sub-buckets with too many distinct k-mers for LDS: same algorithm on global scratch */
-		const u32 n_ovf = (u32)h_cnt[YKC_NOVF];
+	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] lds tier G: %.2f ms, %llu of %zu sub-buckets passed on\n", c->ms_lds, (unsigned long long)h_cnt[YKC_NOVF], n_sb);
+	if (h_cnt[YKC_NOVF]) {      /* crowded bloom blocks / un-staged range: the tier with sort arrays */
+		EvTimer tm(c->st);
+		yk_launch_lds_count(1, fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
+		                    c->d_lastput, d_ndist, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
+		c->st_cur.ms_insert += tm.stop();
+		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+	}
+	if (h_cnt[YKC_NOVF2]) {     /* too many distinct k-mers for LDS: same algorithm on global scratch */
+		const u32 n_ovf = (u32)h_cnt[YKC_NOVF2];
 		std::vector<u32> ovf(n_ovf);
 		std::vector<u64> sbs(n_sb + 1), off(n_ovf);
-		HIPCK(hipMemcpy(ovf.data(), d_ovf, n_ovf * 4, hipMemcpyDeviceToHost));
+		HIPCK(hipMemcpy(ovf.data(), d_ovf2, n_ovf * 4, hipMemcpyDeviceToHost));
 		HIPCK(hipMemcpy(sbs.data(), d_sbstart, (n_sb + 1) * 8, hipMemcpyDeviceToHost));
 		u64 words = 0;
 		for (u32 i = 0; i < n_ovf; ++i) {
@@ -877,13 +889,19 @@ static int fast_finish(yakamd_ctx *c)
 		HIPCK(hipMemcpyAsync(d_off, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
 		EvTimer tm(c->st);
 		yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
-		                        c->d_lastput, c->d_counters, d_ovf, n_ovf, d_off, d_scr, c->st);
+		                        c->d_lastput, d_ndist, d_ovf2, n_ovf, d_off, d_scr, c->st);
 		c->st_cur.ms_insert += tm.stop();
-		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 		HIPCK(hipStreamSynchronize(c->st));
 		dfree(d_scr); dfree(d_off);
 	}
-	c->st_cur.n_distinct_seen = (int64_t)h_cnt[YKC_NDIST];
+	{
+		std::vector<u32> nd(P);
+		HIPCK(hipMemcpy(nd.data(), d_ndist, P * 4, hipMemcpyDeviceToHost));
+		u64 tot_d = 0;
+		for (int p = 0; p < P; ++p) tot_d += nd[p];
+		c->st_cur.n_distinct_seen = (int64_t)tot_d;
+	}
+	dfree(d_ovf2); dfree(d_ndist);
 	dfree(d_r2); dfree(d_sbstart); dfree(d_ovf);
 	std::vector<u32> m(P);
 	HIPCK(hipMemcpy(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost));

@@ -1614,47 +1614,66 @@ void k_part2_scan(const u32 *chunk_first, const u64 *bbase, int s2_bits, u32 *ro
 #define LC_CMASK 0x000fffffu              /* occurrences, clamped; bits 29:20 = rank inside a bloom block */
 #define T32_INF  0xffffffffu
 #define LC_BLOOM_WORDS 2048               /* bloom range staged in LDS: up to 128 blocks of 512 bits */
+#define LC_GMAX 16                        /* keys per bloom block handled by the all-pairs gate */
 
-struct LcTab { u64 *K; u32 *T1, *T2, *CN, *TM; u64 *SO; u32 *SP; u32 *BL; u32 *GC; u32 cap; };
+/* three tiers of the same algorithm: LC_G = LDS tables, all-pairs bloom gate (35 KB of LDS, 4 WG/CU);
+ * LC_S = LDS tables + sort arrays for sub-buckets with crowded bloom blocks or an un-staged range;
+ * LC_X = tables in global scratch for sub-buckets whose distinct k-mers overflow the LDS table */
+enum { LC_G = 0, LC_S = 1, LC_X = 2 };
 
-template <bool GLB> __device__ __forceinline__ void lc_sync() { if (GLB) block_sync_global(); else __syncthreads(); }
+struct LcTab { u64 *K; u32 *T1, *T2, *CN, *TM; u64 *SO; u32 *SP; u32 *BL; u32 *GC; unsigned short *G; u32 cap; };
+
+template <int MODE> __device__ __forceinline__ void lc_sync() { if (MODE == LC_X) block_sync_global(); else __syncthreads(); }
 
 __device__ __forceinline__ u32 lc_home(u64 key, int pre, u32 cap) { return (u32)(((key >> pre) * 0x9E3779B97F4A7C15ull) >> 24) & (cap - 1); }
 
-/* body shared by the LDS kernel (GLB = false) and the global-scratch fallback for sub-buckets
- * whose distinct k-mers do not fit the LDS table (GLB = true).  Returns false on LDS overflow
- * (nothing has been modified at that point). */
-template <bool GLB>
+struct BfSeq { u32 h1, h2, nd; };
+__device__ __forceinline__ BfSeq lc_seq(u64 key, const FastParams &fp)       /* probe sequence inside the 512-bit block (bbf.c:28-33) */
+{
+	BfSeq q;
+	const u64 x = key >> fp.pre;
+	q.h1 = (u32)(x >> (fp.nb - 9)) & 511;
+	q.h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
+	if ((q.h2 & 31) == 0) q.h2 = (q.h2 + 1) & 511;
+	const u32 cyc = 512u >> (__ffs((int)q.h2) - 1);           /* the probes repeat after 512 / gcd(h2, 512) steps */
+	q.nd = (u32)fp.n_hash < cyc ? (u32)fp.n_hash : cyc;
+	return q;
+}
+
+/* Returns false when this tier cannot handle the sub-bucket (nothing observable has been modified). */
+template <int MODE>
 __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 *__restrict__ sbstart,
                         const Rec *__restrict__ rec, u32 *bloom32, const ImgView &img,
-                        const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
+                        const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p,
                         u32 *s_misc /* [8] in LDS */)
 {
+	constexpr bool GLB = MODE == LC_X;
 	const int tid = threadIdx.x;
 	const u32 p = sb >> fp.s2_bits;
 	const u64 lo = sbstart[sb], hi = sbstart[sb + 1];
-	if (lo == hi) {
-		if (!GLB && fp.bloom_mode && fp.bf_virgin) {                      /* nothing maps here: the owned blocks become zeros */
-			const int lb0 = fp.nb - 9 - fp.s2_bits;
-			u32 *g0 = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb0 + 9))) >> 5);
-			for (u32 i = threadIdx.x; i < (16u << lb0); i += 256) g0[i] = 0;
-		}
-		return true;
-	}
-	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_nsel = s_misc + 4, *s_base = s_misc + 5;
 	const int bb = fp.nb - 9, lb = bb - fp.s2_bits;              /* log2 bloom blocks owned by this sub-bucket */
 	const bool stage_bloom = !GLB && fp.bloom_mode && lb <= 7;
 	u32 *gw = 0;                                                   /* first word of the owned bloom range */
 	if (fp.bloom_mode) gw = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5);
+	if (lo == hi) {
+		if (stage_bloom && fp.bf_virgin) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = 0;   /* nothing maps here */
+		return true;
+	}
+	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_nsel = s_misc + 4, *s_base = s_misc + 5, *s_run = s_misc + 7;
+	const bool pre0 = lo + tid < hi, pre1 = lo + 256 + tid < hi, pre2 = lo + 512 + tid < hi;
+	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
+	if (pre0) r0 = rec[lo + tid];
+	if (pre1) r1 = rec[lo + 256 + tid];
+	if (pre2) r2 = rec[lo + 512 + tid];
 	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; T.TM[i] = 0; }
-	if (stage_bloom) { if (!(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = fp.bf_virgin ? 0u : gw[i]; T.GC[tid] = 0; }
+	if (stage_bloom) { for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = fp.bf_virgin ? 0u : gw[i]; T.GC[tid] = 0; }
 	if (tid < 8) s_misc[tid] = 0;
-	lc_sync<GLB>();
+	lc_sync<MODE>();
 
-	/* A: count; first / second / last occurrence times (same loser rule as k_acc_insert) */
+	/* A: count; first / second / last occurrence times (same loser rule as k_acc_insert).  The first
+	 * three records of every lane were requested before the table was initialised. */
 	u32 tmax = 0;
-	for (u64 i = lo + tid; i < hi; i += 256) {
-		const Rec rc = rec[i];
+	auto put = [&](const Rec rc) {
 		const u64 key = rc.x;
 		const u32 t = (u32)rc.y;
 		u32 s = lc_home(key, fp.pre, T.cap), n = 0;
@@ -1667,7 +1686,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 				if (cur == key) break;
 			}
 		}
-		if (n == T.cap) { *s_ovf = 1; continue; }
+		if (n == T.cap) { *s_ovf = 1; return; }
 		if ((T.CN[s] & LC_CMASK) < 0x80000u) atomicAdd(&T.CN[s], 1u);   /* only min(count, 1023) is ever used */
 		const u32 old = atomicMin(&T.T1[s], t);
 		if (fp.bloom_mode) {
@@ -1675,16 +1694,40 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			atomicMax(&T.TM[s], t);
 		}
 		tmax = t + 1 > tmax ? t + 1 : tmax;
-	}
+	};
+	if (pre0) put(r0);
+	if (pre1) put(r1);
+	if (pre2) put(r2);
+	for (u64 i = lo + 768 + tid; i < hi; i += 256) put(rec[i]);
 	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
-	lc_sync<GLB>();
-	if (!GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3)) {
-		if (stage_bloom && fp.bf_virgin) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = 0;   /* the fallback kernel expects real zeros */
-		return false;
-	}
+	lc_sync<MODE>();
+	bool give_up = !GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3);
 	if (fp.dbg & 16) return true;
 
-	/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key) */
+	/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key); done
+	 * after the last give-up point, see below */
+	bool grouped = false;
+	if (!give_up && fp.bloom_mode && !(fp.dbg & 32)) {
+		if (stage_bloom) {
+			/* group the new keys by 512-bit block with LDS counters (rank kept in CN[29:20]) */
+			const u64 lmask = (1ull << lb) - 1;
+			u32 *s_gc = T.GC;
+			for (u32 s = tid; s < T.cap; s += 256) {
+				if (T.K[s] == YK_EMPTY) continue;
+				const u32 r = atomicAdd(&s_gc[(T.K[s] >> fp.pre) & lmask], 1u);
+				T.CN[s] |= (r & 1023u) << 20;
+				atomicMax(s_ne, r + 1);
+			}
+			lc_sync<MODE>();
+			grouped = *s_ne <= LC_GMAX;
+		}
+		if (!grouped && MODE == LC_G) give_up = true;       /* crowded blocks / un-staged range: needs the sort arrays */
+	}
+	if (give_up) {
+		if (stage_bloom && fp.bf_virgin) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = 0;   /* the next tier expects real zeros */
+		return false;
+	}
+
 	if (fp.img_nonempty) {
 		for (u32 s = tid; s < T.cap; s += 256) {
 			if (T.K[s] == YK_EMPTY) continue;
@@ -1695,121 +1738,100 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 				T.CN[s] |= LC_EXIST;
 			}
 		}
-		lc_sync<GLB>();
+		lc_sync<MODE>();
 	}
 
-	/* C: the bloom gate, block by block, in stream order (bbf.c:25-42).  This workgroup is the
-	 * only one whose k-mers map to these 512-bit blocks: no atomics, LDS copy when it fits. */
+	/* C: the bloom gate (bbf.c:25-42 + htab.c:63-65).  This workgroup is the only one whose k-mers map
+	 * to these 512-bit blocks.  A key passes at its first occurrence iff each of its probe bits was
+	 * set before -- by the pre-existing filter or by a key of the same block seen earlier. */
 	if (fp.bloom_mode && !(fp.dbg & 32)) {
 		const u64 lmask = (1ull << lb) - 1;
-		u32 *bw = stage_bloom ? T.BL : gw;
-		bool grouped = false;
-		if (stage_bloom) {
-			/* few keys per 512-bit block: group them with LDS counters (rank kept in CN[29:20]),
-			 * then one lane per block applies its keys in increasing first-occurrence time */
+		if (grouped) {
+			/* all pairs inside a block, every key in parallel; then the bits are ORed in (order-free) */
 			u32 *s_gc = T.GC, *s_go = T.GC + 128;
-			unsigned short *G = (unsigned short*)T.SO;
+			if (tid < 64) {                                           /* exclusive scan of the 128 counters */
+				const u32 a0 = s_gc[2 * tid], b0 = s_gc[2 * tid + 1];
+				u32 v = a0 + b0;
+				for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(v, o); if (tid >= o) v += t; }
+				s_go[2 * tid] = v - a0 - b0; s_go[2 * tid + 1] = v - b0;
+			}
+			lc_sync<MODE>();
+			for (u32 s = tid; s < T.cap; s += 256)
+				if (T.K[s] != YK_EMPTY) T.G[s_go[(T.K[s] >> fp.pre) & lmask] + (T.CN[s] >> 20 & 1023u)] = (unsigned short)s;
+			lc_sync<MODE>();
+			/* one lane per 512-bit block applies the block's few new keys in increasing first-occurrence
+			 * time (repeated selection of the smallest time above the last one applied) */
+			for (u32 b = tid; b < (1u << lb); b += 256) {
+				const u32 g = s_gc[b], g0 = s_go[b];
+				u32 *w = T.BL + (b << 4);
+				u32 last = 0; bool first = true;
+				for (u32 it = 0; it < g; ++it) {
+					u32 best = T32_INF, bs = 0;
+					for (u32 e = 0; e < g; ++e) {
+						const u32 sy = T.G[g0 + e], t1 = T.T1[sy];
+						if ((first || t1 > last) && t1 < best && !(T.CN[sy] & LC_EXIST)) { best = t1; bs = sy; }
+					}
+					if (best == T32_INF) break;
+					first = false; last = best;
+					const BfSeq q = lc_seq(T.K[bs], fp);
+					u32 hits = 0;
+					for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) {
+						const u32 word = w[z >> 5], bit = 1u << (z & 31);
+						if (word & bit) ++hits; else w[z >> 5] = word | bit;
+					}
+					if (hits == q.nd) T.CN[bs] |= LC_FP;                    /* yak_bf_insert() == n_hash */
+				}
+			}
+			lc_sync<MODE>();
+		} else if (MODE != LC_G) {
+			/* sort the new keys by (block, first occurrence); one lane per block applies them in order */
+			if (tid == 0) *s_ne = 0;
+			lc_sync<MODE>();
 			for (u32 s = tid; s < T.cap; s += 256) {
 				if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
-				const u32 r = atomicAdd(&s_gc[(T.K[s] >> fp.pre) & lmask], 1u);
-				T.CN[s] |= (r & 1023u) << 20;
-				atomicMax(s_ne, r + 1);
+				const u64 blk_local = (T.K[s] >> fp.pre) & lmask;
+				const u32 j = atomicAdd(s_ne, 1u);
+				if (GLB) { T.SO[j] = blk_local << 32 | T.T1[s]; T.SP[j] = s; }
+				else T.SO[j] = blk_local << 43 | (u64)T.T1[s] << 11 | s;
 			}
-			lc_sync<GLB>();
-			grouped = *s_ne <= 16;
-			if (grouped) {
-				if (tid < 64) {                                       /* exclusive scan of the 128 counters */
-					const u32 a = s_gc[2 * tid], b = s_gc[2 * tid + 1];
-					u32 v = a + b;
-					for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(v, o); if (tid >= o) v += t; }
-					s_go[2 * tid] = v - a - b; s_go[2 * tid + 1] = v - b;
-				}
-				lc_sync<GLB>();
-				for (u32 s = tid; s < T.cap; s += 256) {
-					if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
-					G[s_go[(T.K[s] >> fp.pre) & lmask] + (T.CN[s] >> 20 & 1023u)] = (unsigned short)s;
-				}
-				lc_sync<GLB>();
-				for (u32 b = tid; b < (1u << lb); b += 256) {
-					const u32 g = s_gc[b], g0 = s_go[b];
-					u32 *w = bw + (b << 4);
-					u32 last = 0; bool first = true;
-					for (u32 it = 0; it < g; ++it) {
-						u32 best = T32_INF, bs = 0;                       /* smallest T1 above the last one applied */
-						for (u32 e = 0; e < g; ++e) {
-							const u32 s = G[g0 + e], t1 = T.T1[s];
-							if ((first || t1 > last) && t1 < best) { best = t1; bs = s; }
-						}
-						first = false; last = best;
-						const u64 x = T.K[bs] >> fp.pre;
-						const u32 h1 = (u32)(x >> bb) & 511;
-						u32 h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
-						if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
-						const u32 cyc = 512u / (h2 & (0u - h2));
-						const u32 nd = (u32)fp.n_hash < cyc ? (u32)fp.n_hash : cyc;
-						u32 hits = 0;
-						for (u32 q = 0, z = h1; q < nd; ++q, z = (z + h2) & 511) {
-							const u32 word = w[z >> 5], bit = 1u << (z & 31);
-							if (word & bit) ++hits; else w[z >> 5] = word | bit;
-						}
-						if (hits == nd) T.CN[bs] |= LC_FP;
-					}
-				}
-			}
-			lc_sync<GLB>();
-			if (tid == 0) *s_ne = 0;
-			lc_sync<GLB>();
-		}
-		if (!grouped) {
-		for (u32 s = tid; s < T.cap; s += 256) {
-			if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
-			const u64 blk_local = (T.K[s] >> fp.pre) & lmask;
-			const u32 j = atomicAdd(s_ne, 1u);
-			if (GLB) { T.SO[j] = blk_local << 32 | T.T1[s]; T.SP[j] = s; }
-			else T.SO[j] = blk_local << 43 | (u64)T.T1[s] << 11 | s;
-		}
-		lc_sync<GLB>();
-		const u32 ne = *s_ne;
-		u32 m = 1; while (m < ne) m <<= 1;
-		for (u32 i = ne + tid; i < m; i += 256) { T.SO[i] = ~0ull; if (GLB) T.SP[i] = 0; }
-		lc_sync<GLB>();
-		for (u32 k2 = 2; k2 <= m; k2 <<= 1)
-			for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-				for (u32 i = tid; i < m; i += 256) {
-					const u32 l = i ^ j;
-					if (l > i) {
-						const u64 a = T.SO[i], b = T.SO[l];
-						if ((a > b) == ((i & k2) == 0)) {
-							T.SO[i] = b; T.SO[l] = a;
-							if (GLB) { const u32 t = T.SP[i]; T.SP[i] = T.SP[l]; T.SP[l] = t; }
+			lc_sync<MODE>();
+			const u32 ne = *s_ne;
+			u32 m = 1; while (m < ne) m <<= 1;
+			for (u32 i = ne + tid; i < m; i += 256) { T.SO[i] = ~0ull; if (GLB) T.SP[i] = 0; }
+			lc_sync<MODE>();
+			for (u32 k2 = 2; k2 <= m; k2 <<= 1)
+				for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+					for (u32 i = tid; i < m; i += 256) {
+						const u32 l = i ^ j;
+						if (l > i) {
+							const u64 a0 = T.SO[i], b0 = T.SO[l];
+							if ((a0 > b0) == ((i & k2) == 0)) {
+								T.SO[i] = b0; T.SO[l] = a0;
+								if (GLB) { const u32 t = T.SP[i]; T.SP[i] = T.SP[l]; T.SP[l] = t; }
+							}
 						}
 					}
+					lc_sync<MODE>();
 				}
-				lc_sync<GLB>();
-			}
-		const int bsh = GLB ? 32 : 43;
-		for (u32 j0 = tid; j0 < ne; j0 += 256) {
-			const u64 blk_local = T.SO[j0] >> bsh;
-			if (j0 && (T.SO[j0 - 1] >> bsh) == blk_local) continue;      /* not the first key of its block */
-			u32 *w = bw + (blk_local << 4);
-			for (u32 j = j0; j < ne && (T.SO[j] >> bsh) == blk_local; ++j) {
-				const u32 s = GLB ? T.SP[j] : (u32)T.SO[j] & 2047u;
-				const u64 x = T.K[s] >> fp.pre;
-				const u32 h1 = (u32)(x >> bb) & 511;
-				u32 h2 = fp.nb < 64 ? (u32)(x >> fp.nb) & 511 : 0;
-				if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
-				const u32 cyc = 512u / (h2 & (0u - h2));
-				const u32 nd = (u32)fp.n_hash < cyc ? (u32)fp.n_hash : cyc;
-				u32 hits = 0;
-				for (u32 q = 0, z = h1; q < nd; ++q, z = (z + h2) & 511) {
-					const u32 word = w[z >> 5], bit = 1u << (z & 31);
-					if (word & bit) ++hits; else w[z >> 5] = word | bit;
+			const int bsh = GLB ? 32 : 43;
+			u32 *bw = stage_bloom ? T.BL : gw;
+			for (u32 j0 = tid; j0 < ne; j0 += 256) {
+				const u64 blk_local = T.SO[j0] >> bsh;
+				if (j0 && (T.SO[j0 - 1] >> bsh) == blk_local) continue;      /* not the first key of its block */
+				u32 *w = bw + (blk_local << 4);
+				for (u32 j = j0; j < ne && (T.SO[j] >> bsh) == blk_local; ++j) {
+					const u32 s = GLB ? T.SP[j] : (u32)T.SO[j] & 2047u;
+					const BfSeq q = lc_seq(T.K[s], fp);
+					u32 hits = 0;
+					for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) {
+						const u32 word = w[z >> 5], bit = 1u << (z & 31);
+						if (word & bit) ++hits; else w[z >> 5] = word | bit;
+					}
+					if (hits == q.nd) T.CN[s] |= LC_FP;
 				}
-				if (hits == nd) T.CN[s] |= LC_FP;                       /* yak_bf_insert() == n_hash */
 			}
+			lc_sync<MODE>();
 		}
-		}
-		lc_sync<GLB>();
 		if (stage_bloom && !(fp.dbg & 64)) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = T.BL[i];
 		/* D: last put-call = last instance that is not a rejected first occurrence (htab.c:63-65) */
 		u32 best = 0;
@@ -1819,55 +1841,63 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			if ((cn & (LC_EXIST | LC_FP)) || (cn & LC_CMASK) >= 2) best = T.TM[s] + 1 > best ? T.TM[s] + 1 : best;
 		}
 		if (best) atomicMax(s_lp, best);
-		lc_sync<GLB>();
+		lc_sync<MODE>();
 	}
 
-	/* E: keys entering the table -> (key<<10|count, insertion time): staged, then appended to the
-	 * sub-table's list with one reservation per workgroup and contiguous stores */
-	for (u32 s = tid; s < T.cap; s += 256) {
-		if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) continue;
-		u32 c = T.CN[s] & LC_CMASK, Tt;
-		if (!fp.bloom_mode || (T.CN[s] & LC_FP)) Tt = T.T1[s];
-		else if (T.T2[s] != T32_INF) { Tt = T.T2[s]; c -= 1; }
-		else continue;
+	/* E: keys entering the table -> (key<<10|count, insertion time), appended to the sub-table's list
+	 * with one reservation per workgroup */
+	auto selected = [&](u32 s, u64 *kc, u32 *Tt) {
+		if (T.K[s] == YK_EMPTY || (T.CN[s] & LC_EXIST)) return false;
+		u32 c = T.CN[s] & LC_CMASK;
+		if (!fp.bloom_mode || (T.CN[s] & LC_FP)) *Tt = T.T1[s];
+		else if (T.T2[s] != T32_INF) { *Tt = T.T2[s]; c -= 1; }
+		else return false;
 		if (c > 1023) c = 1023;
-		const u32 r = atomicAdd(s_nsel, 1u);
-		T.SO[r] = (T.K[s] >> fp.pre) << 10 | c;
-		T.TM[r] = Tt;             /* TM is free again: D is behind a barrier */
-	}
-	lc_sync<GLB>();
-	const u32 nsel = *s_nsel;
+		*kc = (T.K[s] >> fp.pre) << 10 | c;
+		return true;
+	};
+	u32 mine = 0;
+	for (u32 s = tid; s < T.cap; s += 256) { u64 kc; u32 Tt; mine += selected(s, &kc, &Tt); }
+	if (mine) atomicAdd(s_nsel, mine);
+	lc_sync<MODE>();
 	if (tid == 0) {
-		u64 b = nsel ? (u64)atomicAdd(&seg_cur[p], nsel) : 0;
+		const u32 nsel = *s_nsel;
+		const u64 b = nsel ? (u64)atomicAdd(&seg_cur[p], nsel) : 0;
 		s_base[0] = (u32)b; s_base[1] = (u32)(b >> 32);
 		if (*s_lp) atomicMax(&lastput[p], fp.t_pass0 + (u64)(*s_lp - 1) + 1);
-		atomicAdd(&counters[YKC_NDIST], (u64)*s_ndist);
+		atomicAdd(&ndist_p[p], *s_ndist);
 	}
 	__syncthreads();
 	const u64 base = seg_base[p] + ((u64)s_base[0] | (u64)s_base[1] << 32);
-	for (u32 r = tid; r < nsel; r += 256) { out_kc[base + r] = T.SO[r]; out_T[base + r] = fp.t_pass0 + T.TM[r]; }
+	for (u32 s = tid; s < T.cap; s += 256) {
+		u64 kc; u32 Tt;
+		if (selected(s, &kc, &Tt)) { const u32 r = atomicAdd(s_run, 1u); out_kc[base + r] = kc; out_T[base + r] = fp.t_pass0 + Tt; }
+	}
 	return true;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256)
 void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
-                 const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters, u32 *ovf_list)
+                 const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, u64 *counters,
+                 const u32 *in_list, u32 *ovf_list, int ovf_counter)
 {
 	__shared__ u64 s_K[YK_LDS_C];
-	__shared__ u64 s_SO[YK_LDS_C];
+	__shared__ u64 s_SO[MODE == LC_S ? YK_LDS_C : 1];
 	__shared__ u32 s_T1[YK_LDS_C], s_T2[YK_LDS_C], s_CN[YK_LDS_C], s_TM[YK_LDS_C];
 	__shared__ u32 s_BL[LC_BLOOM_WORDS];
 	__shared__ u32 s_GC[256];
+	__shared__ unsigned short s_G[YK_LDS_C];
 	__shared__ u32 s_misc[8];
-	LcTab T; T.GC = s_GC; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.cap = YK_LDS_C;
-	const u32 sb = ((u32)fp.plo << fp.s2_bits) + blockIdx.x;             /* only the sub-tables of this shard */
-	if (!lc_body<false>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc))
-		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[YKC_NOVF], 1ull)] = sb;
+	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.GC = s_GC; T.G = s_G; T.cap = YK_LDS_C;
+	const u32 sb = in_list ? in_list[blockIdx.x] : ((u32)fp.plo << fp.s2_bits) + blockIdx.x;   /* only the sub-tables of this shard */
+	if (!lc_body<MODE>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, s_misc))
+		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[ovf_counter], 1ull)] = sb;
 }
 
 __global__ __launch_bounds__(256)
 void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
-                     const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u64 *counters,
+                     const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p,
                      const u32 *ovf_list, const u64 *scr_off, u64 *scr)
 {
 	__shared__ u32 s_misc[8];
@@ -1875,10 +1905,10 @@ void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *blo
 	const u64 n = sbstart[sb + 1] - sbstart[sb];
 	u32 cap = 4096; while (cap < 2 * n) cap <<= 1;
 	u64 *base = scr + scr_off[blockIdx.x];                      /* 40 B per slot = 5 u64 */
-	LcTab T; T.cap = cap; T.BL = 0; T.GC = 0;
+	LcTab T; T.cap = cap; T.BL = 0; T.GC = 0; T.G = 0;
 	T.K = base; T.SO = base + cap;
 	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap; T.TM = T.SP + cap;
-	lc_body<true>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, counters, s_misc);
+	lc_body<LC_X>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, s_misc);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2087,23 +2117,28 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 	if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 }
 
-void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const Rec *rec,
+/* tier = LC_G over every sub-bucket of the shard (in_list == NULL), or LC_S over a list */
+void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
                          u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                         u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st)
+                         u64 *lastput, u32 *ndist_p, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st)
 {
-	(void)P;
-	const unsigned n_sb = (unsigned)(fp.phi - fp.plo) << fp.s2_bits;
-	hipLaunchKernelGGL(k_lds_count, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
-	                   seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list);
+	if (tier == 0) {
+		const unsigned n_sb = (unsigned)(fp.phi - fp.plo) << fp.s2_bits;
+		hipLaunchKernelGGL(k_lds_count<LC_G>, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
+		                   seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, counters, (const u32*)0, ovf_list, (int)YKC_NOVF);
+	} else if (n_list) {
+		hipLaunchKernelGGL(k_lds_count<LC_S>, dim3(n_list), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
+		                   seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, counters, in_list, ovf_list, (int)YKC_NOVF2);
+	}
 }
 
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                             u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u64 *lastput, u32 *ndist_p, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st)
 {
 	if (n_ovf) hipLaunchKernelGGL(k_lds_count_ovf, dim3(n_ovf), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
-	                              seg_base, seg_cur, out_kc, out_T, lastput, counters, ovf_list, scr_off, scr);
+	                              seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, ovf_list, scr_off, scr);
 }
 
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,

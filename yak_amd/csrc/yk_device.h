@@ -151,18 +151,18 @@ extern "C" {
 #endif
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
                      u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
-void yk_launch_lds_count(FastParams fp, int P, const u64 *sbstart, const Rec *rec,
+void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
                          u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                         u64 *lastput, u64 *counters, u32 *ovf_list, hipStream_t st);
+                         u64 *lastput, u32 *ndist_p, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st);
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                             u64 *lastput, u64 *counters, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u64 *lastput, u32 *ndist_p, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
 #ifdef __cplusplus
 }
 #endif
-enum { YKC_NOVF = 6, YKC_NDIST = 7 };
+enum { YKC_NOVF = 6, YKC_NOVF2 = 7 };
 
 #endif
