@@ -474,7 +474,17 @@ static int new_reserve(yakamd_ctx *c, int64_t n)
 }
 
 /* records [0, n_rec) of d_rh/d_rt (times = t0 + d_rt[i], all within [batch_lo, batch_hi)) -> table */
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart)
+/* LDS bytes of the exclusive-ownership pass-2 counter for the current table image (0: not eligible) */
+static size_t count_lds_bytes(yakamd_ctx *c)
+{
+	size_t lds = 0;
+	if (c->nb_bits != c->pre || env_i64("YAKAMD_COUNT_LDS", 1) == 0) return 0;
+	for (int p = c->plo; p < c->phi; ++p)
+		if (c->h_bits[p] != YK_NOCAP) lds = std::max(lds, yk_img_count_lds_bytes(1u << c->h_bits[p], c->h_count[p]));
+	return lds > 150 * 1024 ? 0 : lds;
+}
+
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart, int hash_only)
 {
 	if (n_rec <= 0) return 0;
 	const ImgView img = img_view(c);
@@ -484,14 +494,11 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		EvTimer tm(c->st);
 		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
 		 * exclusive-ownership counting, no global atomics */
-		size_t lds = 0;
-		if (d_bstart && c->nb_bits == c->pre && env_i64("YAKAMD_COUNT_LDS", 1) != 0) {
-			for (int p = c->plo; p < c->phi; ++p)
-				if (c->h_bits[p] != YK_NOCAP) lds = std::max(lds, yk_img_count_lds_bytes(1u << c->h_bits[p], c->h_count[p]));
-			if (lds > 150 * 1024) lds = 0;
+		const size_t lds = d_bstart ? count_lds_bytes(c) : 0;
+		if (!lds || yk_launch_img_count_lds(c->d_rec, hash_only, d_bstart, img, c->plo, c->phi, lds, c->st) != 0) {
+			if (hash_only) yk_launch_img_count_h((const u64*)c->d_rec, n_rec, img, c->st);
+			else yk_launch_img_count(c->d_rec, n_rec, img, c->st);
 		}
-		if (!lds || yk_launch_img_count_lds(c->d_rec, d_bstart, img, c->plo, c->phi, lds, c->st) != 0)
-			yk_launch_img_count(c->d_rec, n_rec, img, c->st);
 		const double ms = tm.stop();
 		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
 		return 0;
@@ -527,7 +534,7 @@ static int bloom_materialise(yakamd_ctx *c)
 }
 
 /* ---- fast path bookkeeping ---- */
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart = 0);
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart = 0, int hash_only = 0);
 
 /* leave the fast path: push every kept batch through the accumulator path, in stream order */
 static int fast_abandon(yakamd_ctx *c)
@@ -582,6 +589,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	HIPCK(hipSetDevice(c->dev));
 	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 30);
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
+	const int hash_only = !c->create_new;                  /* counting existing keys needs no stream positions */
 	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
 	if (rec_reserve(c, bmax) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;
 	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
@@ -594,12 +602,12 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 		{
 			EvTimer tm(c->st);
 			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
-			                c->d_rows, c->d_partial, c->d_bstart, out, c->st);
+			                c->d_rows, c->d_partial, c->d_bstart, out, hash_only, c->st);
 			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 			c->st_cur.ms_extract += tm.stop();
 		}
 		if (c->fast) { if (fast_keep(c, n_rec)) return -1; if (t0 + (u64)end > c->t_end) c->t_end = t0 + (u64)end; continue; }
-		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart)) return -1;
+		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart, hash_only)) return -1;
 	}
 	return 0;
 }
@@ -645,7 +653,7 @@ extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int
 	const int n_blk = yk_xpart_blocks(n_bytes);
 	u32 *d_rows = 0; u64 *d_partial = 0, *d_bstart = 0;
 	if (dmalloc(&d_rows, NB * (size_t)n_blk) || dmalloc(&d_partial, NB * yk_part_groups()) || dmalloc(&d_bstart, NB + 1)) return -1;
-	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_rec_out, 0);
+	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_rec_out, 0, 0);
 	const hipError_t e = hipMemcpy(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost);
 	dfree(d_rows); dfree(d_partial); dfree(d_bstart);
 	if (e != hipSuccess) { fail("partition: %s", hipGetErrorString(e)); return -1; }

@@ -263,7 +263,7 @@ __device__ __forceinline__ u32 bucket_of(u64 h, int pre, int nb_bits)
 	return nb_bits <= pre ? p >> (pre - nb_bits) : p;   /* nb_bits is clamped to pre by the host */
 }
 
-template <int MODE>   /* 0 = histogram, 1 = scatter */
+template <int MODE>   /* 0 = histogram, 1 = scatter {hash, position}, 2 = scatter hash only (count-existing passes) */
 __global__ __launch_bounds__(XT_THREADS)
 void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
              int nb_bits, u32 *rows, Rec *__restrict__ out)
@@ -288,7 +288,8 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 			ok = ok && (int)p >= plo && (int)p < phi;
 			if (ok) {
 				const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
-				if (MODE) out[d] = make_ulonglong2(h, (u64)(u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub));
+				if (MODE == 1) out[d] = make_ulonglong2(h, (u64)(u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub));
+				if (MODE == 2) ((u64*)out)[d] = h;
 			}
 		}
 		__syncthreads();
@@ -536,8 +537,9 @@ void k_img_count(const Rec *__restrict__ rec, int64_t n, ImgView img)
  * so a hit is turned into the rank of its slot among the used slots and counted in a 16-bit LDS
  * counter -- no global atomics; only the key compare reads HBM/L2.  The counters are flushed into
  * the per-slot delta array with plain read-modify-writes (nobody else touches this sub-table). */
+template <int W>   /* record width in u64 words: 2 = {hash, position}, 1 = hash only */
 __global__ __launch_bounds__(1024)
-void k_img_count_lds(const Rec *__restrict__ rec, const u64 *__restrict__ bstart, ImgView img, int plo)
+void k_img_count_lds(const u64 *__restrict__ rec, const u64 *__restrict__ bstart, ImgView img, int plo)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 	__shared__ u32 s_wsum[16];
@@ -571,7 +573,7 @@ void k_img_count_lds(const Rec *__restrict__ rec, const u64 *__restrict__ bstart
 	__syncthreads();
 	const u32 nmask = cap - 1;
 	for (u64 i = lo + tid; i < hi; i += 1024) {
-		const u64 kid = rec[i].x >> img.pre;
+		const u64 kid = rec[W * i] >> img.pre;
 		u32 s = yk_h2b((u32)kid, bits);
 		const u32 first = s;
 		for (;;) {
@@ -1936,14 +1938,15 @@ void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_
 
 /* partitioning extraction: returns through bstart[1 << nb_bits] (device) the record count */
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st)
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st)
 {
 	if (n <= pos0) return;
 	const int n_blk = (int)(((u64)(n - pos0) + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE));
 	const size_t lds = sizeof(u32) << nb_bits;
 	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
-	hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 }
 
 int yk_part_groups(void) { return PS_G; }
@@ -2002,14 +2005,16 @@ void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st)
 /* LDS needed by k_img_count_lds for a sub-table of `cap` slots holding `count` keys */
 size_t yk_img_count_lds_bytes(u32 cap, u32 count) { return (size_t)((cap + 31) / 32) * 8 + (size_t)(count + 1) / 2 * 4 + 16; }
 
-int yk_launch_img_count_lds(const Rec *rec, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st)
+int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st)
 {
 	static bool attr = false;
 	if (!attr) {
-		if (hipFuncSetAttribute((const void*)k_img_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		if (hipFuncSetAttribute((const void*)k_img_count_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess ||
+		    hipFuncSetAttribute((const void*)k_img_count_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); return -1; }
 		attr = true;
 	}
-	hipLaunchKernelGGL(k_img_count_lds, dim3(phi - plo), dim3(1024), lds, st, rec, bstart, img, plo);
+	if (hash_only) hipLaunchKernelGGL(k_img_count_lds<1>, dim3(phi - plo), dim3(1024), lds, st, (const u64*)rec, bstart, img, plo);
+	else hipLaunchKernelGGL(k_img_count_lds<2>, dim3(phi - plo), dim3(1024), lds, st, (const u64*)rec, bstart, img, plo);
 	return 0;
 }
 

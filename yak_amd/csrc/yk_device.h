@@ -72,7 +72,7 @@ extern "C" {
 void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
                        u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st);
 void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
                      int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
 int yk_xpart_blocks(int64_t n_pos);
@@ -86,7 +86,7 @@ void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
 void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st);
 size_t yk_img_count_lds_bytes(u32 cap, u32 count);
-int yk_launch_img_count_lds(const Rec *rec, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
+int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
