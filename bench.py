@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
 
     import torch
@@ -110,6 +111,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sharded = world > 1 or a.force_exchange
@@ -117,7 +119,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
     L = yak_amd.lib()
     if L.yakamd_device_count() < 1:
         raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")

@@ -38,16 +38,20 @@ def _a2a(recv, send, recv_counts, send_counts):
     for c in recv_counts:
         ro.append(ro[-1] + c)
     recv[ro[rank]:ro[rank + 1]] = send[so[rank]:so[rank + 1]]
-    reqs = []
+    reqs, landing = [], []
     for peer in range(world):
         if peer == rank:
             continue
         if send_counts[peer]:
-            reqs.append(dist.isend(send[so[peer]:so[peer + 1]].contiguous(), peer))
+            reqs.append(dist.isend(send[so[peer]:so[peer + 1]].cpu().contiguous(), peer))   # gloo moves host memory
         if recv_counts[peer]:
-            reqs.append(dist.irecv(recv[ro[peer]:ro[peer + 1]], peer))
+            buf = torch.empty(recv_counts[peer], dtype=recv.dtype)
+            reqs.append(dist.irecv(buf, peer))
+            landing.append((peer, buf))
     for r in reqs:
         r.wait()
+    for peer, buf in landing:
+        recv[ro[peer]:ro[peer + 1]] = buf.to(recv.device)
 
 
 MAX_MSG_ELEMS = 1 << 26      # per-peer message size cap (elements): RCCL/torch mis-handle messages of several GB
