@@ -815,7 +815,7 @@ static int fast_finish(yakamd_ctx *c)
 		else if (bloom_materialise(c)) return -1;
 		c->bf_virgin = false;
 	}
-	const u64 ch2 = std::max<u64>(YK_CH2, (u64)32 << s2);    /* keep >= 32 records per sub-bucket run */
+	const u64 ch2 = std::max<u64>((u64)env_i64("YAKAMD_CH2", YK_CH2), (u64)32 << s2);    /* keep >= 32 records per sub-bucket run */
 	/* chunk table: runs of one sub-table's records, grouped by sub-table */
 	std::vector<Chunk2> chunks;
 	std::vector<u32> chunk_first(P + 1, 0);
@@ -835,6 +835,7 @@ static int fast_finish(yakamd_ctx *c)
 			np += b - a;
 		}
 		bbase[p + 1] = bbase[p] + np;
+		if (chunks.size() > chunk_first[p]) chunks.back().spare = 1;   /* last chunk of its sub-table */
 	}
 	chunk_first[P] = (u32)chunks.size();
 	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;

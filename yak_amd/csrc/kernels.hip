@@ -1562,21 +1562,88 @@ __device__ __forceinline__ u32 sub_of(u64 h, const FastParams &fp)
 }
 
 template <int MODE>   /* 0 = histogram, 1 = scatter */
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
 	const Chunk2 c = chunks[blockIdx.x];
-	const int S2 = 1 << fp.s2_bits;
+	const int S2 = 1 << fp.s2_bits, NT = blockDim.x;
 	u32 *row = rows2 + (size_t)blockIdx.x * S2;
-	for (int j = threadIdx.x; j < S2; j += 256) s_bkt[j] = MODE ? row[j] : 0;
+	for (int j = threadIdx.x; j < S2; j += NT) s_bkt[j] = MODE ? row[j] : 0;
 	__syncthreads();
-	for (u32 i = threadIdx.x; i < c.n; i += 256) {
+	for (u32 i = threadIdx.x; i < c.n; i += NT) {
 		const Rec rc = c.rec[i];
 		const u32 d = atomicAdd(&s_bkt[sub_of(rc.x, fp)], 1u);
 		if (MODE) out[d] = make_ulonglong2(rc.x, (u64)((u32)rc.y + c.tbase));
 	}
-	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += 256) row[j] = s_bkt[j]; }
+	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += NT) row[j] = s_bkt[j]; }
+}
+
+/* The same scatter with software write combining.  A lone 16-byte store to a random address costs
+ * a whole memory transaction (stores are not merged behind the CU: ~21 G records/s measured, whatever
+ * the record size), while 4 neighbouring lanes storing one aligned 64-byte group run at ~110 G
+ * records/s.  So each sub-bucket gets a WC_CAP-record stack in LDS; a round places 1024 records,
+ * and every stack that holds enough to reach the next 64-byte boundary of its output run is
+ * flushed as one aligned group by 4 lanes.  The order of records inside a sub-bucket is free (the
+ * counting kernel orders by stream position itself), so a stack is all the bookkeeping needed.
+ * A record that finds its stack full (a burst of one sub-bucket inside a round) is stored alone,
+ * taken from the END of the workgroup's run of that sub-bucket, so the groups stay aligned. */
+#define WC_CAP 5
+#define WC_NT  1024
+__global__ __launch_bounds__(WC_NT)
+void k_part2_wc(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ rows2, const u64 *__restrict__ sbstart, Rec *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ u32 s_ntask[2];
+	const Chunk2 c = chunks[blockIdx.x];
+	const int S2 = 1 << fp.s2_bits;
+	const u32 tid = threadIdx.x;
+	u64 *s_h = (u64*)s_dyn;                              /* [S2 * WC_CAP] k-mer hash */
+	u32 *s_t = s_dyn + 2 * S2 * WC_CAP;                  /* [S2 * WC_CAP] stream position */
+	u32 *s_cnt = s_t + S2 * WC_CAP, *s_head = s_cnt + S2, *s_tail = s_head + S2, *s_task = s_tail + S2;   /* [S2] each; tasks [WC_NT] */
+	const u32 *row = rows2 + (size_t)blockIdx.x * S2;
+	for (int b = tid; b < S2; b += WC_NT) {
+		s_cnt[b] = 0; s_head[b] = row[b];
+		s_tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + b + 1] : row[S2 + b];   /* start of the next chunk's run = end of mine */
+	}
+	if (tid < 2) s_ntask[tid] = 0;
+	__syncthreads();
+	const u32 n_round = (c.n + WC_NT - 1) / WC_NT;
+	Rec nxt = tid < c.n ? c.rec[tid] : make_ulonglong2(0, 0);
+	for (u32 rd = 0; rd < n_round; ++rd) {
+		const u32 i = rd * WC_NT + tid, par = rd & 1;
+		const Rec rc = nxt;
+		if (i + WC_NT < c.n) nxt = c.rec[i + WC_NT];
+		if (i < c.n) {
+			const u32 b = sub_of(rc.x, fp), t = (u32)rc.y + c.tbase;
+			const u32 pos = atomicAdd(&s_cnt[b], 1u);
+			if (pos < WC_CAP) { s_h[b * WC_CAP + pos] = rc.x; s_t[b * WC_CAP + pos] = t; }
+			else out[atomicSub(&s_tail[b], 1u) - 1] = make_ulonglong2(rc.x, (u64)t);
+			if (pos == 3 - (s_head[b] & 3)) s_task[atomicAdd(&s_ntask[par], 1u)] = b;   /* this record completes the group */
+		}
+		__syncthreads();
+		const u32 nt = s_ntask[par];
+		for (u32 ti = tid >> 2; ti < nt; ti += WC_NT / 4) {
+			const u32 b = s_task[ti], q = tid & 3;
+			const u32 cn = s_cnt[b], stored = cn < WC_CAP ? cn : WC_CAP, h0 = s_head[b], need = 4 - (h0 & 3);
+			const u32 two = stored - need >= 4;                        /* need == 1 and a full stack: a second whole group */
+			const u32 flushed = need + 4 * two, rem = stored - flushed;
+			if (q < need) out[h0 + q] = make_ulonglong2(s_h[b * WC_CAP + q], (u64)s_t[b * WC_CAP + q]);
+			if (two) out[h0 + need + q] = make_ulonglong2(s_h[b * WC_CAP + need + q], (u64)s_t[b * WC_CAP + need + q]);
+			u64 mh = 0; u32 mt = 0;
+			if (q < rem) { mh = s_h[b * WC_CAP + flushed + q]; mt = s_t[b * WC_CAP + flushed + q]; }
+			__builtin_amdgcn_wave_barrier();
+			if (q < rem) { s_h[b * WC_CAP + q] = mh; s_t[b * WC_CAP + q] = mt; }
+			if (q == 0) { s_head[b] = h0 + flushed; s_cnt[b] = rem; }
+		}
+		if (tid == 0) s_ntask[par ^ 1] = 0;
+		__syncthreads();
+	}
+	/* what is left in the stacks: fewer records than reach the next boundary */
+	for (u32 ti = tid >> 2; ti < (u32)S2; ti += WC_NT / 4) {
+		const u32 q = tid & 3, cn = s_cnt[ti], stored = cn < WC_CAP ? cn : WC_CAP;
+		if (q < stored) out[s_head[ti] + q] = make_ulonglong2(s_h[ti * WC_CAP + q], (u64)s_t[ti * WC_CAP + q]);
+	}
 }
 
 /* one workgroup per level-1 bucket: rows2 counts -> absolute offsets; sbstart[bucket * S2 + s] */
@@ -1945,8 +2012,11 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 	const size_t lds = sizeof(u32) << nb_bits;
 	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
-	if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
-	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	static const size_t pad = getenv("YAKAMD_XP_PAD") ? (size_t)atoi(getenv("YAKAMD_XP_PAD")) << 10 : 0;
+	static bool attr = false;
+	if (!attr) { hipFuncSetAttribute((const void*)k_xpart<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); hipFuncSetAttribute((const void*)k_xpart<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr = true; }
+	if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds + pad, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds + pad, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 }
 
 int yk_part_groups(void) { return PS_G; }
@@ -2117,9 +2187,19 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
                      u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st)
 {
 	const size_t lds = sizeof(u32) << fp.s2_bits;
+	static const int nt = getenv("YAKAMD_P2_THREADS") ? atoi(getenv("YAKAMD_P2_THREADS")) : 1024;
+	static const size_t pad = getenv("YAKAMD_P2_PAD") ? (size_t)atoi(getenv("YAKAMD_P2_PAD")) << 10 : 0;
+	static bool attr = false;
+	if (!attr) { hipFuncSetAttribute((const void*)k_part2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr = true; }
 	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
-	if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
+	static const int wc = getenv("YAKAMD_P2_WC") ? atoi(getenv("YAKAMD_P2_WC")) : 1;
+	if (n_chunks && wc && fp.s2_bits <= 11 && fp.s2_bits >= 4) {
+		static bool attr2 = false;
+		if (!attr2) { hipFuncSetAttribute((const void*)k_part2_wc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr2 = true; }
+		const size_t S2 = (size_t)1 << fp.s2_bits, l2 = S2 * WC_CAP * 12 + S2 * 12 + WC_NT * 4;
+		hipLaunchKernelGGL(k_part2_wc, dim3(n_chunks), dim3(WC_NT), l2, st, chunks, fp, (const u32*)rows2, (const u64*)sbstart, out);
+	} else if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(nt), lds + pad, st, chunks, fp, rows2, out);
 }
 
 /* tier = LC_G over every sub-bucket of the shard (in_list == NULL), or LC_S over a list */
