@@ -102,7 +102,7 @@ __device__ __forceinline__ void xt_init(XtTile &S)
 __device__ __forceinline__ void xt_load(XtTile &S, const uint8_t *__restrict__ bases, int64_t tile0, int64_t n)
 {
 	const int64_t origin = tile0 - XT_HALO;
-	for (int w = threadIdx.x; w < (XT_TILE + XT_HALO) / 16; w += XT_THREADS) {
+	for (int w = threadIdx.x; w < (XT_TILE + XT_HALO) / 16; w += blockDim.x) {
 		const int64_t pos = origin + 16 * (int64_t)w;
 		u32 code = 0, val = 0;
 		if (pos >= 0 && pos + 16 <= n) {
@@ -156,9 +156,9 @@ __device__ u32 d_bad_hash;       /* k >= 32 only: a 64-bit hash equal to a table
 /* k in [32, 63] (reference count.c:45-60 + yak-priv.h:35-39): the four k-bit planes are the low / high
  * bits of the forward strand (first base most significant) and the complemented low / high bits of
  * the reverse strand; the strand is chosen on the high planes, the hash is the sum of two 64-bit mixes */
-__device__ __forceinline__ bool xt_kmer_long(const XtTile &S, int r, int k, int pre, int64_t tile0, int64_t n, u64 *h)
+__device__ __forceinline__ bool xt_kmer_long(const XtTile &S, int q, int k, int pre, int64_t tile0, int64_t n, u64 *h)
 {
-	const int e = XT_HALO + r * XT_THREADS + (int)threadIdx.x;
+	const int e = XT_HALO + q;                 /* q = position inside the tile of the k-mer's last base */
 	const int s = e - k + 1;
 	const int v0 = s >> 5, vo = s & 31;
 	const u64 va = (u64)S.valid[v0] | (u64)S.valid[v0 + 1] << 32, vb = S.valid[v0 + 2];
@@ -174,16 +174,16 @@ __device__ __forceinline__ bool xt_kmer_long(const XtTile &S, int r, int k, int 
 	const u64 x0 = __brevll(L) >> (64 - k), x1 = __brevll(H) >> (64 - k), x2 = ~L & kones, x3 = ~H & kones;
 	const u64 hv = x1 < x3 ? yk_hash64_64(x0) + yk_hash64_64(x1) : yk_hash64_64(x2) + yk_hash64_64(x3);
 	*h = hv;
-	const bool ok = (V & kones) == kones && tile0 + r * XT_THREADS + threadIdx.x < n;
+	const bool ok = (V & kones) == kones && tile0 + q < n;
 	if (ok && (hv >> pre) == (~0ull >> pre)) d_bad_hash = 1;       /* would collide with the EMPTY slot pattern */
 	return ok;
 }
 
-/* phase 2: hashed canonical k-mer ending at tile position r * XT_THREADS + tid; false if the window
- * holds a non-ACGT byte or lies beyond n */
-__device__ __forceinline__ bool xt_kmer(const XtTile &S, int r, int k, u64 mask, u64 kones, int64_t tile0, int64_t n, u64 *h)
+/* phase 2: hashed canonical k-mer ending at tile position q; false if the window holds a non-ACGT
+ * byte or lies beyond n */
+__device__ __forceinline__ bool xt_kmer(const XtTile &S, int q, int k, u64 mask, u64 kones, int64_t tile0, int64_t n, u64 *h)
 {
-	const int e = XT_HALO + r * XT_THREADS + (int)threadIdx.x;      /* LDS base index of the k-mer's last base */
+	const int e = XT_HALO + q;                                      /* LDS base index of the k-mer's last base */
 	const int s = e - k + 1;
 	const u64 V = ((u64)S.valid[s >> 5] | (u64)S.valid[(s >> 5) + 1] << 32) >> (s & 31);
 	const int w0 = s >> 4, o = 2 * (s & 15);
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool xt_kmer(const XtTile &S, int r, int k, u64 mask,
 	const u64 rv = ~W & mask;                          /* count.c:37: base j of the window at bits 2j, complemented */
 	const u64 fw = yk_rev2(W) >> (64 - 2 * k);         /* count.c:36: first base most significant */
 	*h = yk_hash64(fw < rv ? fw : rv, mask);
-	return (V & kones) == kones && tile0 + r * XT_THREADS + threadIdx.x < n;
+	return (V & kones) == kones && tile0 + q < n;
 }
 
 /* compacting extraction (no partition): used for the explicit extract entry point */
@@ -216,7 +216,8 @@ void k_extract(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64
 #pragma unroll
 	for (int r = 0; r < XT_ROUNDS; ++r) {
 		u64 h;
-		bool ok = k < 32 ? xt_kmer(S, r, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, r, k, pre, tile0, n, &h);
+		const int q = r * XT_THREADS + (int)threadIdx.x;
+			bool ok = k < 32 ? xt_kmer(S, q, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, q, k, pre, tile0, n, &h);
 		const u32 p = (u32)h & pmask;
 		ok = ok && (int)p >= plo && (int)p < phi;
 		hv[r] = h;
@@ -283,7 +284,8 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 #pragma unroll 4
 		for (int r = 0; r < XT_ROUNDS; ++r) {
 			u64 h;
-			bool ok = k < 32 ? xt_kmer(S, r, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, r, k, pre, tile0, n, &h);
+			const int q = r * XT_THREADS + (int)threadIdx.x;
+			bool ok = k < 32 ? xt_kmer(S, q, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, q, k, pre, tile0, n, &h);
 			const u32 p = (u32)h & pmask;
 			ok = ok && (int)p >= plo && (int)p < phi;
 			if (ok) {
@@ -295,6 +297,126 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 		__syncthreads();
 	}
 	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += XT_THREADS) row[j] = s_bkt[j]; }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Software write combining for the partition scatters.  A lone 8- or 16-byte store to a random
+ * address costs a whole memory transaction (stores are not merged behind the CU: ~21 G records/s
+ * measured on gfx950, whatever the record size), while GS neighbouring lanes storing one aligned
+ * 64-byte group run at 110-220 G records/s.  So each bucket gets a CAP-record stack in LDS; a round
+ * places one record per thread, and every stack that then holds enough to reach the next 64-byte
+ * boundary of its output run is flushed as one aligned group by GS lanes.  The order of records
+ * inside a bucket is free (later stages order by stream position themselves), so a stack is all
+ * the bookkeeping needed.  A record that finds its stack full (a burst of one bucket inside a
+ * round) is stored alone, taken from the END of the workgroup's run of that bucket, so the groups
+ * stay aligned.  HAS_T: {hash, position} records of 16 bytes (GS = 4), else bare hashes (GS = 8).
+ * ------------------------------------------------------------------------------------------ */
+struct WcView { u64 *h; u32 *t, *cnt, *head, *tail, *task, *ntask; };
+
+template <int GS, int CAP, bool HAS_T>
+__device__ __forceinline__ size_t wc_carve(WcView &w, u32 *lds, int NB, int NT)
+{
+	w.h = (u64*)lds;
+	u32 *p = lds + 2 * (size_t)NB * CAP;
+	w.t = p; if (HAS_T) p += (size_t)NB * CAP;
+	w.cnt = p; w.head = p + NB; w.tail = p + 2 * NB; w.task = p + 3 * NB; w.ntask = w.task + NT;
+	return 0;
+}
+template <int GS, int CAP, bool HAS_T> __host__ __device__ constexpr size_t wc_lds_bytes(int NB, int NT)
+{
+	return (size_t)NB * CAP * (HAS_T ? 12 : 8) + (size_t)NB * 12 + (size_t)NT * 4 + 16;
+}
+
+template <bool HAS_T> __device__ __forceinline__ void wc_store(void *out, u32 d, u64 h, u32 t)
+{
+	if (HAS_T) ((Rec*)out)[d] = make_ulonglong2(h, (u64)t); else ((u64*)out)[d] = h;
+}
+
+template <int GS, int CAP, bool HAS_T>
+__device__ __forceinline__ void wc_place(const WcView &w, u32 b, u64 h, u32 t, u32 par, void *out)
+{
+	const u32 pos = atomicAdd(&w.cnt[b], 1u);
+	if (pos < (u32)CAP) { w.h[b * CAP + pos] = h; if (HAS_T) w.t[b * CAP + pos] = t; }
+	else wc_store<HAS_T>(out, atomicSub(&w.tail[b], 1u) - 1, h, t);
+	if (pos == (u32)(GS - 1) - (w.head[b] & (GS - 1))) w.task[atomicAdd(&w.ntask[par], 1u)] = b;   /* this record completes a group */
+}
+
+/* between two barriers: flush every stack listed this round; GS lanes of one wave per stack */
+template <int GS, int CAP, bool HAS_T>
+__device__ __forceinline__ void wc_flush(const WcView &w, u32 par, void *out)
+{
+	const u32 nt = w.ntask[par], q = threadIdx.x & (GS - 1);
+	for (u32 ti = threadIdx.x / GS; ti < nt; ti += blockDim.x / GS) {
+		const u32 b = w.task[ti];
+		const u32 cn = w.cnt[b], stored = cn < (u32)CAP ? cn : (u32)CAP, h0 = w.head[b], need = GS - (h0 & (GS - 1));
+		const u32 two = stored - need >= (u32)GS;                 /* a second whole group behind the first */
+		const u32 flushed = need + GS * two, rem = stored - flushed;
+		if (q < need) wc_store<HAS_T>(out, h0 + q, w.h[b * CAP + q], HAS_T ? w.t[b * CAP + q] : 0);
+		if (two) wc_store<HAS_T>(out, h0 + need + q, w.h[b * CAP + need + q], HAS_T ? w.t[b * CAP + need + q] : 0);
+		u64 mh = 0; u32 mt = 0;
+		if (q < rem) { mh = w.h[b * CAP + flushed + q]; if (HAS_T) mt = w.t[b * CAP + flushed + q]; }
+		__builtin_amdgcn_wave_barrier();
+		if (q < rem) { w.h[b * CAP + q] = mh; if (HAS_T) w.t[b * CAP + q] = mt; }
+		if (q == 0) { w.head[b] = h0 + flushed; w.cnt[b] = rem; }
+	}
+	if (threadIdx.x == 0) w.ntask[par ^ 1] = 0;
+}
+
+/* after the last round: what is left in the stacks (fewer records than reach the next boundary) */
+template <int GS, int CAP, bool HAS_T>
+__device__ __forceinline__ void wc_drain(const WcView &w, int NB, void *out)
+{
+	const u32 q = threadIdx.x & (GS - 1);
+	for (u32 b = threadIdx.x / GS; b < (u32)NB; b += blockDim.x / GS) {
+		const u32 cn = w.cnt[b], stored = cn < (u32)CAP ? cn : (u32)CAP;
+		if (q < stored) wc_store<HAS_T>(out, w.head[b] + q, w.h[b * CAP + q], HAS_T ? w.t[b * CAP + q] : 0);
+	}
+}
+
+/* k_xpart's scatter with write combining: 1024 threads, one round = one quarter tile */
+#define XW_NT 1024
+#define XW_CAP_T 6          /* {hash, position}: groups of 4 */
+#define XW_CAP_H 11         /* hash only: groups of 8 */
+template <int MODE>   /* 1 = {hash, position}, 2 = hash only */
+__global__ __launch_bounds__(XW_NT)
+void k_xpart_wc(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
+                int nb_bits, const u32 *__restrict__ rows, const u64 *__restrict__ bstart, void *__restrict__ out)
+{
+	constexpr bool HAS_T = MODE == 1;
+	constexpr int GS = HAS_T ? 4 : 8, CAP = HAS_T ? XW_CAP_T : XW_CAP_H;
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ XtTile S;
+	const int NB = 1 << nb_bits, tid = threadIdx.x;
+	WcView w;
+	wc_carve<GS, CAP, HAS_T>(w, s_dyn, NB, XW_NT);
+	const u32 *row = rows + (size_t)blockIdx.x * NB;
+	const bool last = blockIdx.x + 1 == gridDim.x;
+	for (int b = tid; b < NB; b += XW_NT) {
+		w.cnt[b] = 0; w.head[b] = row[b];
+		w.tail[b] = last ? (u32)bstart[b + 1] : row[NB + b];      /* the next workgroup's run starts where mine ends */
+	}
+	if (tid < 2) w.ntask[tid] = 0;
+	xt_init(S);
+	const u64 mask = k < 32 ? (1ull << (2 * k)) - 1 : ~0ull, kones = (1ull << k) - 1;
+	const u32 pmask = (1u << pre) - 1;
+	u32 par = 0;
+	for (int t = 0; t < XP_T; ++t) {
+		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
+		if (tile0 >= n) break;
+		xt_load(S, bases, tile0, n);
+		for (int r = 0; r < XT_TILE / XW_NT; ++r, par ^= 1) {
+			const int q = r * XW_NT + tid;
+			u64 h;
+			bool ok = k < 32 ? xt_kmer(S, q, k, mask, kones, tile0, n, &h) : xt_kmer_long(S, q, k, pre, tile0, n, &h);
+			const u32 p = (u32)h & pmask;
+			ok = ok && (int)p >= plo && (int)p < phi;
+			if (ok) wc_place<GS, CAP, HAS_T>(w, bucket_of(h, pre, nb_bits), h, (u32)(tile0 + q - t_sub), par, out);
+			__syncthreads();
+			wc_flush<GS, CAP, HAS_T>(w, par, out);
+			__syncthreads();
+		}
+	}
+	wc_drain<GS, CAP, HAS_T>(w, NB, out);
 }
 
 #define RP_CHUNK 65536
@@ -1579,34 +1701,24 @@ void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, Rec *__restrict__ 
 	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += NT) row[j] = s_bkt[j]; }
 }
 
-/* The same scatter with software write combining.  A lone 16-byte store to a random address costs
- * a whole memory transaction (stores are not merged behind the CU: ~21 G records/s measured, whatever
- * the record size), while 4 neighbouring lanes storing one aligned 64-byte group run at ~110 G
- * records/s.  So each sub-bucket gets a WC_CAP-record stack in LDS; a round places 1024 records,
- * and every stack that holds enough to reach the next 64-byte boundary of its output run is
- * flushed as one aligned group by 4 lanes.  The order of records inside a sub-bucket is free (the
- * counting kernel orders by stream position itself), so a stack is all the bookkeeping needed.
- * A record that finds its stack full (a burst of one sub-bucket inside a round) is stored alone,
- * taken from the END of the workgroup's run of that sub-bucket, so the groups stay aligned. */
+/* the same scatter with write combining (see WcView above): 1024 records per round */
 #define WC_CAP 5
 #define WC_NT  1024
 __global__ __launch_bounds__(WC_NT)
 void k_part2_wc(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ rows2, const u64 *__restrict__ sbstart, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
-	__shared__ u32 s_ntask[2];
 	const Chunk2 c = chunks[blockIdx.x];
 	const int S2 = 1 << fp.s2_bits;
 	const u32 tid = threadIdx.x;
-	u64 *s_h = (u64*)s_dyn;                              /* [S2 * WC_CAP] k-mer hash */
-	u32 *s_t = s_dyn + 2 * S2 * WC_CAP;                  /* [S2 * WC_CAP] stream position */
-	u32 *s_cnt = s_t + S2 * WC_CAP, *s_head = s_cnt + S2, *s_tail = s_head + S2, *s_task = s_tail + S2;   /* [S2] each; tasks [WC_NT] */
+	WcView w;
+	wc_carve<4, WC_CAP, true>(w, s_dyn, S2, WC_NT);
 	const u32 *row = rows2 + (size_t)blockIdx.x * S2;
 	for (int b = tid; b < S2; b += WC_NT) {
-		s_cnt[b] = 0; s_head[b] = row[b];
-		s_tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + b + 1] : row[S2 + b];   /* start of the next chunk's run = end of mine */
+		w.cnt[b] = 0; w.head[b] = row[b];
+		w.tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + b + 1] : row[S2 + b];   /* start of the next chunk's run = end of mine */
 	}
-	if (tid < 2) s_ntask[tid] = 0;
+	if (tid < 2) w.ntask[tid] = 0;
 	__syncthreads();
 	const u32 n_round = (c.n + WC_NT - 1) / WC_NT;
 	Rec nxt = tid < c.n ? c.rec[tid] : make_ulonglong2(0, 0);
@@ -1614,36 +1726,12 @@ void k_part2_wc(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ row
 		const u32 i = rd * WC_NT + tid, par = rd & 1;
 		const Rec rc = nxt;
 		if (i + WC_NT < c.n) nxt = c.rec[i + WC_NT];
-		if (i < c.n) {
-			const u32 b = sub_of(rc.x, fp), t = (u32)rc.y + c.tbase;
-			const u32 pos = atomicAdd(&s_cnt[b], 1u);
-			if (pos < WC_CAP) { s_h[b * WC_CAP + pos] = rc.x; s_t[b * WC_CAP + pos] = t; }
-			else out[atomicSub(&s_tail[b], 1u) - 1] = make_ulonglong2(rc.x, (u64)t);
-			if (pos == 3 - (s_head[b] & 3)) s_task[atomicAdd(&s_ntask[par], 1u)] = b;   /* this record completes the group */
-		}
+		if (i < c.n) wc_place<4, WC_CAP, true>(w, sub_of(rc.x, fp), rc.x, (u32)rc.y + c.tbase, par, out);
 		__syncthreads();
-		const u32 nt = s_ntask[par];
-		for (u32 ti = tid >> 2; ti < nt; ti += WC_NT / 4) {
-			const u32 b = s_task[ti], q = tid & 3;
-			const u32 cn = s_cnt[b], stored = cn < WC_CAP ? cn : WC_CAP, h0 = s_head[b], need = 4 - (h0 & 3);
-			const u32 two = stored - need >= 4;                        /* need == 1 and a full stack: a second whole group */
-			const u32 flushed = need + 4 * two, rem = stored - flushed;
-			if (q < need) out[h0 + q] = make_ulonglong2(s_h[b * WC_CAP + q], (u64)s_t[b * WC_CAP + q]);
-			if (two) out[h0 + need + q] = make_ulonglong2(s_h[b * WC_CAP + need + q], (u64)s_t[b * WC_CAP + need + q]);
-			u64 mh = 0; u32 mt = 0;
-			if (q < rem) { mh = s_h[b * WC_CAP + flushed + q]; mt = s_t[b * WC_CAP + flushed + q]; }
-			__builtin_amdgcn_wave_barrier();
-			if (q < rem) { s_h[b * WC_CAP + q] = mh; s_t[b * WC_CAP + q] = mt; }
-			if (q == 0) { s_head[b] = h0 + flushed; s_cnt[b] = rem; }
-		}
-		if (tid == 0) s_ntask[par ^ 1] = 0;
+		wc_flush<4, WC_CAP, true>(w, par, out);
 		__syncthreads();
 	}
-	/* what is left in the stacks: fewer records than reach the next boundary */
-	for (u32 ti = tid >> 2; ti < (u32)S2; ti += WC_NT / 4) {
-		const u32 q = tid & 3, cn = s_cnt[ti], stored = cn < WC_CAP ? cn : WC_CAP;
-		if (q < stored) out[s_head[ti] + q] = make_ulonglong2(s_h[ti * WC_CAP + q], (u64)s_t[ti * WC_CAP + q]);
-	}
+	wc_drain<4, WC_CAP, true>(w, S2, out);
 }
 
 /* one workgroup per level-1 bucket: rows2 counts -> absolute offsets; sbstart[bucket * S2 + s] */
@@ -2012,11 +2100,21 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 	const size_t lds = sizeof(u32) << nb_bits;
 	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
-	static const size_t pad = getenv("YAKAMD_XP_PAD") ? (size_t)atoi(getenv("YAKAMD_XP_PAD")) << 10 : 0;
+	static const int wc = getenv("YAKAMD_XP_WC") ? atoi(getenv("YAKAMD_XP_WC")) : 3;   /* bit 0: {hash, position} scatter, bit 1: hash-only scatter */
 	static bool attr = false;
-	if (!attr) { hipFuncSetAttribute((const void*)k_xpart<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); hipFuncSetAttribute((const void*)k_xpart<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr = true; }
-	if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds + pad, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
-	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds + pad, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	if (!attr) {
+		hipFuncSetAttribute((const void*)k_xpart_wc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+		hipFuncSetAttribute((const void*)k_xpart_wc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+		attr = true;
+	}
+	if (nb_bits <= 10 && (wc >> (hash_only ? 1 : 0) & 1)) {
+		if (hash_only) hipLaunchKernelGGL(k_xpart_wc<2>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<8, XW_CAP_H, false>(1 << nb_bits, XW_NT)), st,
+		                                  bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
+		else hipLaunchKernelGGL(k_xpart_wc<1>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<4, XW_CAP_T, true>(1 << nb_bits, XW_NT)), st,
+		                        bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
+	}
+	else if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 }
 
 int yk_part_groups(void) { return PS_G; }
@@ -2188,7 +2286,6 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 {
 	const size_t lds = sizeof(u32) << fp.s2_bits;
 	static const int nt = getenv("YAKAMD_P2_THREADS") ? atoi(getenv("YAKAMD_P2_THREADS")) : 1024;
-	static const size_t pad = getenv("YAKAMD_P2_PAD") ? (size_t)atoi(getenv("YAKAMD_P2_PAD")) << 10 : 0;
 	static bool attr = false;
 	if (!attr) { hipFuncSetAttribute((const void*)k_part2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr = true; }
 	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
@@ -2197,9 +2294,9 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 	if (n_chunks && wc && fp.s2_bits <= 11 && fp.s2_bits >= 4) {
 		static bool attr2 = false;
 		if (!attr2) { hipFuncSetAttribute((const void*)k_part2_wc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr2 = true; }
-		const size_t S2 = (size_t)1 << fp.s2_bits, l2 = S2 * WC_CAP * 12 + S2 * 12 + WC_NT * 4;
+		const size_t l2 = wc_lds_bytes<4, WC_CAP, true>(1 << fp.s2_bits, WC_NT);
 		hipLaunchKernelGGL(k_part2_wc, dim3(n_chunks), dim3(WC_NT), l2, st, chunks, fp, (const u32*)rows2, (const u64*)sbstart, out);
-	} else if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(nt), lds + pad, st, chunks, fp, rows2, out);
+	} else if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(nt), lds, st, chunks, fp, rows2, out);
 }
 
 /* tier = LC_G over every sub-bucket of the shard (in_list == NULL), or LC_S over a list */
