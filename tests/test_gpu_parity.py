@@ -231,8 +231,11 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
 
 
 @pytest.mark.parametrize("env", [dict(YAKAMD_FAST="0"), dict(YAKAMD_S2_BITS="0"), dict(YAKAMD_FAST_BUDGET="100000"),
-                                 dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6")],
-                         ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general"])
+                                 dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6"),
+                                 dict(YAKAMD_S2_BITS="6"), dict(YAKAMD_S2_BITS="11", YAKAMD_CH2="4096"),
+                                 dict(YAKAMD_XP_WC="0", YAKAMD_P2_WC="0", YAKAMD_S2_BITS="6")],
+                         ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
+                              "write_combined_level2", "write_combined_level2_wide", "plain_scatters"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""
@@ -242,4 +245,24 @@ def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     for opt in (dict(k=31), dict(k=31, bf_shift=22), dict(k=31, bf_shift=28), dict(k=21, bf_shift=20)):
         got, tot = ya.count_protocol_host(img, **opt)
         want, wtot = oracle.count_protocol_mem(img, **opt)
+        assert (got == want, tot) == (True, wtot), opt
+
+
+@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_S2_BITS="5"), dict(YAKAMD_S2_BITS="8", YAKAMD_BATCH="65536")], ids=["auto", "s2_5", "s2_8_multibatch"])
+def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
+    """homopolymer and short-period reads put thousands of consecutive k-mers into ONE partition
+    bucket: the write-combining stacks overflow and the single-record path at the end of each run
+    is taken; mixed with ordinary reads so the aligned groups and the singles share runs"""
+    import random
+    rnd = random.Random(5)
+    parts = []
+    for i in range(400):
+        parts.append(rnd.choice([b"A" * 150, b"T" * 150, b"AC" * 75, b"ACG" * 50, b"AAAAC" * 30, b"G" * 149 + b"N"]))
+    img = synth(6000, g=40000, s=33)
+    mixed = img[:len(img) // 2] + b"N" + b"N".join(parts) + b"N" + img[len(img) // 2:] + b"N" + b"N".join(parts[:50])
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for opt in (dict(k=31), dict(k=31, bf_shift=28), dict(k=15, bf_shift=27), dict(k=33)):
+        got, tot = ya.count_protocol_host(mixed, **opt)
+        want, wtot = oracle.count_protocol_mem(mixed, **opt)
         assert (got == want, tot) == (True, wtot), opt
