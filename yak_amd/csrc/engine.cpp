@@ -770,8 +770,21 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
 	/* few, large sub-tables (a shard of a multi-GPU job): more lanes per sub-table */
 	const int n_active = c->phi - c->plo;
-	const int n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256);
-	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, c->st);
+	/* owner ranks of the placement stages in LDS: 32-bit up to lds_words slots, 16-bit up to twice that */
+	u32 cap_top = 0;
+	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
+	u32 lds_words = env_i64("YAKAMD_REPLAY_LDS", 1) ? std::min<u32>(cap_top, 32768) : 0;
+	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
+	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
+	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
+	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, lds_words, c->st);
+	if (env_i64("YAKAMD_DBG", 0) & 32) {
+		HIPCK(hipStreamSynchronize(c->st));
+		u64 pr[8]; yk_replay_prof(pr);
+		fprintf(stderr, "[yak_amd] replay block 0 (100 MHz ticks): double<32K %llu, double>=32K %llu, place<32K %llu, place>=32K %llu, publish %llu | par doubling: setup+base %llu, rounds %llu, verify+commit %llu\n",
+		        (unsigned long long)pr[0], (unsigned long long)pr[1], (unsigned long long)pr[2], (unsigned long long)pr[3], (unsigned long long)pr[4],
+		        (unsigned long long)pr[5], (unsigned long long)pr[6], (unsigned long long)pr[7]);
+	}
 	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));

@@ -1124,7 +1124,7 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
  *   * growth happens at the next put-call once count >= 0.75 capacity (khashl.h:202), including a
  *     trailing put-call on an existing key (lastput vs. time of the last new key).
  * ------------------------------------------------------------------------------------------ */
-#define RP_PAR_MIN  8192                                 /* doublings from this size on try the exact parallel routine */
+#define RP_PAR_MIN  2048                                 /* doublings from this size on try the exact parallel routine */
 #define RP_LDS_WORDS 4096                                 /* doublings up to 131072 slots keep their bitmaps in LDS */
 __device__ __forceinline__ bool bm_get(const u32 *u, u32 i) { return u[i >> 5] >> (i & 31) & 1; }
 
@@ -1346,6 +1346,8 @@ __device__ void replay_prefetch(const u64 *keys, u32 n, u32 nbits_new, volatile 
  * the serial routine (nothing has been modified until the commit).
  * ------------------------------------------------------------------------------------------ */
 __device__ u32 d_par_ok, d_par_fail;      /* doublings done by the parallel routine / sent back to the serial one */
+__device__ u64 d_rp_prof[8];              /* debug (dbg & 32): wall-clock ticks of block 0 per phase */
+#define RP_TICK(slot) if ((T.dbg & 32) && blockIdx.x == 0 && tid == 0) { const u64 now_ = wall_clock64(); d_rp_prof[slot] += now_ - tick_; tick_ = now_; }
 #define PD_EMPTY  0xffffffffffffffffull
 #define PD_FINAL  0x8000000000000000ull
 #define PD_PACK(c, d, s) ((u64)(c) << 40 | (u64)(d) << 24 | (u64)(s))
@@ -1359,8 +1361,11 @@ __device__ u32 d_par_ok, d_par_fail;      /* doublings done by the parallel rout
 __device__ __forceinline__ void pd_sync() { __syncthreads(); }
 
 __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u32 N, u32 nb_new,
-                                  u64 *OWN, u64 *SIG, u64 *TMP, u32 *s_par /* LDS [8] */)
+                                  u64 *OWN, u64 *SIG, u64 *TMP, u32 *s_par /* LDS [8] */, u64 *lds, size_t lds_bytes,
+                                  u64 *xtra /* global, N / 2 entries */, bool prof)
 {
+	u64 tk_ = wall_clock64();
+#define PD_TICK(slot) if (prof && threadIdx.x == 0) { const u64 now_ = wall_clock64(); d_rp_prof[slot] += now_ - tk_; tk_ = now_; }
 	const u32 tid = threadIdx.x, Nmask = N - 1, nmask = n - 1;
 	u32 *s_fail = s_par, *s_d1 = s_par + 1, *s_cnt = s_par + 2;
 	if (tid < 8) s_par[tid] = 0;
@@ -1377,46 +1382,62 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	pd_sync();
 	const u32 D1 = *s_d1, n_used = *s_cnt;
 	const u32 F0 = 5 * D1 + 16, B0 = F0 + 2 * D1 + 4;               /* final after the base phase / simulated by it */
-	if (B0 * 4 > n || n > (1u << 23)) return false;                        /* too clustered / too large: serial */
+	if (B0 * 4 > n || n > (1u << 23)) { if (tid == 0) s_par[7] = 1; return false; }   /* too clustered / too large: serial */
 	/* 1. the literal rule for scan positions below B0; a chain is followed only while it stays below
 	 * B0 (what it kicks further up lands beyond anything the first F0 slots can reach, and gets its
-	 * sigma from the lander rule later); only slots < F0 are kept, the rest is margin */
-	if (tid == 0) {
-		for (u32 j = 0; j < B0; ++j) {
-			if (!bm_get(cur, j) || SIG[j] != PD_EMPTY) continue;
-			u32 s = j, d = 0;
-			for (;;) {
-				const u64 me = PD_PACK(j, d, s);
-				SIG[s] = me | PD_FINAL;
-				u32 i = yk_h2b((u32)(TMP[s] >> 10), nb_new);
-				while (OWN[i] != PD_EMPTY) i = (i + 1) & Nmask;
-				OWN[i] = me;
-				if (i < B0 && bm_get(cur, i) && SIG[i] == PD_EMPTY) { s = i; ++d; } else break;
+	 * sigma from the lander rule later); only slots < F0 are kept, the rest is margin.  One lane does
+	 * it, on LDS copies of the few hundred entries involved (the chain is a string of dependent
+	 * accesses: ~10x faster than on the global arrays). */
+	{
+		const u32 WA = 2 * B0 + 4 * D1 + 16, WB = 4 * D1 + 16;           /* landings: [0, WA) and, wrapped, [N - WB, N) */
+		if (WA + WB > N) { if (tid == 0) s_par[7] = 2; return false; }
+		const bool in_lds = (size_t)(2 * B0 + WA + WB) * 8 <= lds_bytes;      /* else the same walk on global scratch */
+		if (!in_lds && 2 * B0 + WA + WB > N / 2) { if (tid == 0) s_par[7] = 2; return false; }
+		u64 *w_tmp, *w_sig, *w_own;
+		if (in_lds) { w_tmp = lds; w_sig = lds + B0; w_own = lds + 2 * B0; }
+		else { w_tmp = xtra; w_sig = xtra + B0; w_own = xtra + 2 * B0; }
+		for (u32 j = tid; j < B0; j += blockDim.x) { w_tmp[j] = bm_get(cur, j) ? TMP[j] : PD_EMPTY; w_sig[j] = PD_EMPTY; }
+		for (u32 i = tid; i < WA + WB; i += blockDim.x) w_own[i] = PD_EMPTY;
+		pd_sync();
+		if (tid == 0) {
+			bool lost = false;
+			for (u32 j = 0; j < B0 && !lost; ++j) {
+				if (w_tmp[j] == PD_EMPTY || w_sig[j] != PD_EMPTY) continue;
+				u32 s = j, d = 0;
+				for (;;) {
+					const u64 me = PD_PACK(j, d, s);
+					w_sig[s] = me | PD_FINAL;
+					u32 i = yk_h2b((u32)(w_tmp[s] >> 10), nb_new);
+					for (;;) {
+						const u32 li = i < WA ? i : i >= N - WB ? WA + (i - (N - WB)) : 0xffffffffu;
+						if (li == 0xffffffffu) { lost = true; break; }
+						if (w_own[li] == PD_EMPTY) { w_own[li] = me; break; }
+						i = (i + 1) & Nmask;
+					}
+					if (lost) break;
+					if (i < B0 && w_tmp[i] != PD_EMPTY && w_sig[i] == PD_EMPTY) { s = i; ++d; } else break;
+				}
 			}
+			if (lost) { *s_fail = 1; s_par[7] = 3; }
+		}
+		pd_sync();
+		if (*s_fail) return false;
+		/* keep what concerns old slots < F0 */
+		for (u32 j = tid; j < F0; j += blockDim.x) SIG[j] = w_sig[j];
+		for (u32 i = tid; i < WA + WB; i += blockDim.x) {
+			const u64 o = w_own[i];
+			if (o != PD_EMPTY && PD_S(o) < F0) OWN[i < WA ? i : N - WB + (i - WA)] = o;
 		}
 	}
 	pd_sync();
-	{
-		const u32 hi0 = 2 * B0 + 4 * D1 + 16, hi = hi0 < N ? hi0 : N;
-		for (u32 i = tid; i < hi; i += blockDim.x) {
-			const u64 o = OWN[i];
-			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
-		}
-		for (u32 i = N - (4 * D1 + 16) + tid; i < N; i += blockDim.x) {             /* landings that wrapped are near the end */
-			const u64 o = OWN[i];
-			if (o != PD_EMPTY && PD_S(o) >= F0) OWN[i] = PD_EMPTY;
-		}
-		pd_sync();
-		for (u32 s = F0 + tid; s < B0; s += blockDim.x) SIG[s] = PD_EMPTY;
-		pd_sync();
-	}
+	PD_TICK(5)
 	/* 2. rounds */
 	u32 F = F0;
 	while (F < n) {
 		u32 S1 = 2 * (F - D1) - 1;
 		if (S1 > n) S1 = n;
 		const u32 S2 = S1 == n ? n : S1 - (2 * D1 + 3);
-		if (S2 <= F) { return false; }
+		if (S2 <= F) { if (tid == 0) s_par[7] = 4; return false; }
 		/* A: sigma of the keys whose possible landers are all final */
 		for (u32 s = F + tid; s < S1; s += blockDim.x) {
 			if (!bm_get(cur, s) || SIG[s] != PD_EMPTY) continue;
@@ -1441,7 +1462,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 			}
 		}
 		pd_sync();
-		if (*s_fail) return false;
+		if (*s_fail) { if (tid == 0) s_par[7] = 5; return false; }
 		/* C: finalise [F, S2); take the not yet final participants [S2, S1) out again */
 		for (u32 s = F + tid; s < S2; s += blockDim.x) if (bm_get(cur, s) && !(SIG[s] & PD_FINAL)) SIG[s] |= PD_FINAL;
 		if (S2 < S1) {
@@ -1456,6 +1477,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 		pd_sync();
 		F = S2;
 	}
+	PD_TICK(6)
 	/* 3. verification of the fixed point */
 	if (tid < 8 && tid >= 2) s_par[tid] = 0;
 	__syncthreads();
@@ -1483,32 +1505,37 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	atomicAdd(s_par + 3, placed);
 	if (bad) *s_fail = 1;
 	__syncthreads();
-	if (*s_fail || s_par[3] != n_used) return false;
-	/* 4. commit: move the keys, publish the new bitmap */
-	for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) {
-		u32 bits = 0;
-		for (u32 b = 0; b < 32 && w * 32 + b < N; ++b) {
-			const u64 o = OWN[w * 32 + b];
-			if (o != PD_EMPTY) { bits |= 1u << b; keys[w * 32 + b] = TMP[PD_S(o)]; }
-		}
-		oth[w] = bits;
+	if (*s_fail || s_par[3] != n_used) { if (tid == 0) s_par[7] = 6; return false; }
+	/* 4. commit: move the keys, publish the new bitmap (one slot per lane: a wave's ballot is two bitmap words) */
+	for (u32 i0 = 0; i0 < N; i0 += blockDim.x) {
+		const u32 i = i0 + tid;
+		const u64 o = i < N ? OWN[i] : PD_EMPTY;
+		if (o != PD_EMPTY) keys[i] = TMP[PD_S(o)];
+		const u64 b = __ballot(o != PD_EMPTY);
+		if ((tid & 63) == 0 && i < N) { oth[i >> 5] = (u32)b; if (i + 32 < N) oth[(i >> 5) + 1] = (u32)(b >> 32); }
 	}
 	__syncthreads();
+	PD_TICK(7)
 	return true;
 }
 
 __global__ __launch_bounds__(1024)
 void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used,
               u32 *scr_used, u32 *scr_owner, u64 *scr_par, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
-              u32 *out_bits, u32 *out_count)
+              u32 *out_bits, u32 *out_count, u32 lds_words)
 {
-	__shared__ u64 s_bm[RP_LDS_WORDS];                    /* doubling: old (high) and new (low) bitmap words, interleaved */
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];   /* >= 2 * RP_LDS_WORDS words: placement owner ranks, or ... */
+	u64 *s_bm = (u64*)s_dyn;                               /* ... doubling: old (high) and new (low) bitmap words, interleaved */
 	__shared__ u32 s_progress;
 	__shared__ u32 s_sel[64];
 	__shared__ u32 s_par[8];
 	const ReplayTask T = tasks[blockIdx.x];
 	const int tid = threadIdx.x;
-	u64 *keys = new_keys + T.new_off;
+	u64 *const gkeys = new_keys + T.new_off;
+	/* while the table has <= 8192 slots its keys live in LDS (second half of s_dyn): the doublings of
+	 * that phase are the serial routine, whose cost is the latency of its dependent key accesses */
+	u64 *const lkeys = (u64*)(s_dyn + 16384);
+	u64 *keys = (lds_words >= 32768 && (T.old_bits == YK_NOCAP || T.old_bits <= 12) && (T.init_bits == YK_NOCAP || T.init_bits <= 12) && !(T.dbg & 64)) ? lkeys : gkeys;
 	u32 *UA = new_used + (T.new_off >> 5), *UB = scr_used + (T.new_off >> 5);
 	u32 *owner = scr_owner + T.new_off;
 	u32 *cur = UA, *oth = UB;
@@ -1524,6 +1551,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 	__syncthreads();
 
 	u32 i0 = 0;
+	u64 tick_ = wall_clock64();
 	for (;;) {
 		const u32 thr = (n >> 1) + (n >> 2);
 		bool grow = false;
@@ -1541,8 +1569,10 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 			bool done = false;
 			if (scr_par && n >= RP_PAR_MIN && !(T.dbg & 16)) {
 				u64 *pb = scr_par + 2 * T.new_off;
-				done = replay_double_par(keys, cur, oth, n, N, nb, pb, pb + N, pb + N + n, s_par);
+				done = replay_double_par(keys, cur, oth, n, N, nb, pb, pb + N, pb + N + n, s_par, (u64*)s_dyn, (size_t)(lds_words < 16384 ? lds_words : 16384) * 4,
+				                         (u64*)(scr_owner + T.new_off), (T.dbg & 32) && blockIdx.x == 0);
 				if (tid == 0) atomicAdd(done ? &d_par_ok : &d_par_fail, 1u);
+				if (!done && (T.dbg & 128) && tid == 0) printf("parfail n=%u code=%u\n", n, s_par[7]);
 			}
 			if (!done) {
 			const bool in_lds = (N + 31) / 32 <= RP_LDS_WORDS && !(T.dbg & 8);
@@ -1557,50 +1587,84 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 			else if (tid < 64) {
 				if (in_lds) replay_double_wave64(keys, s_bm, n, N, nb, &s_progress, s_sel);
 				else replay_double_wave(keys, cur, oth, n, N, nb, &s_progress, s_sel);
-			} else if (tid < 128 && !(T.dbg & 4)) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
+			} else if (tid < 128 && !(T.dbg & 4) && keys == gkeys) replay_prefetch(keys, n, nb, &s_progress, scr_owner + T.new_off);
 			__syncthreads();
 			if (in_lds) { for (u32 w = tid; w < (N + 31) / 32; w += blockDim.x) oth[w] = (u32)s_bm[w]; __syncthreads(); }
 			}
 			u32 *t = cur; cur = oth; oth = t;
 			n = N; bits = nb;
+			if (keys == lkeys && n >= 8192) {                 /* grown out of LDS */
+				for (u32 i = tid; i < n; i += blockDim.x) gkeys[i] = lkeys[i];
+				__syncthreads();
+				keys = gkeys;
+			}
+			RP_TICK(n >= 32768 ? 1 : 0)
 			if (i0 == 0xffffffffu) break;
 			continue;
 		}
-		/* FCFS placement of the next keys, up to the growth threshold */
+		/* FCFS placement of the next keys, up to the growth threshold: every key walks from its home
+		 * slot and claims a slot with min(rank); a displaced later key is carried on by the claimer.
+		 * The owner ranks live in LDS while the table has <= 2 x lds_words slots (32-bit ranks, or
+		 * 16-bit ones updated by compare-and-swap), else in global scratch (memory-side atomics). */
 		const u32 batch = (T.m - i0 < thr - cnt) ? T.m - i0 : thr - cnt;
 		const u32 nmask = n - 1;
 		if (T.dbg & 2) { cnt += batch; i0 += batch; continue; }
-		for (u32 i = tid; i < n; i += blockDim.x) owner[i] = bm_get(cur, i) ? 0u : 0xffffffffu;
+		const u64 *src = rec_kc + T.rec_off + i0;
+#define RP_PLACE(INIT, AMIN, LOAD)                                                                      \
+		for (u32 i = tid; i < n; i += blockDim.x) { INIT(i, bm_get(cur, i)); }                              \
+		__syncthreads();                                                                                    \
+		for (u32 q = tid; q < batch; q += blockDim.x) {                                                     \
+			u32 r = q + 1, slot = yk_h2b((u32)(src[q] >> 10), bits);                                        \
+			for (;;) {                                                                                      \
+				u32 old; AMIN(old, slot, r);                                                                \
+				if (old == EMPTYV) break;                                                                   \
+				if (old > r) r = old;               /* we took the slot; carry the displaced later key on */ \
+				slot = (slot + 1) & nmask;                                                                  \
+			}                                                                                               \
+		}                                                                                                   \
+		__syncthreads();                                                                                    \
+		for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) {   /* one lane per bitmap word: no atomics on the bitmap */ \
+			u32 bw = cur[w];                                                                                \
+			for (u32 b = 0; b < 32 && w * 32 + b < n; ++b) {                                                \
+				const u32 i = w * 32 + b; u32 o; LOAD(o, i);                                                \
+				if (o != 0 && o != EMPTYV) { keys[i] = src[o - 1]; bw |= 1u << b; }                         \
+			}                                                                                               \
+			cur[w] = bw;                                                                                    \
+		}                                                                                                   \
 		__syncthreads();
-		for (u32 q = tid; q < batch; q += blockDim.x) {
-			u32 r = q + 1;
-			u32 slot = yk_h2b((u32)(rec_kc[T.rec_off + i0 + q] >> 10), bits);
-			for (;;) {
-				const u32 old = atomicMin(&owner[slot], r);
-				if (old == 0xffffffffu) break;
-				if (old > r) {                            /* we took the slot; carry the displaced later key on */
-					r = old;
-				}
-				slot = (slot + 1) & nmask;
-			}
+		if (n <= lds_words) {
+#define EMPTYV 0xffffffffu
+#define INIT32(i, used) s_dyn[i] = (used) ? 0u : EMPTYV
+#define AMIN32(old, slot, r) old = atomicMin(&s_dyn[slot], r)
+#define LOAD32(o, i) o = s_dyn[i]
+			RP_PLACE(INIT32, AMIN32, LOAD32)
+#undef EMPTYV
+		} else if (n <= 2 * lds_words && batch < 0xffffu) {
+#define EMPTYV 0xffffu
+#define INIT16(i, used) ((unsigned short*)s_dyn)[i] = (used) ? (unsigned short)0 : (unsigned short)0xffff
+#define AMIN16(old, slot, r) { u32 *wp = &s_dyn[(slot) >> 1]; const u32 sh = 16 * ((slot) & 1); u32 seen = *(volatile u32*)wp;        \
+				for (;;) { old = seen >> sh & 0xffffu; if (old <= (r)) break;                                                            \
+				           const u32 got = atomicCAS(wp, seen, (seen & ~(0xffffu << sh)) | (r) << sh); if (got == seen) break; seen = got; } }
+#define LOAD16(o, i) o = ((unsigned short*)s_dyn)[i]
+			RP_PLACE(INIT16, AMIN16, LOAD16)
+#undef EMPTYV
+		} else {
+#define EMPTYV 0xffffffffu
+#define INITG(i, used) owner[i] = (used) ? 0u : EMPTYV
+#define AMING(old, slot, r) old = atomicMin(&owner[slot], r)
+#define LOADG(o, i) o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+			RP_PLACE(INITG, AMING, LOADG)
+#undef EMPTYV
 		}
-		__syncthreads();
-		for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) {          /* one lane per bitmap word: no atomics on the bitmap */
-			u32 bits = cur[w];
-			for (u32 b = 0; b < 32 && w * 32 + b < n; ++b) {
-				const u32 i = w * 32 + b;
-				const u32 o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (o != 0 && o != 0xffffffffu) { keys[i] = rec_kc[T.rec_off + i0 + o - 1]; bits |= 1u << b; }
-			}
-			cur[w] = bits;
-		}
-		__syncthreads();
 		cnt += batch; i0 += batch;
+		RP_TICK(n >= 32768 ? 3 : 2)
 	}
 	__syncthreads();
+	if (keys == lkeys) { for (u32 i = tid; i < n; i += blockDim.x) gkeys[i] = lkeys[i]; __syncthreads(); keys = gkeys; }
 	/* publish: bitmap in the arena, unused slots normalised to YK_EMPTY */
 	if (cur != UA) for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) UA[w] = cur[w];
 	for (u32 i = tid; i < n; i += blockDim.x) if (!bm_get(cur, i)) keys[i] = YK_EMPTY;
+	RP_TICK(4)
 	if (tid == 0) { out_bits[blockIdx.x] = n ? bits : YK_NOCAP; out_count[blockIdx.x] = cnt; }
 }
 
@@ -2132,6 +2196,7 @@ void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, in
 	hipLaunchKernelGGL(k_rpart<1>, dim3(n_blk), dim3(256), lds, st, in_hash, in_t, n, pre, plo, phi, nb_bits, rows, out);
 }
 
+void yk_replay_prof(u64 *out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(d_rp_prof), 64); u64 z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d_rp_prof), z, 64); }
 void yk_par_counters(u32 *ok, u32 *fail)
 {
 	(void)hipDeviceSynchronize();
@@ -2265,10 +2330,13 @@ void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
                       u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
-                      u32 *out_bits, u32 *out_count, hipStream_t st)
+                      u32 *out_bits, u32 *out_count, u32 lds_words, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(n_threads), 0, st, tasks, old_keys, old_used, new_keys, new_used,
-	                   scr_used, scr_owner, scr_par, rec_kc, rec_t, lastput, out_bits, out_count);
+	static bool attr = false;
+	if (!attr) { hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
+	if (lds_words < 2 * RP_LDS_WORDS) lds_words = 2 * RP_LDS_WORDS;
+	hipLaunchKernelGGL(k_replay, dim3(n_tasks), dim3(n_threads), (size_t)lds_words * 4, st, tasks, old_keys, old_used, new_keys, new_used,
+	                   scr_used, scr_owner, scr_par, rec_kc, rec_t, lastput, out_bits, out_count, lds_words);
 }
 
 void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st)

@@ -80,6 +80,7 @@ int yk_part_groups(void);
 int yk_rpart_blocks(int64_t n_rec);
 int yk_bad_hash_seen(hipStream_t st);
 void yk_par_counters(u32 *ok, u32 *fail);
+void yk_replay_prof(u64 *out8);
 void yk_launch_acc_init(AccSlot *s, u64 n, hipStream_t st);
 void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView img,
                           int img_nonempty, int bloom_mode, u64 *newlist, u64 *counters, hipStream_t st);
@@ -112,7 +113,7 @@ void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
                       u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
-                      u32 *out_bits, u32 *out_count, hipStream_t st);
+                      u32 *out_bits, u32 *out_count, u32 lds_words, hipStream_t st);
 void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st);
 void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc, hipStream_t st);
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st);
