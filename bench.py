@@ -265,9 +265,11 @@ def main():
     # (DESIGN.md section 4): partition sweeps 8 B/instance, insert/count 24 B/instance, pass-2 lookup
     # 16 + 8 f_hit, layout replay 16 B per key placed.
     n1, n2 = s1["n_instances"], (s2["n_instances"] if s2 else 0)
+    dev_batch = int(os.environ.get("YAKAMD_BATCH", 1 << 30))
+    n_batches = -(-n_bytes // dev_batch)
     kern = [
         {"kernel": "k_xpart (extract + level-1 partition, both passes)", "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),
-         "launches": 2 * (-(-n_bytes // (1 << 27))) * (2 if s2 else 1), "bytes": 8.0 * (n1 + n2)},
+         "launches": 2 * n_batches * (2 if s2 else 1), "bytes": 8.0 * (n1 + n2)},   # histogram + scatter per device batch
         {"kernel": "k_part2 (level-2 partition)", "ms": s1["ms_part2"], "launches": 2, "bytes": 8.0 * n1},
         {"kernel": "k_lds_count (insert + bloom gate)" if s1["ms_part2"] > 0 else "k_acc_insert", "ms": s1["ms_insert"],
          "launches": max(1, s1["n_dominant_launches"]), "bytes": B_INSERT * n1},
@@ -285,10 +287,10 @@ def main():
         k_["achieved_GBs"] = k_["bytes"] / (k_["ms"] * 1e-3) / 1e9 if k_["ms"] > 0 else 0.0
         k_["frac"] = k_["achieved_GBs"] / HBM_PEAK_GBS
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01e_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
+    # (profiles/r01g_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))
     except Exception:
         pass
     for k_ in kern:
@@ -318,7 +320,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS,
                      "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
-                     "traffic_source": "profiles/r01e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
+                     "traffic_source": "profiles/r01g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},

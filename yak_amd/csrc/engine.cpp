@@ -773,7 +773,7 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	/* owner ranks of the placement stages in LDS: 32-bit up to lds_words slots, 16-bit up to twice that */
 	u32 cap_top = 0;
 	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
-	u32 lds_words = env_i64("YAKAMD_REPLAY_LDS", 1) ? std::min<u32>(cap_top, 32768) : 0;
+	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 32768));   /* 0: owner ranks in global scratch */
 	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
 	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
 	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
