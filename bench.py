@@ -147,13 +147,13 @@ def main():
         """partition this rank's k-mers by sub-table prefix once, then one all-to-all per pass moves
         every record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI)"""
         from yak_amd import shard
-        n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+        if create_new:
+            n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+        else:                                               # counting existing keys only needs the hashes: 8-byte records
+            n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
         if n < 0:
             raise RuntimeError("partition failed")
-        if create_new:
-            out = shard.exchange_partitioned(s_rec[:n], list(h_bstart), P)
-        else:
-            out = shard.exchange_hashes(s_rec[:n], list(h_bstart), P)
+        out = shard.exchange_partitioned(s_rec[:n] if create_new else s_rec.reshape(-1)[:n], list(h_bstart), P)
         torch.cuda.synchronize()
         return out
 
@@ -164,15 +164,14 @@ def main():
         segs = exchange(create_new)
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
-        if not create_new:
-            if L.yakamd_count_hashes_dev(t.h, segs.data_ptr(), segs.shape[0]) != 0:
-                raise RuntimeError("count_hashes")
-            segs = []
         for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job
             if rec.shape[0]:
                 ob = (C.c_uint64 * (P + 1))(*offs)
-                if L.yakamd_feed_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob, src * n_bytes, n_bytes) != 0:
-                    raise RuntimeError("feed_partitioned")
+                if create_new:
+                    if L.yakamd_feed_partitioned_lent_dev(t.h, rec.data_ptr(), rec.shape[0], ob, src * n_bytes, n_bytes) != 0:   # `segs` outlives pass_end
+                        raise RuntimeError("feed_partitioned")
+                elif L.yakamd_count_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob) != 0:
+                    raise RuntimeError("count_partitioned")
         n_ins = L.yakamd_pass_end(t.h)
         if n_ins < 0:
             raise RuntimeError("pass_end")

@@ -66,6 +66,15 @@ int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes,
 int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart);
 int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart,
                                 uint64_t t0, uint64_t t_span);
+/* same, but d_rec is LENT: the caller keeps it valid and unmodified until yakamd_pass_end() returns,
+ * and the engine works on it in place instead of taking a copy */
+int yakamd_feed_partitioned_lent_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart,
+                                     uint64_t t0, uint64_t t_span);
+
+/* The same for passes that only count existing keys (create_new = 0; main.c:57): 8-byte records,
+ * just the yak_hash64 values, grouped by prefix the same way. */
+int64_t yakamd_partition_hashes_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_hash_out, uint64_t *h_bstart);
+int yakamd_count_partitioned_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n, const uint64_t *h_bstart);
 
 /* create_new = 0 pass on bare yak_hash64 values (any order): count the ones present in the table */
 int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n);

@@ -143,12 +143,13 @@ def test_partitioned_exchange_path_on_one_gpu(bf, ya, oracle, synth):
     nb = len(slices[0])
     parts_by_src = []
     for x in slices:                                     # what every source rank prepares
-        d = L.yakamd_dev_alloc(nb); rec = L.yakamd_dev_alloc(nb * 16)
+        d = L.yakamd_dev_alloc(nb); rec = L.yakamd_dev_alloc(nb * 16); hsh = L.yakamd_dev_alloc(nb * 8)
         assert L.yakamd_memcpy_h2d(d, x, nb) == 0
-        bst = (C.c_uint64 * (P + 1))()
+        bst = (C.c_uint64 * (P + 1))(); bst2 = (C.c_uint64 * (P + 1))()
         n = L.yakamd_partition_dev(31, 10, d, nb, rec, bst)
         assert n == bst[P] and n > 0
-        parts_by_src.append((rec, list(bst)))
+        assert L.yakamd_partition_hashes_dev(31, 10, d, nb, hsh, bst2) == n and list(bst2) == list(bst)
+        parts_by_src.append((rec, list(bst), hsh))
         L.yakamd_dev_free(d)
     parts, tot = [], 0
     for r in range(world):
@@ -158,11 +159,15 @@ def test_partitioned_exchange_path_on_one_gpu(bf, ya, oracle, synth):
 
         def one_pass(create_new):
             assert L.yakamd_pass_begin(t.h, create_new) == 0
-            for src, (rec, bst) in enumerate(parts_by_src):
+            for src, (rec, bst, hsh) in enumerate(parts_by_src):
                 m = bst[hi] - bst[lo]
                 offs = [0] * lo + [b - bst[lo] for b in bst[lo:hi + 1]] + [m] * (P - hi)
                 ob = (C.c_uint64 * (P + 1))(*offs)
-                assert L.yakamd_feed_partitioned_dev(t.h, rec + 16 * bst[lo], m, ob, src * nb, nb) == 0
+                if create_new:
+                    feed = L.yakamd_feed_partitioned_lent_dev if (src + r) & 1 else L.yakamd_feed_partitioned_dev   # lent: used in place
+                    assert feed(t.h, rec + 16 * bst[lo], m, ob, src * nb, nb) == 0
+                else:                                   # count-existing pass: 8-byte hashes, same grouping
+                    assert L.yakamd_count_partitioned_dev(t.h, hsh + 8 * bst[lo], m, ob) == 0
             n_ins = L.yakamd_pass_end(t.h)
             assert n_ins >= 0
             t.h.contents.tot += n_ins
@@ -176,8 +181,8 @@ def test_partitioned_exchange_path_on_one_gpu(bf, ya, oracle, synth):
             if lo <= p < hi:
                 parts.append(data[off:off + 8 + 8 * n])
             off += 8 + 8 * n
-    for rec, _ in parts_by_src:
-        L.yakamd_dev_free(rec)
+    for rec, _, hsh in parts_by_src:
+        L.yakamd_dev_free(rec); L.yakamd_dev_free(hsh)
     want, wtot = oracle.count_protocol_mem(b"".join(slices), k=31, bf_shift=bf)
     assert want[:16] + b"".join(parts) == want and tot == wtot
 

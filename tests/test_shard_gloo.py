@@ -99,3 +99,52 @@ def test_owner_ranges():
         assert all(shard.owner_of(p, world, 1024) == i for i, (lo, hi) in enumerate(r) for p in (lo, hi - 1))
     with pytest.raises(ValueError):
         shard.owner_range(0, 3, 1024)
+
+
+WORKER2 = r'''
+import sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from yak_amd import shard
+
+P = 1024
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lo, hi = shard.owner_range(rank, world, P)
+
+def records_of(r):
+    """what rank r partitions: {{hash, position}} sorted by prefix = low 10 bits of the hash (ragged groups, some empty)"""
+    g = np.random.default_rng(100 + r)
+    n = 5000 + 700 * r
+    h = g.integers(0, 1 << 62, size=n, dtype=np.int64)
+    h[(h & (P - 1)) % 7 == 3] |= 5                     # leave some prefixes empty
+    o = np.argsort(h & (P - 1), kind="stable")
+    h = h[o]; t = g.integers(0, 1 << 31, size=n, dtype=np.int64)
+    bst = np.searchsorted(h & (P - 1), np.arange(P + 1))
+    return np.stack([h, t], axis=1), bst
+
+rec, bst = records_of(rank)
+for width in (2, 1):
+    send = torch.from_numpy(rec if width == 2 else np.ascontiguousarray(rec[:, 0]))
+    got = shard.exchange_partitioned(send, [int(x) for x in bst], P)
+    assert len(got) == world
+    for src, (sl, offs) in enumerate(got):
+        r2, b2 = records_of(src)
+        want = r2[b2[lo]:b2[hi]] if width == 2 else r2[b2[lo]:b2[hi], 0]
+        assert sl.shape[0] == b2[hi] - b2[lo] and np.array_equal(sl.numpy(), want), (width, src)
+        assert len(offs) == P + 1 and offs[0] == 0 and offs[-1] == sl.shape[0]
+        assert all(offs[p + 1] - offs[p] == (b2[p + 1] - b2[p] if lo <= p < hi else 0) for p in range(P))
+dist.destroy_process_group()
+'''
+
+
+def test_partitioned_exchange_formats_two_ranks(tmp_path):
+    """the production exchange (per-source slices + per-prefix offsets), 16-byte records of a counting
+    pass and the 8-byte hashes of a count-existing pass, ragged and empty prefix groups"""
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                   check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

@@ -28,6 +28,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
+    "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
 ]
 
 
@@ -104,6 +105,12 @@ def lib():
     L.yakamd_partition_dev.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_uint64)]
     L.yakamd_feed_partitioned_dev.restype = C.c_int
     L.yakamd_feed_partitioned_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, P(C.c_uint64), C.c_uint64, C.c_uint64]
+    L.yakamd_feed_partitioned_lent_dev.restype = C.c_int
+    L.yakamd_feed_partitioned_lent_dev.argtypes = L.yakamd_feed_partitioned_dev.argtypes
+    L.yakamd_partition_hashes_dev.restype = C.c_int64
+    L.yakamd_partition_hashes_dev.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_uint64)]
+    L.yakamd_count_partitioned_dev.restype = C.c_int
+    L.yakamd_count_partitioned_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, P(C.c_uint64)]
     L.yakamd_count_hashes_dev.restype = C.c_int
     L.yakamd_count_hashes_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64]
     L.yakamd_dev_alloc.restype = C.c_void_p; L.yakamd_dev_alloc.argtypes = [C.c_size_t]

@@ -176,7 +176,7 @@ struct yakamd_ctx {
 	uint8_t *d_stage; int64_t stage_cap;
 	u32 *d_rows; u64 *d_partial, *d_bstart; int rows_blk; int nb_bits;
 	/* fast path: level-1 partitioned batches kept until pass_end */
-	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; };
+	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; bool owned; };
 	std::vector<Kept> kept;
 	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set;
 	double ms_part2, ms_lds;
@@ -285,7 +285,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 
 static void pass_free(yakamd_ctx *c)
 {
-	for (auto &k : c->kept) dfree(k.d_rec);
+	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(c->acc.s); c->acc_count = 0;
 	dfree(c->d_rec); c->rec_cap = 0;
@@ -545,7 +545,7 @@ static int fast_abandon(yakamd_ctx *c)
 	for (auto &k : c->kept) {
 		c->d_rec = k.d_rec;
 		if (!r) r = consume_records(c, (int64_t)k.n, k.t0, k.t0, k.t0 + k.span);
-		dfree(k.d_rec);
+		if (k.owned) dfree(k.d_rec);
 	}
 	c->d_rec = keep;
 	c->kept.clear(); c->kept_bytes = 0;
@@ -554,15 +554,16 @@ static int fast_abandon(yakamd_ctx *c)
 
 /* may this batch (n_pos stream positions starting at time t) stay on the fast path?  If so,
  * allocate its level-1 output buffers */
-static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out)
+static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec *borrowed = 0)
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
-	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + n_cap * 16 <= c->fast_budget;
+	const u64 cost = borrowed ? 0 : n_cap * 16;                  /* a borrowed buffer is the caller's memory */
+	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + cost <= c->fast_budget;
 	if (!fits) { if (fast_abandon(c)) return -1; return 0; }
 	yakamd_ctx::Kept k;
-	k.d_rec = 0; k.n = 0; k.t0 = t; k.span = n_pos;
-	if (dmalloc(&k.d_rec, (size_t)n_cap)) return -1;
-	c->kept_bytes += n_cap * 16;
+	k.d_rec = borrowed; k.n = 0; k.t0 = t; k.span = n_pos; k.owned = !borrowed;
+	if (!borrowed && dmalloc(&k.d_rec, (size_t)n_cap)) return -1;
+	c->kept_bytes += cost;
 	c->kept.push_back(k);
 	*out = k.d_rec;
 	return 0;
@@ -645,7 +646,7 @@ extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const voi
 	return consume_records(c, (int64_t)n_rec, t0, t0, t0 + t_span, c->d_bstart);
 }
 
-extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart)
+static int64_t partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_out, uint64_t *h_bstart, int hash_only)
 {
 	if (k < 1 || k > 63 || pre < 3 || pre > 13) { fail("partition: unsupported k / pre"); return -1; }
 	if (((uintptr_t)d_bases & 15) != 0 || n_bytes >= ((int64_t)1 << 32)) { fail("partition: base image must be 16-byte aligned and < 4 GiB"); return -1; }
@@ -653,14 +654,24 @@ extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int
 	const int n_blk = yk_xpart_blocks(n_bytes);
 	u32 *d_rows = 0; u64 *d_partial = 0, *d_bstart = 0;
 	if (dmalloc(&d_rows, NB * (size_t)n_blk) || dmalloc(&d_partial, NB * yk_part_groups()) || dmalloc(&d_bstart, NB + 1)) return -1;
-	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_rec_out, 0, 0);
+	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_out, hash_only, 0);
 	const hipError_t e = hipMemcpy(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost);
 	dfree(d_rows); dfree(d_partial); dfree(d_bstart);
 	if (e != hipSuccess) { fail("partition: %s", hipGetErrorString(e)); return -1; }
 	return (int64_t)h_bstart[NB];
 }
 
-extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span)
+extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec_out, uint64_t *h_bstart)
+{
+	return partition_dev(k, pre, d_bases, n_bytes, d_rec_out, h_bstart, 0);
+}
+
+extern "C" int64_t yakamd_partition_hashes_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_hash_out, uint64_t *h_bstart)
+{
+	return partition_dev(k, pre, d_bases, n_bytes, d_hash_out, h_bstart, 1);
+}
+
+static int feed_partitioned(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span, bool borrow)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("feed outside a pass");
@@ -670,9 +681,9 @@ extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64
 	const size_t NB = (size_t)1 << c->nb_bits;
 	if (c->fast) {
 		Rec *out = 0;
-		if (fast_admit(c, t0, t_span, (u64)n, &out)) return -1;
-		if (c->fast) {                                       /* admitted: keep a private copy, already grouped by prefix */
-			HIPCK(hipMemcpyAsync(out, d_rec, (size_t)n * sizeof(Rec), hipMemcpyDeviceToDevice, c->st));
+		if (fast_admit(c, t0, t_span, (u64)n, &out, borrow ? (Rec*)d_rec : 0)) return -1;
+		if (c->fast) {                                       /* admitted: already grouped by prefix; keep a private copy unless lent */
+			if (!borrow) HIPCK(hipMemcpyAsync(out, d_rec, (size_t)n * sizeof(Rec), hipMemcpyDeviceToDevice, c->st));
 			yakamd_ctx::Kept &k = c->kept.back();
 			k.bstart.assign(h_bstart, h_bstart + NB + 1);
 			k.n = (u64)n;
@@ -685,6 +696,34 @@ extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64
 	c->d_rec = (Rec*)d_rec;
 	const int r = consume_records(c, n, t0, t0, t0 + t_span);
 	c->d_rec = keep;
+	return r;
+}
+
+extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span)
+{
+	return feed_partitioned(h, d_rec, n, h_bstart, t0, t_span, false);
+}
+
+extern "C" int yakamd_feed_partitioned_lent_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span)
+{
+	return feed_partitioned(h, d_rec, n, h_bstart, t0, t_span, true);
+}
+
+extern "C" int yakamd_count_partitioned_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n, const uint64_t *h_bstart)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass || c->create_new) return fail("count_partitioned needs an open create_new = 0 pass");
+	if (c->nb_bits != c->pre) return fail("count_partitioned needs pre <= 13");
+	HIPCK(hipSetDevice(c->dev));
+	if (n <= 0) return 0;
+	const size_t NB = (size_t)1 << c->nb_bits;
+	if (part_reserve(c, 1)) return -1;
+	HIPCK(hipMemcpyAsync(c->d_bstart, h_bstart, (NB + 1) * 8, hipMemcpyHostToDevice, c->st));
+	Rec *keep = c->d_rec;
+	c->d_rec = (Rec*)d_hash_u64;
+	const int r = consume_records(c, n, 0, 0, 0, c->d_bstart, 1);
+	c->d_rec = keep;
+	HIPCK(hipStreamSynchronize(c->st));                       /* h_bstart may be a temporary of the caller */
 	return r;
 }
 
@@ -868,7 +907,7 @@ static int fast_finish(yakamd_ctx *c)
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 = c->ms_part2;
 	}
-	for (auto &k : c->kept) dfree(k.d_rec);
+	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
 	if (dmalloc(&kc[0], n_total) || dmalloc(&tt[0], n_total)) return -1;

@@ -129,12 +129,15 @@ def exchange_hashes(send_rec, bstart, n_prefix):
 
 
 def exchange_partitioned(send_rec, bstart, n_prefix):
-    """send_rec: int64 tensor [n, 2] of records grouped by sub-table prefix (ascending), `bstart` the
-    n_prefix + 1 group offsets (yakamd_partition_dev).  Owners are contiguous prefix ranges, so the
-    per-destination send buffers are slices.  Returns a list, in source-rank order, of
-    (recv_slice [m, 2], offsets[n_prefix + 1] of that slice) ready for yakamd_feed_partitioned_dev."""
+    """send_rec: int64 tensor of records grouped by sub-table prefix (ascending) -- [n, 2] {hash,
+    position} for a counting pass (yakamd_partition_dev), or [n] bare hashes for a pass that only
+    counts existing keys (yakamd_partition_hashes_dev); `bstart` the n_prefix + 1 group offsets.
+    Owners are contiguous prefix ranges, so the per-destination send buffers are slices.  Returns a
+    list, in source-rank order, of (recv_slice, offsets[n_prefix + 1] of that slice) ready for
+    yakamd_feed_partitioned_dev / yakamd_count_partitioned_dev."""
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = send_rec.device
+    width = send_rec.shape[1] if send_rec.dim() == 2 else 1
     per = n_prefix // world
     send_counts = [int(bstart[(d + 1) * per] - bstart[d * per]) for d in range(world)]
     # relative offsets of the owned prefixes inside each destination's slice
@@ -145,9 +148,10 @@ def exchange_partitioned(send_rec, bstart, n_prefix):
     rel_in = rel_in.reshape(world, per + 1).tolist()
     recv_counts = [r[-1] for r in rel_in]
     flat = send_rec.reshape(-1)
-    recv = torch.empty(2 * sum(recv_counts), dtype=torch.int64, device=dev)
-    _a2a_rounds(recv, flat, [2 * c for c in recv_counts], [2 * c for c in send_counts])
-    recv = recv.reshape(-1, 2)
+    recv = torch.empty(width * sum(recv_counts), dtype=torch.int64, device=dev)
+    _a2a_rounds(recv, flat, [width * c for c in recv_counts], [width * c for c in send_counts])
+    if width > 1:
+        recv = recv.reshape(-1, width)
     lo = rank * per
     out, off = [], 0
     for src in range(world):
