@@ -1348,6 +1348,7 @@ __device__ void replay_prefetch(const u64 *keys, u32 n, u32 nbits_new, volatile 
 __device__ u32 d_par_ok, d_par_fail;      /* doublings done by the parallel routine / sent back to the serial one */
 __device__ u64 d_rp_prof[8];              /* debug (dbg & 32): wall-clock ticks of block 0 per phase */
 #define RP_TICK(slot) if ((T.dbg & 32) && blockIdx.x == 0 && tid == 0) { const u64 now_ = wall_clock64(); d_rp_prof[slot] += now_ - tick_; tick_ = now_; }
+#define PD_U 4
 #define PD_EMPTY  0xffffffffffffffffull
 #define PD_FINAL  0x8000000000000000ull
 #define PD_PACK(c, d, s) ((u64)(c) << 40 | (u64)(d) << 24 | (u64)(s))
@@ -1381,6 +1382,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	atomicMax(s_d1, d1); atomicAdd(s_cnt, nused);
 	pd_sync();
 	const u32 D1 = *s_d1, n_used = *s_cnt;
+	PD_TICK(4)
 	const u32 F0 = 5 * D1 + 16, B0 = F0 + 2 * D1 + 4;               /* final after the base phase / simulated by it */
 	if (B0 * 4 > n || n > (1u << 23)) { if (tid == 0) s_par[7] = 1; return false; }   /* too clustered / too large: serial */
 	/* 1. the literal rule for scan positions below B0; a chain is followed only while it stays below
@@ -1439,26 +1441,43 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 		const u32 S2 = S1 == n ? n : S1 - (2 * D1 + 3);
 		if (S2 <= F) { if (tid == 0) s_par[7] = 4; return false; }
 		/* A: sigma of the keys whose possible landers are all final */
-		for (u32 s = F + tid; s < S1; s += blockDim.x) {
-			if (!bm_get(cur, s) || SIG[s] != PD_EMPTY) continue;
-			const u64 o = OWN[s];
-			SIG[s] = (o != PD_EMPTY && PD_S(o) != s && PD_C(o) < s) ? PD_PACK(PD_C(o), PD_D(o) + 1, s) : PD_PACK(s, 0, s);
+		for (u32 s0 = F + tid; s0 < S1; s0 += PD_U * blockDim.x) {          /* PD_U independent slots per lane in flight */
+			u64 g[PD_U], o[PD_U]; bool ok[PD_U];
+#pragma unroll
+			for (int u = 0; u < PD_U; ++u) {
+				const u32 s = s0 + u * blockDim.x;
+				ok[u] = s < S1 && bm_get(cur, s);
+				g[u] = ok[u] ? SIG[s] : 0; o[u] = ok[u] ? OWN[s] : 0;
+			}
+#pragma unroll
+			for (int u = 0; u < PD_U; ++u) {
+				const u32 s = s0 + u * blockDim.x;
+				if (ok[u] && g[u] == PD_EMPTY)
+					SIG[s] = (o[u] != PD_EMPTY && PD_S(o[u]) != s && PD_C(o[u]) < s) ? PD_PACK(PD_C(o[u]), PD_D(o[u]) + 1, s) : PD_PACK(s, 0, s);
+			}
 		}
 		pd_sync();
 		/* B: ordered probing of those keys on top of the final ones */
-		for (u32 s = F + tid; s < S1; s += blockDim.x) {
-			if (!bm_get(cur, s)) continue;
-			u64 cand = SIG[s];
-			if (cand & PD_FINAL) continue;
-			u32 i = yk_h2b((u32)(TMP[s] >> 10), nb_new);
-			for (u32 guard = 0; guard < N; ++guard) {
-				const u64 old = atomicMin(&OWN[i], cand);
-				if (old == PD_EMPTY) break;
-				if (old > cand) {
-					if (__hip_atomic_load(&SIG[PD_S(old)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PD_FINAL) { *s_fail = 1; break; }
-					cand = old;
-				}
-				i = (i + 1) & Nmask;
+		for (u32 s0 = F + tid; s0 < S1; s0 += PD_U * blockDim.x) {
+			u64 cand[PD_U], old[PD_U]; u32 i[PD_U], act = 0;
+#pragma unroll
+			for (int u = 0; u < PD_U; ++u) {
+				const u32 s = s0 + u * blockDim.x;
+				if (s < S1 && bm_get(cur, s)) { cand[u] = SIG[s]; i[u] = yk_h2b((u32)(TMP[s] >> 10), nb_new); if (!(cand[u] & PD_FINAL)) act |= 1u << u; }
+			}
+			for (u32 guard = 0; act && guard < N; ++guard) {
+#pragma unroll
+				for (int u = 0; u < PD_U; ++u) if (act >> u & 1) old[u] = atomicMin(&OWN[i[u]], cand[u]);
+#pragma unroll
+				for (int u = 0; u < PD_U; ++u)
+					if (act >> u & 1) {
+						if (old[u] == PD_EMPTY) { act &= ~(1u << u); continue; }
+						if (old[u] > cand[u]) {
+							if (__hip_atomic_load(&SIG[PD_S(old[u])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PD_FINAL) { *s_fail = 1; act &= ~(1u << u); continue; }
+							cand[u] = old[u];
+						}
+						i[u] = (i[u] + 1) & Nmask;
+					}
 			}
 		}
 		pd_sync();
@@ -1482,17 +1501,24 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	if (tid < 8 && tid >= 2) s_par[tid] = 0;
 	__syncthreads();
 	u32 placed = 0, bad = 0;
-	for (u32 i = tid; i < N; i += blockDim.x) {
-		const u64 o = OWN[i];
-		if (o == PD_EMPTY) continue;
-		++placed;
-		const u32 so = PD_S(o);
-		if ((SIG[so] & ~PD_FINAL) != o) { bad = 1; continue; }
-		u32 q = yk_h2b((u32)(TMP[so] >> 10), nb_new), steps = 0;
-		while (q != i) {                                              /* every slot before it holds an earlier key */
-			const u64 p = OWN[q];
-			if (p == PD_EMPTY || p > o || ++steps > 4 * D1 + 64) { bad = 1; break; }
-			q = (q + 1) & Nmask;
+	for (u32 i0 = tid; i0 < N; i0 += PD_U * blockDim.x) {
+		u64 o[PD_U], g[PD_U], k[PD_U];
+#pragma unroll
+		for (int u = 0; u < PD_U; ++u) { const u32 i = i0 + u * blockDim.x; o[u] = i < N ? OWN[i] : PD_EMPTY; }
+#pragma unroll
+		for (int u = 0; u < PD_U; ++u) if (o[u] != PD_EMPTY) { g[u] = SIG[PD_S(o[u])]; k[u] = TMP[PD_S(o[u])]; }
+#pragma unroll
+		for (int u = 0; u < PD_U; ++u) {
+			if (o[u] == PD_EMPTY) continue;
+			const u32 i = i0 + u * blockDim.x;
+			++placed;
+			if ((g[u] & ~PD_FINAL) != o[u]) { bad = 1; continue; }
+			u32 q = yk_h2b((u32)(k[u] >> 10), nb_new), steps = 0;
+			while (q != i) {                                          /* every slot before it holds an earlier key */
+				const u64 p = OWN[q];
+				if (p == PD_EMPTY || p > o[u] || ++steps > 4 * D1 + 64) { bad = 1; break; }
+				q = (q + 1) & Nmask;
+			}
 		}
 	}
 	for (u32 s = tid; s < n; s += blockDim.x) {
