@@ -271,3 +271,18 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
         got, tot = ya.count_protocol_host(mixed, **opt)
         want, wtot = oracle.count_protocol_mem(mixed, **opt)
         assert (got == want, tot) == (True, wtot), opt
+
+
+@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0")],
+                         ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling"])
+def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
+    """~7 M distinct k-mers (1x coverage): every sub-table grows to 16 Ki slots, so the layout replay
+    goes through LDS-resident keys, 32- and 16-bit LDS owner ranks, global ranks, and the parallel
+    doubling with its LDS base phase -- each variant must give the reference bytes"""
+    img = synth(50000, g=8_000_000, s=77, e=0.0, N=0.0)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for opt in (dict(k=31), dict(k=27, bf_shift=30)):
+        got, tot = ya.count_protocol_host(img, **opt)
+        want, wtot = oracle.count_protocol_mem(img, **opt)
+        assert (got == want, tot) == (True, wtot), opt
