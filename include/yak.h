@@ -40,6 +40,15 @@ typedef struct {
 
 /* blocked bloom filter of one sub-table (reference yak.h:49-52).  In this implementation the
  * authoritative bits live in HBM; `b` is a host mirror that is brought up to date on demand. */
+typedef struct {                    /* reference yak.h:33-40 */
+	int32_t print_each, print_err_kmer;
+	int32_t min_len;
+	int32_t n_threads;
+	double min_frac;
+	double fpr;
+	int64_t chunk_size;
+} yak_qopt_t;
+
 typedef struct {
 	int n_shift, n_hashes;
 	uint8_t *b;
@@ -97,6 +106,12 @@ yak_ch_t *yak_ch_restore(const char *fn);                         /* reference h
  * h0 != NULL: only increment k-mers already present in h0 (k and pre must match) and return h0.
  * NULL when the file cannot be opened or no usable GPU is present (a message goes to stderr). */
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0);
+
+/* `yak qv` counting step (reference qv.c:34-135, yak.h:33-40,105-106): per sequence of fn with at
+ * least min_len bases, the table count of every k-mer; sequences whose fraction of present k-mers is
+ * >= min_frac add their counts to cnt[YAK_N_COUNTS].  Runs on the device-resident table. */
+void yak_qopt_init(yak_qopt_t *opt);
+void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *cnt);
 
 #ifdef __cplusplus
 }

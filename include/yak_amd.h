@@ -79,6 +79,17 @@ int yakamd_count_partitioned_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n,
 /* create_new = 0 pass on bare yak_hash64 values (any order): count the ones present in the table */
 int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n);
 
+/* Lookup-only path (`yak qv`, reference qv.c:34-86, k < 32).  yakamd_lookup_dev(): d_out_u16[i] =
+ * max(0, yak_ch_get()) of the canonical k-mer ENDING at byte i of the base image, 0xffff where no
+ * k-mer ends (window shorter than k or holding a non-ACGT byte).  yakamd_qv_reduce_dev(): sequence j
+ * is bytes [d_seq_off[j], d_seq_off[j] + d_seq_len[j]) of that image; d_tot / d_non0 receive its
+ * number of k-mers / of k-mers present in the table (d_tot = 0xffffffff for a sequence shorter than
+ * min_len), and every sequence with non0 >= tot * min_frac adds its values to d_hist1024 (uint64
+ * bins, accumulated: zero them first). */
+int yakamd_lookup_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, void *d_out_u16);
+int yakamd_qv_reduce_dev(yak_ch_t *h, const void *d_t_u16, const uint64_t *d_seq_off, const uint32_t *d_seq_len, int64_t n_seq,
+                         int min_len, double min_frac, uint32_t *d_tot, uint32_t *d_non0, uint64_t *d_hist1024);
+
 /* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
 void *yakamd_dev_alloc(size_t bytes);
 void yakamd_dev_free(void *p);

@@ -21,6 +21,11 @@ class Copt(C.Structure):
                 ("pre", C.c_int32), ("n_thread", C.c_int32), ("chunk_size", C.c_int64)]
 
 
+class Qopt(C.Structure):                       # yko_qopt_t == yak_qopt_t (yak.h:33-40)
+    _fields_ = [("print_each", C.c_int32), ("print_err_kmer", C.c_int32), ("min_len", C.c_int32),
+                ("n_threads", C.c_int32), ("min_frac", C.c_double), ("fpr", C.c_double), ("chunk_size", C.c_int64)]
+
+
 class Ch(C.Structure):
     _fields_ = [("k", C.c_int), ("pre", C.c_int), ("n_hash", C.c_int), ("n_shift", C.c_int),
                 ("tot", C.c_uint64), ("h", C.c_void_p)]
@@ -67,6 +72,8 @@ def lib():
         L.yko_count_mem.argtypes = [C.c_char_p, C.c_int64, P(Copt), P(Ch)]
         L.yko_count_protocol_mem.restype = P(Ch)
         L.yko_count_protocol_mem.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, P(Copt)]
+        L.yko_qopt_init.argtypes = [P(Qopt)]
+        L.yko_qv.restype = C.c_int; L.yko_qv.argtypes = [P(Qopt), C.c_char_p, P(Ch), P(C.c_int64), C.c_void_p]
         L.yko_count_protocol_file.restype = P(Ch)
         L.yko_count_protocol_file.argtypes = [C.c_char_p, C.c_char_p, P(Copt)]
         _lib = L
@@ -110,3 +117,30 @@ def ref_count_cli(args, timeout=3600):
     t = time.time()
     subprocess.run([REF_BIN, "count"] + list(args), check=True, stderr=subprocess.DEVNULL, timeout=timeout)
     return time.time() - t
+
+
+def qv_counts(table_fn, seq_fn, min_len=0, min_frac=0.5):
+    """counting step of `yak qv` (qv.c:34-135) -> the 1024-bin histogram"""
+    L = lib()
+    h = L.yko_ch_restore(table_fn.encode())
+    o = Qopt()
+    L.yko_qopt_init(C.byref(o))
+    o.min_len, o.min_frac = min_len, min_frac
+    cnt = (C.c_int64 * 1024)()
+    assert L.yko_qv(C.byref(o), seq_fn.encode(), h, cnt, None) == 0
+    L.yko_ch_destroy(h)
+    return list(cnt)
+
+
+def parse_qv_output(text):
+    """stdout of `yak qv` / `yko qv` / `yak-amd qv` -> ({count: (table k-mers, input k-mers)}, sorted SQ lines, sorted EK lines)"""
+    ct, sq, ek = {}, [], []
+    for l in text.splitlines():
+        f = l.split("\t")
+        if f[0] == "CT":
+            ct[int(f[1])] = (int(f[2]), int(f[3]))
+        elif f[0] == "SQ":
+            sq.append(l)
+        elif f[0] == "EK":
+            ek.append(l)
+    return ct, sorted(sq), sorted(ek)

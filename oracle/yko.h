@@ -102,6 +102,19 @@ yko_ch_t *yko_count_protocol_mem(const uint8_t *b1, int64_t n1, const uint8_t *b
                                  const yko_copt_t *opt);
 yko_ch_t *yko_count_protocol_file(const char *fn1, const char *fn2, const yko_copt_t *opt);
 
+/* ---- `yak qv` counting step (qv.c:34-135); the statistics of yak_qv_solve are host math outside the path ---- */
+typedef struct {                                              /* yak.h:33-40 */
+	int32_t print_each, print_err_kmer;
+	int32_t min_len;
+	int32_t n_threads;
+	double min_frac;
+	double fpr;
+	int64_t chunk_size;
+} yko_qopt_t;
+void yko_qopt_init(yko_qopt_t *o);
+/* cnt: 1 << YKO_COUNTER_BITS bins; `out` (FILE*, may be NULL) receives the EK / SQ lines */
+int yko_qv(const yko_qopt_t *opt, const char *fn, const yko_ch_t *ch, int64_t *cnt, void *out);
+
 #ifdef __cplusplus
 }
 #endif

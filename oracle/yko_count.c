@@ -99,7 +99,7 @@ typedef struct {
 	gzFile fp;
 	unsigned char *buf;
 	int beg, end, eof, last;
-	fxstr_t seq, qual;
+	fxstr_t seq, qual, name;
 } fx_t;
 
 #define FX_BUF 16384
@@ -149,8 +149,8 @@ static int64_t fx_read(fx_t *f)
 		if (c == -1) return -1;
 		f->last = c;
 	}
-	f->seq.l = f->qual.l = 0;
-	if (fx_until(f, 0, 0, &d) < 0) return -1;               /* name */
+	f->seq.l = f->qual.l = f->name.l = 0;
+	if (fx_until(f, 0, &f->name, &d) < 0) return -1;        /* name */
 	if (d != '\n') fx_until(f, 1, 0, 0);                     /* comment */
 	while ((c = fx_getc(f)) != -1 && c != '>' && c != '+' && c != '@') {
 		unsigned char ch = (unsigned char)c;
@@ -282,4 +282,72 @@ yko_ch_t *yko_count_protocol_file(const char *fn1, const char *fn2, const yko_co
 {
 	yko_ch_t *h = yko_count_file(fn1, opt, 0);
 	return finish_protocol(h, opt, fn2 ? fn2 : fn1, 0, 0);
+}
+
+
+/* ------------------------------------------------------------------ yak qv counting step (qv.c:34-135)
+ * For every sequence of at least min_len bases: t = max(0, count in the table) of each k-mer
+ * (canonical, non-ACGT resets the window); tot = number of k-mers, non0 = those present.  Lines the
+ * reference prints ("EK" per absent k-mer with -E, "SQ" per sequence with -p) go to `out`.  Sequences
+ * with non0 >= tot * min_frac add all their t values to the 1024-bin histogram cnt[]. */
+#include <math.h>
+void yko_qopt_init(yko_qopt_t *o)                            /* qv.c:137-144 */
+{
+	memset(o, 0, sizeof(*o));
+	o->chunk_size = 1000000000; o->n_threads = 4; o->min_frac = 0.5; o->fpr = 0.00004;
+}
+
+int yko_qv(const yko_qopt_t *opt, const char *fn, const yko_ch_t *ch, int64_t *cnt, void *out_)
+{
+	fx_t f;
+	FILE *out = (FILE*)out_;
+	int32_t *tv = 0;
+	size_t tv_m = 0;
+	const int k = ch->k;
+	if (k >= 32) return -1;                                   /* qv.c:44 asserts */
+	memset(&f, 0, sizeof(f));
+	f.fp = (fn && strcmp(fn, "-")) ? gzopen(fn, "r") : gzdopen(0, "r");
+	if (!f.fp) return -1;
+	f.buf = (unsigned char*)malloc(FX_BUF);
+	memset(cnt, 0, sizeof(int64_t) << YKO_COUNTER_BITS);
+	const uint64_t mask = (1ULL << 2 * k) - 1;
+	const int shift = 2 * (k - 1);
+	int64_t len;
+	while ((len = fx_read(&f)) >= 0) {
+		int64_t i;
+		int l = 0, tot = 0, non0 = 0;
+		uint64_t x0 = 0, x1 = 0;
+		if (f.name.s) f.name.s[f.name.l] = 0;
+		if (len < opt->min_len) continue;
+		if ((size_t)len > tv_m) { tv_m = (size_t)len * 2; tv = (int32_t*)realloc(tv, tv_m * sizeof(int32_t)); }
+		for (i = 0; i < len; ++i) {
+			const int c = yko_nt4[(uint8_t)f.seq.s[i]];
+			if (c < 4) {
+				x0 = (x0 << 2 | (uint64_t)c) & mask;
+				x1 = x1 >> 2 | (uint64_t)(3 - c) << shift;
+				if (++l >= k) {
+					int t = yko_ch_get(ch, yko_hash64(x0 < x1 ? x0 : x1, mask));
+					if (t < 0) t = 0;
+					if (t > 0) ++non0;
+					else if (opt->print_err_kmer && out) fprintf(out, "EK\t%s\t%d\n", f.name.s ? f.name.s : "", (int)(i + 1 - k));
+					tv[tot++] = t;
+				}
+			} else l = 0, x0 = x1 = 0;
+		}
+		if (opt->print_each && out) {
+			double qv = -1.0;
+			if (tot > 0) {
+				if (non0 > 0) {
+					if (tot > non0) { qv = log((double)tot / non0) / k; qv = -4.3429448190325175 * log(qv); }
+					else qv = 99.0;
+				} else qv = 0.0;
+			}
+			fprintf(out, "SQ\t%s\t%d\t%d\t%d\t%.2f\n", f.name.s ? f.name.s : "", (int)len, tot, non0, qv);
+		}
+		if (non0 < tot * opt->min_frac) continue;
+		for (i = 0; i < tot; ++i) ++cnt[tv[i]];
+	}
+	free(tv); free(f.buf); free(f.seq.s); free(f.qual.s); free(f.name.s);
+	gzclose(f.fp);
+	return 0;
 }

@@ -51,6 +51,14 @@ CASES = {
 }
 
 
+# `yak qv` (lookup-only path): table = a stored .yak above, query = synthetic contigs of the same genome
+QV_CASES = {
+    "qv_b24_k31":       ("b24_k31", dict(n=30, l=1000, g=2500, s=5, a=1, e=0.01, N=0.001), ["-p", "-E"]),
+    "qv_b24_k31_filt":  ("b24_k31", dict(n=30, l=1000, g=2500, s=5, a=1, e=0.05, N=0.001), ["-p", "-f", "0.25", "-l", "1000"]),
+    "qv_nb_k21":        ("nb_k21",  dict(n=12, l=3000, g=5000, s=2, a=1, e=0.002),          ["-p", "-K", "5k"]),
+}
+
+
 def synth_args(d):
     a = ["-n", str(d["n"]), "-l", str(d["l"]), "-g", str(d["g"]), "-s", str(d["s"])]
     if d.get("a"):
@@ -138,6 +146,19 @@ def main():
         man[name] = desc
         print(name, len(data), desc["md5"])
     json.dump(man, open(os.path.join(G, "manifest.json"), "w"), indent=1)
+    sys.path.insert(0, ROOT)
+    from oracle.pyoracle import parse_qv_output
+    qv = {}
+    for name, (table, inp, args) in QV_CASES.items():
+        fn = os.path.join(tmp, name + ".fa")
+        subprocess.check_call([SYNTH] + synth_args(inp) + ["-o", fn])
+        txt = subprocess.run([os.path.join(REF, "yak"), "qv"] + args + [os.path.join(G, table + ".yak"), fn], check=True,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        ct, sq, ek = parse_qv_output(txt)
+        qv[name] = {"table": table, "synth": inp, "args": args, "cnt": {str(c): v[1] for c, v in ct.items() if v[1]},
+                    "sq": sq, "n_ek": len(ek), "ek_md5": hashlib.md5("\n".join(ek).encode()).hexdigest()}
+        print(name, sum(v[1] for v in ct.values()), len(sq), len(ek))
+    json.dump(qv, open(os.path.join(G, "qv.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,147 @@
+"""The lookup-only path (`yak qv`, reference qv.c:34-135).
+CPU: the oracle's restatement against the reference-produced golden vectors (tests/golden/qv.json)
+and, where the prebuilt reference binary exists, against `yak qv` itself.
+GPU: the library (yak_ch_restore + yak_qv through the C ABI, the `yak-amd qv` caller, and the two
+device entry points on their own) against the oracle and the golden vectors."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+REF = os.path.join(ROOT, "oracle", "_ref", "yak")
+YKO = os.path.join(ROOT, "oracle", "yko")
+YAM = os.path.join(ROOT, "yak_amd", "yak-amd")
+SYN = os.path.join(ROOT, "tools", "yaksynth")
+QV = json.load(open(os.path.join(GOLD, "qv.json")))
+
+
+def query_file(desc, tmp_path):
+    d = desc["synth"]
+    fn = str(tmp_path / "q.fa")
+    a = [SYN, "-a", "-n", str(d["n"]), "-l", str(d["l"]), "-g", str(d["g"]), "-s", str(d["s"]), "-e", str(d["e"]), "-o", fn]
+    if "N" in d:
+        a += ["-N", str(d["N"])]
+    subprocess.check_call(a)
+    return fn
+
+
+def check_against_golden(out_text, desc, oracle):
+    ct, sq, ek = oracle.parse_qv_output(out_text)
+    assert {str(c): v[1] for c, v in ct.items() if v[1]} == desc["cnt"]
+    assert sq == desc["sq"]
+    assert (len(ek), hashlib.md5("\n".join(ek).encode()).hexdigest()) == (desc["n_ek"], desc["ek_md5"])
+
+
+@pytest.mark.parametrize("name", sorted(QV))
+def test_oracle_qv_matches_reference_golden(name, oracle, tmp_path):
+    desc = QV[name]
+    out = subprocess.run([YKO, "qv"] + desc["args"] + [os.path.join(GOLD, desc["table"] + ".yak"), query_file(desc, tmp_path)],
+                         check=True, stdout=subprocess.PIPE).stdout.decode()
+    check_against_golden(out, desc, oracle)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="prebuilt reference binary not present")
+@pytest.mark.parametrize("args", [["-p", "-E"], ["-p", "-l", "2500"], ["-f", "0.88", "-p"], ["-K", "10k", "-p"]], ids=lambda a: "".join(a))
+def test_oracle_qv_cli_equals_reference_cli(args, oracle, tmp_path):
+    fq, fa, tab = str(tmp_path / "r.fq"), str(tmp_path / "a.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([SYN, "-n", "5000", "-l", "150", "-g", "30000", "-s", "11", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "25", "-l", "3000", "-g", "30000", "-s", "11", "-e", "0.004", "-N", "0.0005", "-o", fa])
+    subprocess.run([REF, "count", "-k27", "-b24", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+    a = oracle.parse_qv_output(subprocess.run([REF, "qv"] + args + [tab, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode())
+    b = oracle.parse_qv_output(subprocess.run([YKO, "qv"] + args + [tab, fa], check=True, stdout=subprocess.PIPE).stdout.decode())
+    assert a == b and sum(v[1] for v in a[0].values()) > 0
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ya():
+    import yak_amd
+    if yak_amd.lib().yakamd_device_count() < 1:
+        pytest.skip("no MI355X visible")
+    return yak_amd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(QV))
+def test_device_qv_matches_reference_golden(name, ya, oracle, tmp_path):
+    desc = QV[name]
+    out = subprocess.run([YAM, "qv"] + desc["args"] + [os.path.join(GOLD, desc["table"] + ".yak"), query_file(desc, tmp_path)],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+    check_against_golden(out, desc, oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", [dict(), dict(min_len=2500), dict(min_frac=0.88), dict(min_frac=0.0, min_len=100), dict(chunk=10000)],
+                         ids=["default", "min_len", "min_frac", "all_pass", "small_batches"])
+@pytest.mark.parametrize("k,bf", [(27, 24), (21, 0), (15, 0)])
+def test_yak_qv_through_the_c_abi(opt, k, bf, ya, oracle, tmp_path):
+    fq, fa, tab = str(tmp_path / "r.fq"), str(tmp_path / "a.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([SYN, "-n", "20000", "-l", "150", "-g", "100000", "-s", "13", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "60", "-l", "4000", "-g", "100000", "-s", "13", "-e", "0.004", "-N", "0.0005", "-o", fa])
+    subprocess.run([YKO, "count", f"-k{k}", f"-b{bf}", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+    o2 = {k_: v for k_, v in opt.items() if k_ != "chunk"}
+    want = oracle.qv_counts(tab, fa, **o2)
+    assert ya.qv_counts(tab, fa, **opt) == want and sum(want) > 0
+
+
+@pytest.mark.gpu
+def test_lookup_and_reduce_entry_points(ya, oracle, synth, tmp_path):
+    """yakamd_lookup_dev / yakamd_qv_reduce_dev on their own: per-position counts against
+    yko_ch_get on the oracle's table; ragged sequences incl. empty, shorter than k and runs of N"""
+    import numpy as np
+    L, O = ya.lib(), oracle.lib()
+    K = 25
+    reads = synth(3000, g=20000, s=3)
+    o = oracle.copt(k=K)
+    ho = O.yko_count_protocol_mem(reads, len(reads), None, 0, C.byref(o))
+    tab = str(tmp_path / "t.yak")
+    assert O.yko_ch_dump(ho, tab.encode()) == 0
+    h = L.yak_ch_restore(tab.encode())
+    assert h
+    other = synth(40, g=20000, s=3, e=0.02)                     # same genome, more errors: absent k-mers
+    seqs = [b"", b"ACGT", b"N" * 40] + [other[i * 151:i * 151 + 150] for i in range(40)] + [reads[:1500].replace(b"\n", b"A")]
+    img = b"".join(x + b"\n" for x in seqs)
+    off = np.cumsum([0] + [len(x) + 1 for x in seqs[:-1]]).astype(np.uint64)
+    ln = np.array([len(x) for x in seqs], dtype=np.uint32)
+    # expected per-position values from the oracle
+    hh = np.empty(len(img), dtype=np.uint64); tt = np.empty(len(img), dtype=np.uint32)
+    m = O.yko_extract_pos(K, img, len(img), hh.ctypes.data, tt.ctypes.data)
+    want = np.full(len(img), 0xffff, dtype=np.uint16)
+    for j in range(m):
+        want[tt[j]] = max(0, O.yko_ch_get(ho, int(hh[j])))
+    pad = (len(img) + 15) // 16 * 16
+    d_b, d_t = L.yakamd_dev_alloc(pad), L.yakamd_dev_alloc(2 * pad)
+    assert L.yakamd_memcpy_h2d(d_b, img + b"\n" * (pad - len(img)), pad) == 0
+    assert L.yakamd_lookup_dev(h, d_b, len(img), d_t) == 0
+    got = np.empty(len(img), dtype=np.uint16)
+    assert L.yakamd_memcpy_d2h(got.ctypes.data, d_t, 2 * len(img)) == 0
+    assert np.array_equal(got, want) and (want == 0).sum() > 0 and ((want > 0) & (want < 0xffff)).sum() > 0
+    ns = len(seqs)
+    d_off, d_len, d_tot, d_non0, d_hist = (L.yakamd_dev_alloc(8 * ns), L.yakamd_dev_alloc(4 * ns), L.yakamd_dev_alloc(4 * ns),
+                                           L.yakamd_dev_alloc(4 * ns), L.yakamd_dev_alloc(8 * 1024))
+    assert L.yakamd_memcpy_h2d(d_off, off.tobytes(), 8 * ns) == 0 and L.yakamd_memcpy_h2d(d_len, ln.tobytes(), 4 * ns) == 0
+    for min_len, min_frac in ((0, 0.5), (100, 0.9), (0, 0.0)):
+        assert L.yakamd_memcpy_h2d(d_hist, bytes(8 * 1024), 8 * 1024) == 0
+        assert L.yakamd_qv_reduce_dev(h, d_t, d_off, d_len, ns, min_len, min_frac, d_tot, d_non0, d_hist) == 0
+        tot, non0, hist = np.empty(ns, np.uint32), np.empty(ns, np.uint32), np.empty(1024, np.uint64)
+        L.yakamd_memcpy_d2h(tot.ctypes.data, d_tot, 4 * ns); L.yakamd_memcpy_d2h(non0.ctypes.data, d_non0, 4 * ns)
+        L.yakamd_memcpy_d2h(hist.ctypes.data, d_hist, 8 * 1024)
+        eh = np.zeros(1024, np.uint64)
+        for j in range(ns):
+            v = want[int(off[j]):int(off[j]) + int(ln[j])]
+            v = v[v != 0xffff]
+            if ln[j] < min_len:
+                assert tot[j] == 0xffffffff
+                continue
+            assert (tot[j], non0[j]) == (len(v), int((v > 0).sum()))
+            if not (int((v > 0).sum()) < len(v) * min_frac):
+                eh += np.bincount(v, minlength=1024).astype(np.uint64)
+        assert np.array_equal(hist, eh)
+    for p_ in (d_b, d_t, d_off, d_len, d_tot, d_non0, d_hist):
+        L.yakamd_dev_free(p_)
+    L.yak_ch_destroy(h); O.yko_ch_destroy(ho)

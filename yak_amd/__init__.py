@@ -20,7 +20,7 @@ YAK_H_SYMBOLS = [
     "yak_copt_init", "yak_bf_init", "yak_bf_destroy", "yak_bf_insert",
     "yak_ch_init", "yak_ch_destroy", "yak_ch_destroy_bf", "yak_ch_insert_list", "yak_ch_get",
     "yak_ch_inc", "yak_ch_getseq", "yak_ch_clear", "yak_ch_hist", "yak_ch_shrink", "yak_ch_dump",
-    "yak_ch_restore", "yak_count", "yak_verbose", "seq_nt4_table",
+    "yak_ch_restore", "yak_count", "yak_verbose", "seq_nt4_table", "yak_qopt_init", "yak_qv",
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
@@ -29,6 +29,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
+    "yakamd_lookup_dev", "yakamd_qv_reduce_dev",
 ]
 
 
@@ -40,6 +41,11 @@ class CoptT(C.Structure):                      # yak_copt_t, include/yak.h (refe
 class ChT(C.Structure):                        # yak_ch_t (reference yak.h:61-65)
     _fields_ = [("k", C.c_int), ("pre", C.c_int), ("n_hash", C.c_int), ("n_shift", C.c_int),
                 ("tot", C.c_uint64), ("h", C.c_void_p)]
+
+
+class QoptT(C.Structure):                      # yak_qopt_t (reference yak.h:33-40)
+    _fields_ = [("print_each", C.c_int32), ("print_err_kmer", C.c_int32), ("min_len", C.c_int32),
+                ("n_threads", C.c_int32), ("min_frac", C.c_double), ("fpr", C.c_double), ("chunk_size", C.c_int64)]
 
 
 class StatsT(C.Structure):                     # yakamd_stats_t
@@ -113,6 +119,12 @@ def lib():
     L.yakamd_count_partitioned_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, P(C.c_uint64)]
     L.yakamd_count_hashes_dev.restype = C.c_int
     L.yakamd_count_hashes_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64]
+    L.yak_qopt_init.argtypes = [P(QoptT)]
+    L.yak_qv.restype = None; L.yak_qv.argtypes = [P(QoptT), C.c_char_p, P(ChT), P(C.c_int64)]
+    L.yakamd_lookup_dev.restype = C.c_int; L.yakamd_lookup_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_void_p]
+    L.yakamd_qv_reduce_dev.restype = C.c_int
+    L.yakamd_qv_reduce_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
     L.yakamd_dev_alloc.restype = C.c_void_p; L.yakamd_dev_alloc.argtypes = [C.c_size_t]
     L.yakamd_dev_free.argtypes = [C.c_void_p]
     L.yakamd_memcpy_h2d.restype = C.c_int; L.yakamd_memcpy_h2d.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -217,3 +229,19 @@ def count_protocol_host(buf1, k=31, pre=10, n_hash=4, bf_shift=0, buf2=None):
         return t.dump_bytes(), t.tot
     finally:
         t.close()
+
+
+def qv_counts(table_fn, seq_fn, min_len=0, min_frac=0.5, chunk=1000000000):
+    """`yak qv` counting step through the C ABI (yak_ch_restore + yak_qv): the 1024-bin histogram of
+    table counts over the k-mers of the accepted sequences"""
+    L = lib()
+    h = L.yak_ch_restore(table_fn.encode())
+    if not h:
+        raise RuntimeError("yak_ch_restore failed: " + _err())
+    o = QoptT()
+    L.yak_qopt_init(C.byref(o))
+    o.min_len, o.min_frac, o.chunk_size = min_len, min_frac, chunk
+    cnt = (C.c_int64 * 1024)()
+    L.yak_qv(C.byref(o), seq_fn.encode(), h, cnt)
+    L.yak_ch_destroy(h)
+    return list(cnt)

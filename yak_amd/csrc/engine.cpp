@@ -741,6 +741,31 @@ extern "C" int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int6
 	return 0;
 }
 
+/* ---- lookup-only path (yak qv) ---- */
+extern "C" int yakamd_lookup_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, void *d_out_u16)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c) return fail("not an engine table");
+	if (c->in_pass) return fail("lookup during an open pass");
+	if (c->k < 1 || c->k >= 32) return fail("lookup: k must be below 32 (reference qv.c:44)");
+	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
+	HIPCK(hipSetDevice(c->dev));
+	yk_launch_lookup((const uint8_t*)d_bases, n_bytes, c->k, img_view(c), (unsigned short*)d_out_u16, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int yakamd_qv_reduce_dev(yak_ch_t *h, const void *d_t_u16, const uint64_t *d_seq_off, const uint32_t *d_seq_len, int64_t n_seq,
+                                    int min_len, double min_frac, uint32_t *d_tot, uint32_t *d_non0, uint64_t *d_hist1024)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c) return fail("not an engine table");
+	HIPCK(hipSetDevice(c->dev));
+	yk_launch_qv_reduce((const unsigned short*)d_t_u16, (const u64*)d_seq_off, d_seq_len, n_seq, min_len, min_frac, d_tot, d_non0, (u64*)d_hist1024, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
 extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_bytes, void *d_hash, void *d_t,
                                       int pre, int plo, int phi, void *stream)
 {

@@ -524,6 +524,77 @@ __device__ __forceinline__ int64_t img_find(const ImgView &img, u64 key)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * lookup-only path (`yak qv`, reference qv.c:34-86): t = max(0, yak_ch_get()) of the k-mer ENDING
+ * at every position of a base image (QV_NOKMER where none ends: window shorter than k or holding a
+ * non-ACGT byte); then per sequence tot = k-mers, non0 = present ones, and the sequences with
+ * non0 >= tot * min_frac add all their t values to the 1024-bin histogram.
+ * ------------------------------------------------------------------------------------------ */
+#define QV_NOKMER 0xffffu
+__global__ __launch_bounds__(XT_THREADS)
+void k_lookup(const uint8_t *__restrict__ bases, int64_t n, int k, ImgView img, unsigned short *__restrict__ out)
+{
+	__shared__ XtTile S;
+	xt_init(S);
+	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	for (int t = 0; t < XP_T; ++t) {
+		const int64_t tile0 = ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
+		if (tile0 >= n) break;
+		xt_load(S, bases, tile0, n);
+#pragma unroll 4
+		for (int r = 0; r < XT_ROUNDS; ++r) {
+			const int q = r * XT_THREADS + (int)threadIdx.x;
+			u64 h;
+			const bool ok = xt_kmer(S, q, k, mask, kones, tile0, n, &h);
+			if (tile0 + q < n) {
+				u32 v = QV_NOKMER;
+				if (ok) { const int64_t idx = img_find(img, h); v = idx >= 0 ? (u32)(img.keys[idx] & 1023u) : 0u; }
+				out[tile0 + q] = (unsigned short)v;
+			}
+		}
+		__syncthreads();
+	}
+}
+
+/* one wave per sequence; tot = 0xffffffff marks a sequence below min_len (qv.c:45) */
+__global__ __launch_bounds__(256)
+void k_qv_reduce(const unsigned short *__restrict__ t, const u64 *__restrict__ roff, const u32 *__restrict__ rlen, int64_t n_reads,
+                 int min_len, double min_frac, u32 *tot_out, u32 *non0_out, unsigned long long *hist)
+{
+	__shared__ u32 s_hist[1024];
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (u32 i = threadIdx.x; i < 1024; i += 256) s_hist[i] = 0;
+	__syncthreads();
+	for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n_reads; r += (int64_t)gridDim.x * 4) {
+		const u64 off = roff[r];
+		const u32 len = rlen[r];
+		if ((int64_t)len < (int64_t)min_len) { if (lane == 0) { tot_out[r] = 0xffffffffu; non0_out[r] = 0; } continue; }
+		u32 tot = 0, non0 = 0;
+		for (u32 i = lane; i < len; i += 64) { const u32 v = t[off + i]; if (v != QV_NOKMER) { ++tot; non0 += v > 0; } }
+		for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o); non0 += __shfl_xor(non0, o); }
+		if (lane == 0) { tot_out[r] = tot; non0_out[r] = non0; }
+		if ((double)non0 < (double)tot * min_frac) continue;                /* qv.c:83 */
+		for (u32 i = lane; i < len; i += 64) { const u32 v = t[off + i]; if (v != QV_NOKMER) atomicAdd(&s_hist[v], 1u); }
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < 1024; i += 256) if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
+}
+
+void yk_launch_lookup(const uint8_t *bases, int64_t n, int k, ImgView img, unsigned short *out, hipStream_t st)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_lookup, dim3(yk_xpart_blocks(n)), dim3(XT_THREADS), 0, st, bases, n, k, img, out);
+}
+
+void yk_launch_qv_reduce(const unsigned short *t, const u64 *roff, const u32 *rlen, int64_t n_reads, int min_len, double min_frac,
+                         u32 *tot_out, u32 *non0_out, u64 *hist, hipStream_t st)
+{
+	if (n_reads <= 0) return;
+	const int64_t want = (n_reads + 3) / 4;
+	hipLaunchKernelGGL(k_qv_reduce, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, t, roff, rlen, n_reads, min_len, min_frac,
+	                   tot_out, non0_out, (unsigned long long*)hist);
+}
+
+/* ------------------------------------------------------------------------------------------
  * accumulator table (our own layout: one 32-B slot per distinct k-mer, linear probing).
  * Slot index = prefix-major: the high bits select the sub-table region so that a later
  * prefix-partitioned pass touches one contiguous region per sub-table.

@@ -1,5 +1,5 @@
 /*
- * main.c -- `yak-amd count`: the caller side of the hot path, i.e. what reference main.c:13-64
+ * main.c -- `yak-amd count` (and `yak-amd qv`): the caller side of the hot path, i.e. what reference main.c:13-64
  * (main_count) does, written in C against include/yak.h only.  It exists to show that the
  * library is a drop-in: the protocol below is the reference's, line for line in meaning
  * (count -> [destroy_bf, clear, second pass, shrink] -> dump).
@@ -20,14 +20,47 @@ static long long parse_num(const char *s)                    /* K/M/G suffixes a
 	return (long long)(x + .499);
 }
 
+/* `yak-amd qv`: the table side of reference main.c:163-215 (main_qv) -- restore, histogram, the
+ * device lookup of every k-mer of <seq.fa>.  The statistics of yak_qv_solve (FR/ER/CV/QV lines and
+ * the fourth CT column) are host arithmetic outside this library; a reference build keeps them. */
+static int main_qv(int argc, char *argv[])
+{
+	yak_qopt_t opt;
+	yak_ch_t *ch;
+	int64_t cnt[YAK_N_COUNTS], hist[YAK_N_COUNTS];
+	int c, i;
+	yak_qopt_init(&opt);
+	while ((c = getopt(argc, argv, "K:t:l:f:pe:E")) >= 0) {
+		if (c == 'K') opt.chunk_size = parse_num(optarg);
+		else if (c == 'l') opt.min_len = (int32_t)parse_num(optarg);
+		else if (c == 'f') opt.min_frac = atof(optarg);
+		else if (c == 't') opt.n_threads = atoi(optarg);
+		else if (c == 'p') opt.print_each = 1;
+		else if (c == 'E') opt.print_err_kmer = 1;
+		else if (c == 'e') opt.fpr = atof(optarg);
+	}
+	if (argc - optind < 2) {
+		fprintf(stderr, "Usage: yak-amd qv [-l min_len] [-f min_frac] [-p] [-E] [-K batch] <kmer.hash> <seq.fa>\n");
+		return 1;
+	}
+	ch = yak_ch_restore(argv[optind]);
+	if (ch == 0) { fprintf(stderr, "ERROR: failed to load '%s' (or no MI355X visible)\n", argv[optind]); return 1; }
+	yak_ch_hist(ch, hist, opt.n_threads);
+	yak_qv(&opt, argv[optind + 1], ch, cnt);
+	for (i = YAK_N_COUNTS - 1; i >= 0; --i) printf("CT\t%d\t%ld\t%ld\n", i, (long)hist[i], (long)cnt[i]);
+	yak_ch_destroy(ch);
+	return 0;
+}
+
 int main(int argc, char *argv[])
 {
 	yak_copt_t opt;
 	yak_ch_t *h;
 	const char *fn_out = 0;
 	int c;
+	if (argc >= 2 && strcmp(argv[1], "qv") == 0) return main_qv(argc - 1, argv + 1);
 	if (argc < 2 || strcmp(argv[1], "count") != 0) {
-		fprintf(stderr, "Usage: yak-amd count [options] <in.fa> [in.fa]\n");
+		fprintf(stderr, "Usage: yak-amd count [options] <in.fa> [in.fa]\n       yak-amd qv [options] <kmer.hash> <seq.fa>\n");
 		return 1;
 	}
 	--argc, ++argv;

@@ -15,6 +15,8 @@
 #include <sys/time.h>
 #include <sys/resource.h>
 #include <vector>
+#include <string>
+#include <cmath>
 #include "engine.h"
 
 struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };
@@ -331,7 +333,7 @@ yak_ch_t *yak_ch_restore(const char *fn)
  * ------------------------------------------------------------------------------------------ */
 struct FxReader {
 	gzFile fp; unsigned char *buf; int beg, end, eof, last;
-	std::vector<char> seq; size_t qlen; int qlast;
+	std::vector<char> seq, name; size_t qlen; int qlast;
 	enum { BUF = 1 << 16 };
 	FxReader() : fp(0), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0) {}
 	bool fill() {
@@ -343,7 +345,7 @@ struct FxReader {
 		return true;
 	}
 	int getc() { return fill() ? buf[beg++] : -1; }
-	/* consume through the next delimiter; what: 0 discard, 1 append to seq, 2 count quality bytes */
+	/* consume through the next delimiter; what: 0 discard, 1 append to seq, 2 count quality bytes, 3 append to name */
 	int until(bool line, int what, int *dret) {
 		if (dret) *dret = 0;
 		if (beg >= end && eof) return -1;
@@ -352,6 +354,7 @@ struct FxReader {
 			if (line) { const unsigned char *q = (const unsigned char*)memchr(buf + beg, '\n', end - beg); i = q ? (int)(q - buf) : end; }
 			else while (i < end && !isspace(buf[i])) ++i;
 			if (what == 1) seq.insert(seq.end(), buf + beg, buf + i);
+			else if (what == 3) name.insert(name.end(), buf + beg, buf + i);
 			else if (what == 2 && i > beg) { qlen += i - beg; qlast = buf[i - 1]; }
 			const bool hit = i < end;
 			if (hit && dret) *dret = buf[i];
@@ -369,8 +372,8 @@ struct FxReader {
 			if (c == -1) return -1;
 			last = c;
 		}
-		seq.clear(); qlen = 0; qlast = 0;
-		if (until(false, 0, &d) < 0) return -1;
+		seq.clear(); name.clear(); qlen = 0; qlast = 0;
+		if (until(false, 3, &d) < 0) return -1;
 		if (d != '\n') until(true, 0, 0);
 		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
 			if (c == '\n') continue;
@@ -435,6 +438,94 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	gzclose(fx.fp);
 	if (!ok) { if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
+}
+
+/* reference qv.c:137-144 */
+void yak_qopt_init(yak_qopt_t *opt)
+{
+	memset(opt, 0, sizeof(yak_qopt_t));
+	opt->chunk_size = 1000000000;
+	opt->n_threads = 4;
+	opt->min_frac = 0.5;
+	opt->fpr = 0.00004;
+}
+
+/* reference qv.c:34-135.  The table is already resident on the device; every chunk of sequences is
+ * looked up there (k_lookup), reduced per sequence and binned (k_qv_reduce).  The EK / SQ lines of
+ * -E / -p are printed from the values copied back, in input order (the reference prints them in a
+ * thread-dependent order).  On a device error the function prints a message and leaves cnt zeroed. */
+void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *cnt)
+{
+	const int n_cnt = 1 << YAK_COUNTER_BITS;
+	memset(cnt, 0, n_cnt * sizeof(int64_t));
+	yak_ch_t *h = (yak_ch_t*)ch;
+	if (ch->k >= 32) { fprintf(stderr, "[E::yak_qv] k must be below 32\n"); return; }   /* qv.c:44 asserts */
+	FxReader fx;
+	fx.fp = (fn == 0 || strcmp(fn, "-") == 0) ? gzdopen(0, "r") : gzopen(fn, "r");
+	if (fx.fp == 0) return;
+	fx.buf = (unsigned char*)malloc(FxReader::BUF);
+	uint64_t *d_hist = (uint64_t*)yakamd_dev_alloc(n_cnt * 8);
+	std::vector<uint64_t> zero(n_cnt, 0), h_off;
+	std::vector<uint32_t> h_len, h_tot, h_non0;
+	std::vector<std::string> names;
+	std::vector<char> chunk;
+	std::vector<unsigned short> h_t;
+	bool ok = d_hist && yakamd_memcpy_h2d(d_hist, zero.data(), n_cnt * 8) == 0;
+	int64_t l, sum_len = 0;
+	auto flush = [&]() {
+		const size_t nb = chunk.size(), ns = h_len.size();
+		if (ns == 0) return;
+		chunk.resize((nb + 15) & ~(size_t)15, '\n');
+		void *d_b = yakamd_dev_alloc(chunk.size()), *d_t = yakamd_dev_alloc(chunk.size() * 2);
+		uint64_t *d_off = (uint64_t*)yakamd_dev_alloc(ns * 8);
+		uint32_t *d_len = (uint32_t*)yakamd_dev_alloc(ns * 4), *d_tot = (uint32_t*)yakamd_dev_alloc(ns * 4), *d_non0 = (uint32_t*)yakamd_dev_alloc(ns * 4);
+		ok = ok && d_b && d_t && d_off && d_len && d_tot && d_non0
+		     && yakamd_memcpy_h2d(d_b, chunk.data(), chunk.size()) == 0 && yakamd_memcpy_h2d(d_off, h_off.data(), ns * 8) == 0
+		     && yakamd_memcpy_h2d(d_len, h_len.data(), ns * 4) == 0
+		     && yakamd_lookup_dev(h, d_b, (int64_t)nb, d_t) == 0
+		     && yakamd_qv_reduce_dev(h, d_t, d_off, d_len, (int64_t)ns, opt->min_len, opt->min_frac, d_tot, d_non0, d_hist) == 0;
+		if (ok && (opt->print_each || opt->print_err_kmer)) {
+			h_tot.resize(ns); h_non0.resize(ns);
+			ok = yakamd_memcpy_d2h(h_tot.data(), d_tot, ns * 4) == 0 && yakamd_memcpy_d2h(h_non0.data(), d_non0, ns * 4) == 0;
+			if (ok && opt->print_err_kmer) { h_t.resize(chunk.size()); ok = yakamd_memcpy_d2h(h_t.data(), d_t, chunk.size() * 2) == 0; }
+			for (size_t j = 0; ok && j < ns; ++j) {
+				if (h_tot[j] == 0xffffffffu) continue;                          /* below min_len: qv.c:45 */
+				if (opt->print_err_kmer)
+					for (uint32_t i = 0; i < h_len[j]; ++i)
+						if (h_t[h_off[j] + i] == 0) printf("EK\t%s\t%d\n", names[j].c_str(), (int)(i + 1 - ch->k));
+				if (opt->print_each) {
+					const int tot = (int)h_tot[j], non0 = (int)h_non0[j];
+					double qv = -1.0;
+					if (tot > 0) {
+						if (non0 > 0) {
+							if (tot > non0) { qv = log((double)tot / non0) / ch->k; qv = -4.3429448190325175 * log(qv); }
+							else qv = 99.0;
+						} else qv = 0.0;
+					}
+					printf("SQ\t%s\t%d\t%d\t%d\t%.2f\n", names[j].c_str(), (int)h_len[j], tot, non0, qv);
+				}
+			}
+		}
+		yakamd_dev_free(d_b); yakamd_dev_free(d_t); yakamd_dev_free(d_off); yakamd_dev_free(d_len); yakamd_dev_free(d_tot); yakamd_dev_free(d_non0);
+		fprintf(stderr, "[M::%s] processed %ld sequences\n", "yak_qv", (long)ns);
+		chunk.clear(); h_off.clear(); h_len.clear(); names.clear(); sum_len = 0;
+	};
+	while (ok && (l = fx.next()) >= 0) {                     /* bseq.c:40 */
+		h_off.push_back(chunk.size()); h_len.push_back((uint32_t)l);
+		if (opt->print_each || opt->print_err_kmer) names.emplace_back(fx.name.begin(), fx.name.end());
+		chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end());
+		chunk.push_back('\n');
+		sum_len += l;
+		if (sum_len >= opt->chunk_size || chunk.size() > ((size_t)1 << 31)) flush();   /* bseq.c:54 */
+	}
+	if (ok) flush();
+	std::vector<uint64_t> hh(n_cnt, 0);
+	ok = ok && yakamd_memcpy_d2h(hh.data(), d_hist, n_cnt * 8) == 0;
+	if (ok) for (int i = 0; i < n_cnt; ++i) cnt[i] = (int64_t)hh[i];
+	else fprintf(stderr, "[E::yak_qv] %s\n", yakamd_last_error());
+	yakamd_dev_free(d_hist);
+	free(fx.buf);
+	gzclose(fx.fp);
 }
 
 } /* extern "C" */

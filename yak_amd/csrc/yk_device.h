@@ -87,6 +87,9 @@ void yk_launch_acc_insert(const Rec *rec, int64_t n, u64 t0, AccTab tab, ImgView
 void yk_launch_acc_rehash(AccTab oldt, AccTab newt, hipStream_t st);
 void yk_launch_img_count(const Rec *rec, int64_t n, ImgView img, hipStream_t st);
 size_t yk_img_count_lds_bytes(u32 cap, u32 count);
+void yk_launch_lookup(const uint8_t *bases, int64_t n, int k, ImgView img, unsigned short *out, hipStream_t st);
+void yk_launch_qv_reduce(const unsigned short *t, const u64 *roff, const u32 *rlen, int64_t n_reads, int min_len, double min_frac,
+                         u32 *tot_out, u32 *non0_out, u64 *hist, hipStream_t st);
 int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
