@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
+    ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
 
@@ -253,6 +254,29 @@ def main():
         import __graft_entry__ as ge
         ge.smoke()
 
+    # second kernel family (BASELINE configs[4]): the lookup-only kernel of `yak qv`
+    # on the table just built, over the same resident reads -- a side measurement, never `value`
+    qv_probe = None
+    if not a.no_qv and not sharded:
+        t_q, _, _, _ = step(keep=True)
+        d_t16 = torch.empty(n_bytes, dtype=torch.int16, device=dev)
+        L.yakamd_lookup_dev(t_q.h, d_reads.data_ptr(), n_bytes, d_t16.data_ptr())       # warm-up
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(3):
+            if L.yakamd_lookup_dev(t_q.h, d_reads.data_ptr(), n_bytes, d_t16.data_ptr()) != 0:
+                raise RuntimeError("lookup")
+        torch.cuda.synchronize()
+        ms_q = (time.perf_counter() - tq) / 3 * 1e3
+        n_q = int((d_t16 != -1).sum().item())
+        present = int((d_t16 > 0).sum().item())
+        # algorithmic bytes per looked-up k-mer: 1 (base) + 2 (result) + 8 (table slot)
+        qv_probe = {"kernel": "k_lookup", "kmers_looked_up": n_q, "present": present, "ms": ms_q, "lookups_per_s": n_q / (ms_q * 1e-3),
+                    "achieved_GBs": 11.0 * n_q / (ms_q * 1e-3) / 1e9, "frac_of_hbm_peak": 11.0 * n_q / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "random 64-byte-granule reads bound this kernel: ~6 TB/s / 64 B = ~100 G slot reads/s"}
+        t_q.close()
+        del d_t16
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -324,6 +348,7 @@ def main():
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
         "verify": verify,
+        "qv_lookup_probe": qv_probe,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }
     if not a.no_cpu_baseline:

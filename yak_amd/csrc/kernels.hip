@@ -530,6 +530,27 @@ __device__ __forceinline__ int64_t img_find(const ImgView &img, u64 key)
  * non0 >= tot * min_frac add all their t values to the 1024-bin histogram.
  * ------------------------------------------------------------------------------------------ */
 #define QV_NOKMER 0xffffu
+/* yak_ch_get() clamped at 0 (qv.c:59-60), read-only and on the key array alone: the image keeps every
+ * unused slot at YK_EMPTY (k_replay publishes it so), which no 2k < 64-bit key can equal, so the
+ * `used` bitmap -- a second random 64-byte read per probe -- is not needed here */
+__device__ __forceinline__ u32 img_get_count(const ImgView &img, u64 key)
+{
+	const u32 p = (u32)key & ((1u << img.pre) - 1);
+	const u32 bits = img.bits[p];
+	if (bits == YK_NOCAP) return 0;
+	const u64 kid = key >> img.pre;
+	const u64 *keys = img.keys + img.off[p];
+	const u32 nmask = (1u << bits) - 1;
+	u32 i = yk_h2b((u32)kid, bits);
+	const u32 first = i;
+	for (;;) {
+		const u64 kc = keys[i];
+		if (kc == YK_EMPTY) return 0;
+		if (kc >> 10 == kid) return (u32)(kc & 1023u);
+		i = (i + 1) & nmask;
+		if (i == first) return 0;
+	}
+}
 __global__ __launch_bounds__(XT_THREADS)
 void k_lookup(const uint8_t *__restrict__ bases, int64_t n, int k, ImgView img, unsigned short *__restrict__ out)
 {
@@ -547,7 +568,7 @@ void k_lookup(const uint8_t *__restrict__ bases, int64_t n, int k, ImgView img, 
 			const bool ok = xt_kmer(S, q, k, mask, kones, tile0, n, &h);
 			if (tile0 + q < n) {
 				u32 v = QV_NOKMER;
-				if (ok) { const int64_t idx = img_find(img, h); v = idx >= 0 ? (u32)(img.keys[idx] & 1023u) : 0u; }
+				if (ok) v = img_get_count(img, h);
 				out[tile0 + q] = (unsigned short)v;
 			}
 		}
