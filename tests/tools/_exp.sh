@@ -1,6 +1,3 @@
-timeout 800 python -m pytest tests/test_qv.py -m gpu -x -q 2>&1 | tail -2
-timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify 2>/dev/null | grep "^{" | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print('ms', round(d['ms_per_step'],1), d['qv_lookup_probe'])
-"
+bash tests/tools/prof_stats.sh r01h > gpurun_out/r01h_table.txt 2>&1; tail -22 gpurun_out/r01h_table.txt
+bash tests/tools/prof_pmc.sh r01h > gpurun_out/r01h_pmc_table.txt 2>&1; tail -16 gpurun_out/r01h_pmc_table.txt
+timeout 900 python bench.py > gpurun_out/r01h_bench_default.json 2> gpurun_out/r01h_bench_default.err; tail -c 1500 gpurun_out/r01h_bench_default.json
