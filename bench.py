@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not queue the pass-2 exchange behind pass 1's computation")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
@@ -142,27 +143,43 @@ def main():
     # exchange buffers (sharded path only): 16-byte records {hash, position} grouped by prefix
     if sharded:
         s_rec = torch.empty((n_bytes, 2), dtype=torch.int64, device=dev)
+        s_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)
         h_bstart = (C.c_uint64 * (P + 1))()
 
-    def exchange(create_new):
+    def exchange(create_new, async_op=False):
         """partition this rank's k-mers by sub-table prefix once, then one all-to-all per pass moves
-        every record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI)"""
+        every record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI).  async_op:
+        the all-to-all is queued and a function that waits for it is returned."""
         from yak_amd import shard
         if create_new:
             n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+            send = s_rec[:n]
         else:                                               # counting existing keys only needs the hashes: 8-byte records
-            n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+            n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_hash.data_ptr(), h_bstart)
+            send = s_hash[:n]
         if n < 0:
             raise RuntimeError("partition failed")
-        out = shard.exchange_partitioned(s_rec[:n] if create_new else s_rec.reshape(-1)[:n], list(h_bstart), P)
-        torch.cuda.synchronize()
+        out = shard.exchange_partitioned(send, list(h_bstart), P, async_op=async_op)
+        if not async_op:
+            torch.cuda.synchronize()
         return out
+
+    pending = [None]      # the pass-2 exchange of the step in flight (queued while pass 1 computes)
 
     def one_pass(t, create_new):
         if not sharded:
             t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
-        segs = exchange(create_new)
+        if create_new:
+            segs = exchange(1)
+            # both passes read the same input (main.c:53-57), so the second pass's k-mers can travel while
+            # the first pass is still counting: queue that all-to-all now, wait for it when pass 2 starts
+            if a.bf_shift > 0 and not a.no_overlap:
+                pending[0] = exchange(0, async_op=True)
+        else:
+            segs = pending[0]() if pending[0] is not None else exchange(0)
+            pending[0] = None
+            torch.cuda.synchronize()
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
         for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job

@@ -1,3 +1,8 @@
-bash tests/tools/prof_stats.sh r01h > gpurun_out/r01h_table.txt 2>&1; tail -22 gpurun_out/r01h_table.txt
-bash tests/tools/prof_pmc.sh r01h > gpurun_out/r01h_pmc_table.txt 2>&1; tail -16 gpurun_out/r01h_pmc_table.txt
-timeout 900 python bench.py > gpurun_out/r01h_bench_default.json 2> gpurun_out/r01h_bench_default.err; tail -c 1500 gpurun_out/r01h_bench_default.json
+for fe in "--force-exchange" "--force-exchange --no-overlap"; do
+timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-qv $fe 2>/tmp/fe.err | grep "^{" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$fe', 'ms', round(d['ms_per_step'],1), d['final_distinct'], d['phase_wall_ms_last_step'])
+" || tail -5 /tmp/fe.err
+done
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 700 bash tests/tools/two_ranks_one_gpu.sh 1000000 2>&1 | tail -3

@@ -57,9 +57,11 @@ def _a2a(recv, send, recv_counts, send_counts):
 MAX_MSG_ELEMS = 1 << 26      # per-peer message size cap (elements): RCCL/torch mis-handle messages of several GB
 
 
-def _a2a_rounds(recv, send, recv_counts, send_counts):
+def _a2a_rounds(recv, send, recv_counts, send_counts, async_op=False):
     """all-to-all of variable-size segments in rounds of at most MAX_MSG_ELEMS elements per peer;
-    every round writes straight into its final place (views), so `recv` ends up grouped by source"""
+    every round writes straight into its final place (views), so `recv` ends up grouped by source.
+    async_op (RCCL only): the rounds are queued on the collective stream and a list of work handles is
+    returned for the caller to wait on -- the exchange then overlaps whatever the caller runs next."""
     world = dist.get_world_size()
     so, ro = [0], [0]
     for c in send_counts:
@@ -70,6 +72,7 @@ def _a2a_rounds(recv, send, recv_counts, send_counts):
     if world > 1:
         dist.all_reduce(biggest, op=dist.ReduceOp.MAX)           # every rank must run the same number of rounds
     rounds = (int(biggest.item()) + MAX_MSG_ELEMS - 1) // MAX_MSG_ELEMS
+    works = []
     for r in range(rounds):
         a, b = r * MAX_MSG_ELEMS, (r + 1) * MAX_MSG_ELEMS
         sc = [max(0, min(c, b) - a) if c > a else 0 for c in send_counts]
@@ -83,8 +86,11 @@ def _a2a_rounds(recv, send, recv_counts, send_counts):
                 recv[ro[s_] + a:ro[s_] + a + rc[s_]] = out[o:o + rc[s_]]
                 o += rc[s_]
         else:
-            dist.all_to_all([recv[ro[s_] + a:ro[s_] + a + rc[s_]] for s_ in range(world)],
-                            [send[so[d] + a:so[d] + a + sc[d]] for d in range(world)])
+            w = dist.all_to_all([recv[ro[s_] + a:ro[s_] + a + rc[s_]] for s_ in range(world)],
+                                [send[so[d] + a:so[d] + a + sc[d]] for d in range(world)], async_op=async_op)
+            if async_op:
+                works.append(w)
+    return works
 
 
 def exchange(send_hash, send_t, send_counts):
@@ -128,13 +134,15 @@ def exchange_hashes(send_rec, bstart, n_prefix):
     return recv_hash
 
 
-def exchange_partitioned(send_rec, bstart, n_prefix):
+def exchange_partitioned(send_rec, bstart, n_prefix, async_op=False):
     """send_rec: int64 tensor of records grouped by sub-table prefix (ascending) -- [n, 2] {hash,
     position} for a counting pass (yakamd_partition_dev), or [n] bare hashes for a pass that only
     counts existing keys (yakamd_partition_hashes_dev); `bstart` the n_prefix + 1 group offsets.
     Owners are contiguous prefix ranges, so the per-destination send buffers are slices.  Returns a
     list, in source-rank order, of (recv_slice, offsets[n_prefix + 1] of that slice) ready for
-    yakamd_feed_partitioned_dev / yakamd_count_partitioned_dev."""
+    yakamd_feed_partitioned_dev / yakamd_count_partitioned_dev.
+    async_op: the payload all-to-all is only queued; the return value is a function that waits for
+    it and yields that list (send_rec must stay untouched until then)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = send_rec.device
     width = send_rec.shape[1] if send_rec.dim() == 2 else 1
@@ -149,14 +157,18 @@ def exchange_partitioned(send_rec, bstart, n_prefix):
     recv_counts = [r[-1] for r in rel_in]
     flat = send_rec.reshape(-1)
     recv = torch.empty(width * sum(recv_counts), dtype=torch.int64, device=dev)
-    _a2a_rounds(recv, flat, [width * c for c in recv_counts], [width * c for c in send_counts])
-    if width > 1:
-        recv = recv.reshape(-1, width)
-    lo = rank * per
-    out, off = [], 0
-    for src in range(world):
-        m = recv_counts[src]
-        offs = [0] * lo + rel_in[src] + [m] * (n_prefix - lo - per)
-        out.append((recv[off:off + m], offs))
-        off += m
-    return out
+    works = _a2a_rounds(recv, flat, [width * c for c in recv_counts], [width * c for c in send_counts], async_op=async_op)
+
+    def finish():
+        for w in works:
+            w.wait()
+        got = recv.reshape(-1, width) if width > 1 else recv
+        lo = rank * per
+        out, off = [], 0
+        for src in range(world):
+            m = recv_counts[src]
+            offs = [0] * lo + rel_in[src] + [m] * (n_prefix - lo - per)
+            out.append((got[off:off + m], offs))
+            off += m
+        return out
+    return finish if async_op else finish()
