@@ -90,6 +90,11 @@ int yakamd_lookup_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, void *d
 int yakamd_qv_reduce_dev(yak_ch_t *h, const void *d_t_u16, const uint64_t *d_seq_off, const uint32_t *d_seq_len, int64_t n_seq,
                          int min_len, double min_frac, uint32_t *d_tot, uint32_t *d_non0, uint64_t *d_hist1024);
 
+/* Host-only test hook (no device needed): the base image yak_count() hands to the device for a
+ * FASTA/FASTQ(.gz) file -- sequences of >= min_len bases, each followed by '\n'.  use_fast_path = 0
+ * forces the general record reader for every record.  *out is malloc()ed; returns its length or -1. */
+int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char **out);
+
 /* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
 void *yakamd_dev_alloc(size_t bytes);
 void yakamd_dev_free(void *p);

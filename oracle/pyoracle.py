@@ -72,6 +72,7 @@ def lib():
         L.yko_count_mem.argtypes = [C.c_char_p, C.c_int64, P(Copt), P(Ch)]
         L.yko_count_protocol_mem.restype = P(Ch)
         L.yko_count_protocol_mem.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, P(Copt)]
+        L.yko_read_image.restype = C.c_int64; L.yko_read_image.argtypes = [C.c_char_p, C.c_int, P(C.c_void_p)]
         L.yko_qopt_init.argtypes = [P(Qopt)]
         L.yko_qv.restype = C.c_int; L.yko_qv.argtypes = [P(Qopt), C.c_char_p, P(Ch), P(C.c_int64), C.c_void_p]
         L.yko_count_protocol_file.restype = P(Ch)
@@ -144,3 +145,14 @@ def parse_qv_output(text):
         elif f[0] == "EK":
             ek.append(l)
     return ct, sorted(sq), sorted(ek)
+
+
+def read_image(fn, min_len=0):
+    L = lib()
+    out = C.c_void_p()
+    n = L.yko_read_image(fn.encode(), min_len, C.byref(out))
+    if n < 0:
+        raise OSError("cannot read " + fn)
+    data = C.string_at(out, n)
+    C.CDLL(None).free(out)
+    return data

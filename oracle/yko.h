@@ -102,6 +102,9 @@ yko_ch_t *yko_count_protocol_mem(const uint8_t *b1, int64_t n1, const uint8_t *b
                                  const yko_copt_t *opt);
 yko_ch_t *yko_count_protocol_file(const char *fn1, const char *fn2, const yko_copt_t *opt);
 
+/* test helper: the sequences of fn that count.c:93-96 would process, each followed by '\n'; free(*out) */
+int64_t   yko_read_image(const char *fn, int min_len, char **out);
+
 /* ---- `yak qv` counting step (qv.c:34-135); the statistics of yak_qv_solve are host math outside the path ---- */
 typedef struct {                                              /* yak.h:33-40 */
 	int32_t print_each, print_err_kmer;

@@ -285,6 +285,27 @@ yko_ch_t *yko_count_protocol_file(const char *fn1, const char *fn2, const yko_co
 }
 
 
+/* test helper: the sequences count.c:93-96 would process (length >= min_len), each followed by '\n' */
+int64_t yko_read_image(const char *fn, int min_len, char **out)
+{
+	fx_t f;
+	fxstr_t img = { 0, 0, 0 };
+	int64_t len;
+	memset(&f, 0, sizeof(f));
+	f.fp = (fn && strcmp(fn, "-")) ? gzopen(fn, "r") : gzdopen(0, "r");
+	if (!f.fp) return -1;
+	f.buf = (unsigned char*)malloc(FX_BUF);
+	while ((len = fx_read(&f)) >= 0) {
+		if (len < min_len) continue;
+		fxstr_add(&img, (const unsigned char*)f.seq.s, (size_t)len);
+		fxstr_add(&img, (const unsigned char*)"\n", 1);
+	}
+	free(f.buf); free(f.seq.s); free(f.qual.s); free(f.name.s);
+	gzclose(f.fp);
+	*out = img.s ? img.s : (char*)calloc(1, 1);
+	return (int64_t)img.l;
+}
+
 /* ------------------------------------------------------------------ yak qv counting step (qv.c:34-135)
  * For every sequence of at least min_len bases: t = max(0, count in the table) of each k-mer
  * (canonical, non-ACGT resets the window); tot = number of k-mers, non0 = those present.  Lines the

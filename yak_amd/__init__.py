@@ -29,7 +29,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
-    "yakamd_lookup_dev", "yakamd_qv_reduce_dev",
+    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
 ]
 
 
@@ -119,6 +119,8 @@ def lib():
     L.yakamd_count_partitioned_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, P(C.c_uint64)]
     L.yakamd_count_hashes_dev.restype = C.c_int
     L.yakamd_count_hashes_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64]
+    L.yakamd_host_image.restype = C.c_int64
+    L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
     L.yak_qopt_init.argtypes = [P(QoptT)]
     L.yak_qv.restype = None; L.yak_qv.argtypes = [P(QoptT), C.c_char_p, P(ChT), P(C.c_int64)]
     L.yakamd_lookup_dev.restype = C.c_int; L.yakamd_lookup_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_void_p]
@@ -245,3 +247,15 @@ def qv_counts(table_fn, seq_fn, min_len=0, min_frac=0.5, chunk=1000000000):
     L.yak_qv(C.byref(o), seq_fn.encode(), h, cnt)
     L.yak_ch_destroy(h)
     return list(cnt)
+
+
+def host_image(fn, min_len=0, fast=True):
+    """the base image yak_count() would feed for file `fn` (host only)"""
+    L = lib()
+    out = C.c_void_p()
+    n = L.yakamd_host_image(fn.encode(), min_len, 1 if fast else 0, C.byref(out))
+    if n < 0:
+        raise OSError("cannot read " + fn)
+    data = C.string_at(out, n)
+    C.CDLL(None).free(out)
+    return data

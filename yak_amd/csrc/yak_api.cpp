@@ -14,6 +14,8 @@
 #include <zlib.h>
 #include <sys/time.h>
 #include <sys/resource.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <vector>
 #include <string>
 #include <cmath>
@@ -332,14 +334,29 @@ yak_ch_t *yak_ch_restore(const char *fn)
  * quality lines covering at least the sequence length; a truncated quality ends the input.
  * ------------------------------------------------------------------------------------------ */
 struct FxReader {
-	gzFile fp; unsigned char *buf; int beg, end, eof, last;
+	gzFile fp; int fd; unsigned char *buf; int beg, end, eof, last;
 	std::vector<char> seq, name; size_t qlen; int qlast;
-	enum { BUF = 1 << 16 };
-	FxReader() : fp(0), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0) {}
+	enum { BUF = 1 << 20, NOT_FAST = -3 };
+	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0) {}
+	/* open `fn` (NULL or "-": stdin); a plain (not gzip) regular file is then read with read(2), skipping zlib's copy */
+	bool open_file(const char *fn) {
+		const bool is_stdin = fn == 0 || strcmp(fn, "-") == 0;
+		fp = is_stdin ? gzdopen(0, "r") : gzopen(fn, "r");
+		if (fp == 0) return false;
+		gzbuffer(fp, 1 << 20);                               /* zlib's default 8 KB means a read() per 8 KB */
+		if (!is_stdin && gzdirect(fp)) fd = ::open(fn, O_RDONLY);
+		buf = (unsigned char*)malloc(BUF);
+		return true;
+	}
+	void close_file() { if (fd >= 0) ::close(fd); if (fp) gzclose(fp); free(buf); fp = 0; fd = -1; buf = 0; }
 	bool fill() {
 		if (beg < end) return true;
 		if (eof) return false;
-		beg = 0; end = gzread(fp, buf, BUF);
+		beg = 0;
+		if (fd >= 0) {                                       /* read(2) may return short counts before EOF */
+			end = 0;
+			while (end < BUF) { const ssize_t r = ::read(fd, buf + end, BUF - end); if (r <= 0) break; end += (int)r; }
+		} else end = gzread(fp, buf, BUF);
 		if (end < BUF) eof = 1;
 		if (end <= 0) { end = 0; return false; }
 		return true;
@@ -364,6 +381,43 @@ struct FxReader {
 		if (line && what == 1 && seq.size() > 1 && seq.back() == '\r') seq.pop_back();
 		if (line && what == 2 && qlen > 1 && qlast == '\r') { --qlen; qlast = 0; }
 		return 0;
+	}
+	/* Fast path for the record shapes real files are made of -- header line, ONE sequence line, and
+	 * either the next record's marker (FASTA) or a '+' line and ONE quality line of the same length
+	 * (FASTQ) -- when all of it, plus the byte after it, already sits in the buffer: located with
+	 * memchr and appended to `out` (sequence + '\n') straight from the buffer if it has >= min_len
+	 * bases.  The reader state it leaves is exactly what next() would leave; anything else (blank or
+	 * wrapped lines, CR, a record cut by the buffer end, EOF) returns NOT_FAST without touching the
+	 * state, and the caller takes next(). */
+	int64_t fast(std::vector<char> &out, int64_t min_len) {
+		const unsigned char *b = buf;
+		int p = beg;
+		if (p >= end) return NOT_FAST;
+		if (last == 0) { if (b[p] != '@' && b[p] != '>') return NOT_FAST; ++p; }
+		const unsigned char *q = (const unsigned char*)memchr(b + p, '\n', end - p);
+		if (!q) return NOT_FAST;
+		const int s0 = (int)(q - b) + 1;
+		if (s0 >= end) return NOT_FAST;
+		const int c0 = b[s0];
+		if (c0 == '\n' || c0 == '>' || c0 == '+' || c0 == '@') return NOT_FAST;
+		q = (const unsigned char*)memchr(b + s0, '\n', end - s0);
+		if (!q) return NOT_FAST;
+		const int s1 = (int)(q - b), slen = s1 - s0, n0 = s1 + 1;
+		if (b[s1 - 1] == '\r' || n0 >= end) return NOT_FAST;
+		int nbeg, nlast;
+		if (b[n0] == '>' || b[n0] == '@') { nlast = b[n0]; nbeg = n0 + 1; }
+		else if (b[n0] == '+') {
+			q = (const unsigned char*)memchr(b + n0, '\n', end - n0);
+			if (!q) return NOT_FAST;
+			const int q0 = (int)(q - b) + 1;
+			if ((int64_t)q0 + slen + 1 >= end) return NOT_FAST;
+			if (b[q0 + slen] != '\n' || memchr(b + q0, '\n', slen)) return NOT_FAST;
+			if (slen > 1 && b[q0 + slen - 1] == '\r') return NOT_FAST;
+			nlast = 0; nbeg = q0 + slen + 1;
+		} else return NOT_FAST;
+		if (slen >= min_len) { out.insert(out.end(), b + s0, b + s1); out.push_back('\n'); }
+		beg = nbeg; last = nlast;
+		return slen;
 	}
 	int64_t next() {
 		int c, d;
@@ -394,8 +448,7 @@ struct FxReader {
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 {
 	FxReader fx;
-	fx.fp = (fn == 0 || strcmp(fn, "-") == 0) ? gzdopen(0, "r") : gzopen(fn, "r");
-	if (fx.fp == 0) return 0;                                /* count.c:152 */
+	if (!fx.open_file(fn)) return 0;                         /* count.c:152 */
 	yak_ch_t *h;
 	int create_new;
 	if (h0) {
@@ -404,9 +457,8 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	} else {
 		create_new = 1;
 		h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
-		if (h == 0) { gzclose(fx.fp); return 0; }
+		if (h == 0) { fx.close_file(); return 0; }
 	}
-	fx.buf = (unsigned char*)malloc(FxReader::BUF);
 	yk_realtime();
 	int ok = yakamd_pass_begin(h, create_new) == 0;
 	std::vector<char> chunk;
@@ -420,10 +472,12 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq);
 		chunk.clear(); sum_len = 0; n_seq = 0;
 	};
-	while (ok && (l = fx.next()) >= 0) {                     /* count.c:93 */
+	while (ok) {                                             /* count.c:93 */
+		if ((l = fx.fast(chunk, opt->k)) == FxReader::NOT_FAST) {
+			if ((l = fx.next()) < 0) break;
+			if (l >= opt->k) { chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end()); chunk.push_back('\n'); }   /* a non-ACGT byte ends the read (count.c:41) */
+		}
 		if (l < opt->k) continue;                            /* count.c:95 */
-		chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end());
-		chunk.push_back('\n');                                /* a non-ACGT byte ends the read (count.c:41) */
 		sum_len += l; ++n_seq;
 		if (sum_len >= opt->chunk_size || chunk.size() > ((size_t)1 << 31)) flush();   /* count.c:106 */
 	}
@@ -434,10 +488,32 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot);
-	free(fx.buf);
-	gzclose(fx.fp);
+	fx.close_file();
 	if (!ok) { if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
+}
+
+/* host-only hook for tests: the base image yak_count() would hand to the device for `fn` (sequences
+ * of at least min_len bases, each followed by '\n'); caller frees *out with free().  -1 if unreadable. */
+int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char **out)
+{
+	FxReader fx;
+	if (!fx.open_file(fn)) return -1;
+	std::vector<char> img;
+	int64_t l;
+	const double t_ = yk_realtime();
+	if (getenv("YAKAMD_VERBOSE")) img.reserve((size_t)1 << 29);
+	for (;;) {
+		if (!use_fast_path || (l = fx.fast(img, min_len)) == FxReader::NOT_FAST) {
+			if ((l = fx.next()) < 0) break;
+			if (l >= min_len) { img.insert(img.end(), fx.seq.begin(), fx.seq.end()); img.push_back('\n'); }
+		}
+	}
+	if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s in the reader loop\n", yk_realtime() - t_);
+	fx.close_file();
+	*out = (char*)malloc(img.size() + 1);
+	memcpy(*out, img.data(), img.size());
+	return (int64_t)img.size();
 }
 
 /* reference qv.c:137-144 */
@@ -461,9 +537,7 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 	yak_ch_t *h = (yak_ch_t*)ch;
 	if (ch->k >= 32) { fprintf(stderr, "[E::yak_qv] k must be below 32\n"); return; }   /* qv.c:44 asserts */
 	FxReader fx;
-	fx.fp = (fn == 0 || strcmp(fn, "-") == 0) ? gzdopen(0, "r") : gzopen(fn, "r");
-	if (fx.fp == 0) return;
-	fx.buf = (unsigned char*)malloc(FxReader::BUF);
+	if (!fx.open_file(fn)) return;
 	uint64_t *d_hist = (uint64_t*)yakamd_dev_alloc(n_cnt * 8);
 	std::vector<uint64_t> zero(n_cnt, 0), h_off;
 	std::vector<uint32_t> h_len, h_tot, h_non0;
@@ -524,8 +598,7 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 	if (ok) for (int i = 0; i < n_cnt; ++i) cnt[i] = (int64_t)hh[i];
 	else fprintf(stderr, "[E::yak_qv] %s\n", yakamd_last_error());
 	yakamd_dev_free(d_hist);
-	free(fx.buf);
-	gzclose(fx.fp);
+	fx.close_file();
 }
 
 } /* extern "C" */
