@@ -5,7 +5,7 @@ import torch
 import yak_amd, bench
 L = yak_amd.lib()
 dev = torch.device("cuda", 0)
-for n_reads, frac in ((10_000_000, 1), (20_000_000, 2), (40_000_000, 4))[:int(os.environ.get("NCASE", "2"))]:
+for n_reads, frac in ((10_000_000, 1), (20_000_000, 2), (40_000_000, 4))[int(os.environ.get("CASE0", "0")):int(os.environ.get("NCASE", "2"))]:
     h = bench.make_reads(n_reads, 5 * n_reads, 42, 0, torch, 32)
     d = h.to(dev); torch.cuda.synchronize(); nb = d.numel()
     for rep in range(2):

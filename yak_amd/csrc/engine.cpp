@@ -484,6 +484,63 @@ static size_t count_lds_bytes(yakamd_ctx *c)
 	return lds > 150 * 1024 ? 0 : lds;
 }
 
+/* count-existing pass, records = 8-byte hashes grouped by prefix (d_bstart), tables beyond the LDS
+ * kernel: level-2 partition by home-slot range (k_hpart2) + one workgroup per range (k_img_count_rng).
+ * Returns 0 done, -1 error, 1 not applicable (caller falls back to the device-atomics kernel). */
+static int count_by_ranges(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart)
+{
+	const int P = c->P;
+	u32 bmax = 0;
+	for (int p = c->plo; p < c->phi; ++p) if (c->h_bits[p] != YK_NOCAP) bmax = std::max(bmax, c->h_bits[p]);
+	const int rb = (int)bmax > yk_rng_log() ? (int)bmax - yk_rng_log() : 0;
+	if (bmax == 0 || rb > 8) return 1;
+	const size_t NB = (size_t)1 << c->nb_bits, S2 = (size_t)1 << rb, n_sb = (size_t)P << rb;
+	std::vector<u64> bst(NB + 1);
+	HIPCK(hipMemcpyAsync(bst.data(), d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	const u64 ch = (u64)yk_hpart2_chunk();
+	std::vector<Chunk2> chunks;
+	std::vector<u32> chunk_first(P + 1, 0);
+	std::vector<u64> bbase(P + 1, 0);
+	for (int p = 0; p < P; ++p) {
+		chunk_first[p] = (u32)chunks.size();
+		const u64 a = bst[p], b = bst[p + 1];
+		for (u64 o = a; o < b; o += ch) {
+			Chunk2 k;
+			k.rec = (const Rec*)((const u64*)c->d_rec + o); k.spare = 0;
+			k.n = (u32)std::min<u64>(ch, b - o); k.bucket = (u32)p; k.tbase = 0; k.pad = 0;
+			chunks.push_back(k);
+		}
+		if (chunks.size() > chunk_first[p]) chunks.back().spare = 1;
+		bbase[p + 1] = bbase[p] + (b - a);
+	}
+	chunk_first[P] = (u32)chunks.size();
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_ln = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_h2 = 0, *d_list = 0;
+	const u32 list_cap = (u32)std::min<int64_t>(env_i64("YAKAMD_XLIST_CAP", 1 << 22), 1 << 22);   /* the knob is for tests */
+	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, (chunks.size() + 1) * S2) ||
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_h2, (size_t)n_rec) || dmalloc(&d_list, (size_t)1 << 22) || dmalloc(&d_ln, 2)) return -1;
+	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemsetAsync(d_ln, 0, 8, c->st));
+	const ImgView img = img_view(c);
+	yk_launch_hpart2(d_chunks, (int)chunks.size(), d_cf, d_bbase, img, rb, P, d_rows2, d_sbstart, d_h2, c->st);
+	const u32 max_len = bmax > (u32)yk_rng_log() ? 1u << yk_rng_log() : 1u << bmax;
+	int r = 0;
+	if (yk_launch_img_count_rng(d_h2, 0, d_sbstart, img, c->plo, c->phi, rb, max_len, d_list, d_ln, list_cap, c->st)) r = fail("range count kernel could not be configured");
+	u32 xn[2] = { 0, 0 };
+	if (!r) {
+		HIPCK(hipMemcpyAsync(xn, d_ln, 8, hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+		if (xn[1]) yk_launch_img_count_rng(d_h2, 1, d_sbstart, img, c->plo, c->phi, rb, max_len, d_list, d_ln, list_cap, c->st);   /* list too small: second sweep */
+		else if (xn[0]) yk_launch_img_count_h(d_list, (int64_t)xn[0], img, c->st);
+		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] range count: 2^%d ranges per sub-table, %u boundary-crossing instances%s\n", rb, xn[0], xn[1] ? " (list overflow: second sweep)" : "");
+		HIPCK(hipStreamSynchronize(c->st));
+	}
+	dfree(d_chunks); dfree(d_cf); dfree(d_bbase); dfree(d_rows2); dfree(d_sbstart); dfree(d_h2); dfree(d_list); dfree(d_ln);
+	return r;
+}
+
 static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart, int hash_only)
 {
 	if (n_rec <= 0) return 0;
@@ -495,6 +552,15 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
 		 * exclusive-ownership counting, no global atomics */
 		const size_t lds = d_bstart ? count_lds_bytes(c) : 0;
+		if (!lds && d_bstart && hash_only && c->nb_bits == c->pre && env_i64("YAKAMD_COUNT_RNG", 1) != 0) {
+			/* sub-tables too large for one workgroup's LDS: split each one's hashes by home-slot range first */
+			const int r = count_by_ranges(c, n_rec, d_bstart);
+			if (r <= 0) {                                        /* done (0) or failed (-1); 1 = not applicable */
+				const double ms = tm.stop();
+				c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+				return r;
+			}
+		}
 		if (!lds || yk_launch_img_count_lds(c->d_rec, hash_only, d_bstart, img, c->plo, c->phi, lds, c->st) != 0) {
 			if (hash_only) yk_launch_img_count_h((const u64*)c->d_rec, n_rec, img, c->st);
 			else yk_launch_img_count(c->d_rec, n_rec, img, c->st);

@@ -2261,6 +2261,119 @@ static inline int grid_for(u64 n, int per_block = 256, int cap = 256 * 8)
 	return (int)g;
 }
 
+/* ==========================================================================================
+ * Count-existing passes on sub-tables too large for k_img_count_lds (its bitmap + rank table + one
+ * counter per key must fit one workgroup's LDS: ~70 K keys).  The hashes of a sub-table are split
+ * once more by the HOME-SLOT RANGE of their key -- khashl.h:98 takes the home slot from the top bits
+ * of one 32-bit product, so the top bits of that product name a contiguous range of 2^RNG_LOG slots --
+ * and ONE workgroup then owns a range: `used` bits and one 16-bit counter per slot in LDS, the key
+ * compare against HBM/L2, plain read-modify-writes at the end.  A probe that runs past the end of
+ * the range (linear probing across the boundary) is handed over: appended to `list` and counted by
+ * k_img_count_h afterwards; if the list overflows, a second sweep (CROSS = 1) redoes exactly those
+ * instances with global reads and atomics.
+ * ========================================================================================== */
+#define RNG_LOG 16
+/* range id, out of 2^rb per sub-table; a sub-table with fewer ranges uses every 2^(rb - rbp)-th id */
+__device__ __forceinline__ u32 rng_of(u64 h, const ImgView &img, int rb, int rng_log)
+{
+	const u32 p = (u32)h & ((1u << img.pre) - 1), bits = img.bits[p];
+	if (bits == YK_NOCAP || (int)bits <= rng_log || rb == 0) return 0;
+	const int rbp = (int)bits - rng_log;
+	return ((u32)(h >> img.pre) * 2654435769u) >> (32 - rbp) << (rb - rbp);
+}
+
+template <int MODE>   /* 0 = histogram, 1 = write-combining scatter (groups of 8 hashes) */
+__global__ __launch_bounds__(WC_NT)
+void k_hpart2(const Chunk2 *chunks, ImgView img, int rb, int rng_log, u32 *rows2, const u64 *__restrict__ sbstart, u64 *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	const Chunk2 c = chunks[blockIdx.x];
+	const u64 *src = (const u64*)c.rec;
+	const int S2 = 1 << rb;
+	const u32 tid = threadIdx.x;
+	if (MODE == 0) {
+		for (int j = tid; j < S2; j += WC_NT) s_dyn[j] = 0;
+		__syncthreads();
+		for (u32 i = tid; i < c.n; i += WC_NT) atomicAdd(&s_dyn[rng_of(src[i], img, rb, rng_log)], 1u);
+		__syncthreads();
+		for (int j = tid; j < S2; j += WC_NT) rows2[(size_t)blockIdx.x * S2 + j] = s_dyn[j];
+		return;
+	}
+	WcView w;
+	wc_carve<8, XW_CAP_H, false>(w, s_dyn, S2, WC_NT);
+	const u32 *row = rows2 + (size_t)blockIdx.x * S2;
+	for (int b = tid; b < S2; b += WC_NT) {
+		w.cnt[b] = 0; w.head[b] = row[b];
+		w.tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + b + 1] : row[S2 + b];
+	}
+	if (tid < 2) w.ntask[tid] = 0;
+	__syncthreads();
+	const u32 n_round = (c.n + WC_NT - 1) / WC_NT;
+	for (u32 rd = 0; rd < n_round; ++rd) {
+		const u32 i = rd * WC_NT + tid, par = rd & 1;
+		if (i < c.n) { const u64 h = src[i]; wc_place<8, XW_CAP_H, false>(w, rng_of(h, img, rb, rng_log), h, 0, par, out); }
+		__syncthreads();
+		wc_flush<8, XW_CAP_H, false>(w, par, out);
+		__syncthreads();
+	}
+	wc_drain<8, XW_CAP_H, false>(w, S2, out);
+}
+
+template <int CROSS>
+__global__ __launch_bounds__(1024)
+void k_img_count_rng(const u64 *__restrict__ rec, const u64 *__restrict__ sbstart, ImgView img, int plo, int rb, int rng_log,
+                     u64 *__restrict__ list, u32 *list_n, u32 list_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	const u32 bkt = ((u32)plo << rb) + blockIdx.x, p = bkt >> rb, r = bkt & ((1u << rb) - 1), tid = threadIdx.x;
+	const u32 bits = img.bits[p];
+	const u64 lo = sbstart[bkt], hi = sbstart[bkt + 1];
+	if (bits == YK_NOCAP || lo == hi) return;
+	const int rbp = (int)bits > rng_log ? (int)bits - rng_log : 0;
+	const u32 cap = 1u << bits, nmask = cap - 1, len = cap >> rbp, start = (r >> (rb - rbp)) * len, nw = (len + 31) / 32;
+	const u64 off = img.off[p];
+	u32 *s_bm = s_dyn, *s_ct = s_dyn + nw;                             /* used bits | one 16-bit counter per slot of the range */
+	for (u32 w = tid; w < nw; w += 1024) s_bm[w] = img.used[((off + start) >> 5) + w];
+	for (u32 i = tid; i < (len + 1) / 2; i += 1024) s_ct[i] = 0;
+	__syncthreads();
+	for (u64 i = lo + tid; i < hi; i += 1024) {
+		const u64 h = rec[i], kid = h >> img.pre;
+		const u32 first = yk_h2b((u32)kid, bits) - start;              /* the partition put the home slot in this range */
+		u32 li = first;
+		for (;;) {
+			if (!(s_bm[li >> 5] >> (li & 31) & 1)) break;                 /* khashl get: stop at the first unused slot */
+			if (img.keys[off + start + li] >> 10 == kid) {
+				if (!CROSS) {
+					const u32 sh = 16 * (li & 1);
+					if ((s_ct[li >> 1] >> sh & 0xffffu) < 4096u) atomicAdd(&s_ct[li >> 1], 1u << sh);   /* only min(count, 1023) matters */
+				}
+				break;
+			}
+			++li;
+			if (rbp == 0) { li &= nmask; if (li == first) break; continue; }   /* the range is the whole table: plain wrap-around */
+			if (li < len) continue;
+			if (!CROSS) {                                                 /* the probe leaves the range */
+				const u32 at = atomicAdd(&list_n[0], 1u);
+				if (at < list_cap) list[at] = h; else atomicAdd(&list_n[1], 1u);
+			} else {
+				const u32 home = (start + first) & nmask;
+				for (u32 s2 = (start + len) & nmask; s2 != home; s2 = (s2 + 1) & nmask) {
+					const u64 g = off + s2;
+					if (!(img.used[g >> 5] >> (g & 31) & 1)) break;
+					if (img.keys[g] >> 10 == kid) { atomicAdd(&img.delta[g], 1u); break; }
+				}
+			}
+			break;
+		}
+	}
+	if (CROSS) return;
+	__syncthreads();
+	for (u32 li = tid; li < len; li += 1024) {
+		const u32 c = s_ct[li >> 1] >> (16 * (li & 1)) & 0xffffu;
+		if (c) img.delta[off + start + li] += c;                          /* exclusive owner: plain read-modify-write */
+	}
+}
+
 extern "C" {
 
 /* k-mers ENDING at positions [pos0, n) of `bases` (bytes before pos0 are read as left context);
@@ -2483,6 +2596,41 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 		const size_t l2 = wc_lds_bytes<4, WC_CAP, true>(1 << fp.s2_bits, WC_NT);
 		hipLaunchKernelGGL(k_part2_wc, dim3(n_chunks), dim3(WC_NT), l2, st, chunks, fp, (const u32*)rows2, (const u64*)sbstart, out);
 	} else if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(nt), lds, st, chunks, fp, rows2, out);
+}
+
+int yk_rng_log(void)                      /* log2 slots per range; the env knob lets tests split small tables */
+{
+	static const int v = getenv("YAKAMD_RNG_LOG") ? atoi(getenv("YAKAMD_RNG_LOG")) : RNG_LOG;
+	return v < 5 ? 5 : v > RNG_LOG ? RNG_LOG : v;
+}
+int yk_hpart2_chunk(void) { return 131072; }
+
+void yk_launch_hpart2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, ImgView img, int rb, int P,
+                      u32 *rows2, u64 *sbstart, u64 *out, hipStream_t st)
+{
+	const int S2 = 1 << rb;
+	static bool attr = false;
+	if (!attr) { hipFuncSetAttribute((const void*)k_hpart2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr = true; }
+	if (n_chunks) hipLaunchKernelGGL(k_hpart2<0>, dim3(n_chunks), dim3(WC_NT), sizeof(u32) * S2, st, chunks, img, rb, yk_rng_log(), rows2, (const u64*)sbstart, out);
+	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, rb, rows2, sbstart, P);
+	if (n_chunks) hipLaunchKernelGGL(k_hpart2<1>, dim3(n_chunks), dim3(WC_NT), (wc_lds_bytes<8, XW_CAP_H, false>(S2, WC_NT)), st,
+	                                 chunks, img, rb, yk_rng_log(), rows2, (const u64*)sbstart, out);
+}
+
+int yk_launch_img_count_rng(const u64 *rec, int cross, const u64 *sbstart, ImgView img, int plo, int phi, int rb, u32 max_len,
+                            u64 *list, u32 *list_n, u32 list_cap, hipStream_t st)
+{
+	static bool attr = false;
+	if (!attr) {
+		if (hipFuncSetAttribute((const void*)k_img_count_rng<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess ||
+		    hipFuncSetAttribute((const void*)k_img_count_rng<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		attr = true;
+	}
+	const size_t lds = (size_t)((max_len + 31) / 32) * 4 + (size_t)(max_len + 1) / 2 * 4 + 16;
+	const dim3 grid((unsigned)(phi - plo) << rb), blk(1024);
+	if (cross) hipLaunchKernelGGL(k_img_count_rng<1>, grid, blk, lds, st, rec, sbstart, img, plo, rb, yk_rng_log(), list, list_n, list_cap);
+	else hipLaunchKernelGGL(k_img_count_rng<0>, grid, blk, lds, st, rec, sbstart, img, plo, rb, yk_rng_log(), list, list_n, list_cap);
+	return 0;
 }
 
 /* tier = LC_G over every sub-bucket of the shard (in_list == NULL), or LC_S over a list */

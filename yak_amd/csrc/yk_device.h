@@ -153,6 +153,12 @@ struct FastParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
+int yk_rng_log(void);
+int yk_hpart2_chunk(void);
+void yk_launch_hpart2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, ImgView img, int rb, int P,
+                      u32 *rows2, u64 *sbstart, u64 *out, hipStream_t st);
+int yk_launch_img_count_rng(const u64 *rec, int cross, const u64 *sbstart, ImgView img, int plo, int phi, int rb, u32 max_len,
+                            u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
                      u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
 void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
