@@ -237,14 +237,14 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
 
 @pytest.mark.parametrize("env", [dict(YAKAMD_FAST="0"), dict(YAKAMD_S2_BITS="0"), dict(YAKAMD_FAST_BUDGET="100000"),
                                  dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6"),
-                                 dict(YAKAMD_S2_BITS="6"), dict(YAKAMD_S2_BITS="11", YAKAMD_CH2="4096"),
+                                 dict(YAKAMD_S2_BITS="6"), dict(YAKAMD_S2_BITS="11", YAKAMD_CH2="4096"), dict(YAKAMD_S2_BITS="13"),
                                  dict(YAKAMD_XP_WC="0", YAKAMD_P2_WC="0", YAKAMD_S2_BITS="6"),
                                  dict(YAKAMD_COUNT_LDS="0"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6"),
                                  dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="5", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6", YAKAMD_XLIST_CAP="7"),
                                  dict(YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
-                              "write_combined_level2", "write_combined_level2_wide", "plain_scatters",
+                              "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
                               "count_with_device_atomics"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):

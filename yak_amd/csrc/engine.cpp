@@ -350,6 +350,9 @@ extern "C" int yakamd_set_shard(yak_ch_t *h, int lo, int hi)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || lo < 0 || hi > c->P || lo >= hi) return fail("bad shard range");
+	if (c->in_pass) return fail("shard change inside a pass");
+	if (c->has_bloom && !c->bf_virgin && (lo != c->plo || hi != c->phi))
+		return fail("the shard cannot move once its bloom filters have been written (only the shard's part is initialised)");
 	c->plo = lo; c->phi = hi;
 	return 0;
 }
@@ -954,7 +957,7 @@ static int fast_finish(yakamd_ctx *c)
 	fp.s2_bits = s2;
 	fp.bf_virgin = 0;
 	if (c->bloom_mode) {
-		if (c->bf_virgin && c->nb - 9 - s2 <= 7 && c->plo == 0 && c->phi == P) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block */
+		if (c->bf_virgin && c->nb - 9 - s2 <= 7) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
 		else if (bloom_materialise(c)) return -1;
 		c->bf_virgin = false;
 	}

@@ -1886,34 +1886,43 @@ void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, Rec *__restrict__ 
 /* the same scatter with write combining (see WcView above): 1024 records per round */
 #define WC_CAP 5
 #define WC_NT  1024
+#define WC_SEG 2048          /* sub-buckets whose stacks fit in LDS at once */
 __global__ __launch_bounds__(WC_NT)
 void k_part2_wc(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ rows2, const u64 *__restrict__ sbstart, Rec *__restrict__ out)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 	const Chunk2 c = chunks[blockIdx.x];
-	const int S2 = 1 << fp.s2_bits;
+	const int S2 = 1 << fp.s2_bits, SEG = S2 < WC_SEG ? S2 : WC_SEG;
 	const u32 tid = threadIdx.x;
 	WcView w;
-	wc_carve<4, WC_CAP, true>(w, s_dyn, S2, WC_NT);
+	wc_carve<4, WC_CAP, true>(w, s_dyn, SEG, WC_NT);
 	const u32 *row = rows2 + (size_t)blockIdx.x * S2;
-	for (int b = tid; b < S2; b += WC_NT) {
-		w.cnt[b] = 0; w.head[b] = row[b];
-		w.tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + b + 1] : row[S2 + b];   /* start of the next chunk's run = end of mine */
-	}
-	if (tid < 2) w.ntask[tid] = 0;
-	__syncthreads();
 	const u32 n_round = (c.n + WC_NT - 1) / WC_NT;
-	Rec nxt = tid < c.n ? c.rec[tid] : make_ulonglong2(0, 0);
-	for (u32 rd = 0; rd < n_round; ++rd) {
-		const u32 i = rd * WC_NT + tid, par = rd & 1;
-		const Rec rc = nxt;
-		if (i + WC_NT < c.n) nxt = c.rec[i + WC_NT];
-		if (i < c.n) wc_place<4, WC_CAP, true>(w, sub_of(rc.x, fp), rc.x, (u32)rc.y + c.tbase, par, out);
+	/* more sub-buckets than stacks fit in LDS: one sweep over the chunk per segment of WC_SEG
+	 * sub-buckets (the chunk is small enough to come back from L2) */
+	for (int seg0 = 0; seg0 < S2; seg0 += SEG) {
 		__syncthreads();
-		wc_flush<4, WC_CAP, true>(w, par, out);
+		for (int b = tid; b < SEG; b += WC_NT) {
+			w.cnt[b] = 0; w.head[b] = row[seg0 + b];
+			w.tail[b] = (c.spare & 1) ? (u32)sbstart[(size_t)c.bucket * S2 + seg0 + b + 1] : row[S2 + seg0 + b];   /* start of the next chunk's run = end of mine */
+		}
+		if (tid < 2) w.ntask[tid] = 0;
 		__syncthreads();
+		Rec nxt = tid < c.n ? c.rec[tid] : make_ulonglong2(0, 0);
+		for (u32 rd = 0; rd < n_round; ++rd) {
+			const u32 i = rd * WC_NT + tid, par = rd & 1;
+			const Rec rc = nxt;
+			if (i + WC_NT < c.n) nxt = c.rec[i + WC_NT];
+			if (i < c.n) {
+				const u32 sub = sub_of(rc.x, fp) - (u32)seg0;
+				if (sub < (u32)SEG) wc_place<4, WC_CAP, true>(w, sub, rc.x, (u32)rc.y + c.tbase, par, out);
+			}
+			__syncthreads();
+			wc_flush<4, WC_CAP, true>(w, par, out);
+			__syncthreads();
+		}
+		wc_drain<4, WC_CAP, true>(w, SEG, out);
 	}
-	wc_drain<4, WC_CAP, true>(w, S2, out);
 }
 
 /* one workgroup per level-1 bucket: rows2 counts -> absolute offsets; sbstart[bucket * S2 + s] */
@@ -2590,10 +2599,10 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
 	static const int wc = getenv("YAKAMD_P2_WC") ? atoi(getenv("YAKAMD_P2_WC")) : 1;
-	if (n_chunks && wc && fp.s2_bits <= 11 && fp.s2_bits >= 4) {
+	if (n_chunks && wc && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
 		static bool attr2 = false;
 		if (!attr2) { hipFuncSetAttribute((const void*)k_part2_wc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr2 = true; }
-		const size_t l2 = wc_lds_bytes<4, WC_CAP, true>(1 << fp.s2_bits, WC_NT);
+		const size_t l2 = wc_lds_bytes<4, WC_CAP, true>(fp.s2_bits < 11 ? 1 << fp.s2_bits : WC_SEG, WC_NT);
 		hipLaunchKernelGGL(k_part2_wc, dim3(n_chunks), dim3(WC_NT), l2, st, chunks, fp, (const u32*)rows2, (const u64*)sbstart, out);
 	} else if (n_chunks) hipLaunchKernelGGL(k_part2<1>, dim3(n_chunks), dim3(nt), lds, st, chunks, fp, rows2, out);
 }
