@@ -107,6 +107,8 @@ yak_ch_t *yak_ch_restore(const char *fn);                         /* reference h
  * NULL when the file cannot be opened or no usable GPU is present (a message goes to stderr). */
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0);
 
+void yak_recount(const char *fn, yak_ch_t *h);                  /* reference count.c:168: clear + count existing k-mers of fn */
+
 /* `yak qv` counting step (reference qv.c:34-135, yak.h:33-40,105-106): per sequence of fn with at
  * least min_len bases, the table count of every k-mer; sequences whose fraction of present k-mers is
  * >= min_frac add their counts to cnt[YAK_N_COUNTS].  Runs on the device-resident table. */

@@ -103,3 +103,37 @@ def test_yak_count_file_api(ya, oracle, tmp_path):
     assert t.dump_bytes() == oracle.dump_bytes(want) and t.tot == want.contents.tot
     assert L.yak_count(fq.encode(), C.byref(o), h)       # second call returns h0 itself
     t.close(); oracle.lib().yko_ch_destroy(want)
+
+
+@pytest.mark.gpu
+def test_recount_equals_clear_plus_count_existing(ya, oracle, tmp_path):
+    """yak_recount (count.c:168-193): counts of the table's k-mers in ANOTHER file; layout untouched"""
+    import subprocess
+    from conftest import ROOT
+    L, O = ya.lib(), oracle.lib()
+    syn = os.path.join(ROOT, "tools", "yaksynth")
+    f1, f2, tab = str(tmp_path / "a.fq"), str(tmp_path / "b.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([syn, "-n", "8000", "-l", "150", "-g", "40000", "-s", "21", "-o", f1])
+    subprocess.check_call([syn, "-a", "-n", "30", "-l", "5000", "-g", "40000", "-s", "21", "-e", "0.01", "-N", "0.001", "-o", f2])
+    subprocess.run([os.path.join(ROOT, "oracle", "yko"), "count", "-k27", "-o", tab, f1], check=True, stderr=subprocess.DEVNULL)
+    h = L.yak_ch_restore(tab.encode())
+    assert h
+
+    def dump():
+        out = C.POINTER(C.c_uint8)()
+        n = L.yakamd_dump_mem(h, C.byref(out))
+        data = C.string_at(out, n)
+        C.CDLL(None).free(out)
+        return data
+    L.yak_recount(f2.encode(), h)
+    got = dump()
+    ho = O.yko_ch_restore(tab.encode())
+    O.yko_ch_clear(ho)
+    o = oracle.copt(k=27)
+    assert O.yko_count_file(f2.encode(), C.byref(o), ho)
+    want = oracle.dump_bytes(ho)
+    O.yko_ch_destroy(ho)
+    assert got == want
+    L.yak_recount(str(tmp_path / "missing.fa").encode(), h)          # unreadable file: table untouched
+    assert dump() == want
+    L.yak_ch_destroy(h)

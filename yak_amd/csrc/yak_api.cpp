@@ -493,6 +493,21 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	return h;
 }
 
+/* reference count.c:168-193: clear the counts, then count the k-mers of fn that are in the table --
+ * one count-existing pass on the device (sequences shorter than k have no k-mer either way) */
+void yak_recount(const char *fn, yak_ch_t *h)
+{
+	yak_copt_t o;
+	yak_copt_init(&o);
+	o.k = h->k; o.pre = h->pre;
+	{                                                         /* count.c:172-173: an unreadable file leaves the table untouched */
+		gzFile fp = (fn == 0 || strcmp(fn, "-") == 0) ? 0 : gzopen(fn, "r");
+		if (fn != 0 && strcmp(fn, "-") != 0) { if (fp == 0) return; gzclose(fp); }
+	}
+	yak_ch_clear(h, 1);
+	if (yak_count(fn, &o, h) == 0) fprintf(stderr, "[E::yak_recount] %s\n", yakamd_last_error());
+}
+
 /* host-only hook for tests: the base image yak_count() would hand to the device for `fn` (sequences
  * of at least min_len bases, each followed by '\n'); caller frees *out with free().  -1 if unreadable. */
 int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char **out)
