@@ -96,6 +96,7 @@ yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n);   /* reference 
 
 void yak_ch_clear(yak_ch_t *h, int n_thread);                     /* reference htab.c:127 */
 void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread); /* htab.c:156 */
+void yak_ch_setcnt(yak_ch_t *h, int cnt, int n_thread);            /* htab.c:225: set every stored count */
 void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread);  /* reference htab.c:199 */
 
 int yak_ch_dump(const yak_ch_t *h, const char *fn);               /* reference htab.c:373 */

@@ -73,6 +73,8 @@ def lib():
         L.yko_count_protocol_mem.restype = P(Ch)
         L.yko_count_protocol_mem.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, P(Copt)]
         L.yko_read_image.restype = C.c_int64; L.yko_read_image.argtypes = [C.c_char_p, C.c_int, P(C.c_void_p)]
+        L.yko_ch_hist.argtypes = [P(Ch), P(C.c_int64)]
+        L.yko_ch_setcnt.argtypes = [P(Ch), C.c_int]
         L.yko_qopt_init.argtypes = [P(Qopt)]
         L.yko_qv.restype = C.c_int; L.yko_qv.argtypes = [P(Qopt), C.c_char_p, P(Ch), P(C.c_int64), C.c_void_p]
         L.yko_count_file.restype = P(Ch); L.yko_count_file.argtypes = [C.c_char_p, P(Copt), P(Ch)]

@@ -137,3 +137,38 @@ def test_recount_equals_clear_plus_count_existing(ya, oracle, tmp_path):
     L.yak_recount(str(tmp_path / "missing.fa").encode(), h)          # unreadable file: table untouched
     assert dump() == want
     L.yak_ch_destroy(h)
+
+
+@pytest.mark.gpu
+def test_hist_and_setcnt_on_the_device(ya, oracle, synth):
+    """yak_ch_hist (htab.c:145-169) and yak_ch_setcnt (htab.c:219-235) run on the device image"""
+    L, O = ya.lib(), oracle.lib()
+    img = synth(6000, g=30000, s=8)
+    o = oracle.copt(k=31, bf_shift=24)
+    ho = O.yko_count_protocol_mem(img, len(img), None, 0, C.byref(o))
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".yak") as f:
+        assert O.yko_ch_dump(ho, f.name.encode()) == 0
+        O.yko_ch_destroy(ho)
+        h = L.yak_ch_restore(f.name.encode())
+        ho = O.yko_ch_restore(f.name.encode())              # restore re-inserts in file order: compare restored with restored
+    assert h
+    want = (C.c_int64 * 1024)(); have = (C.c_int64 * 1024)()
+    O.yko_ch_hist(ho, want)
+    L.yak_ch_hist(h, have, 4)
+    n_keys = sum(want)
+    assert list(have) == list(want) and n_keys > 10000
+
+    def dump():
+        out = C.POINTER(C.c_uint8)()
+        n = L.yakamd_dump_mem(h, C.byref(out))
+        data = C.string_at(out, n)
+        C.CDLL(None).free(out)
+        return data
+    for cnt in (1, 1023, 0):
+        O.yko_ch_setcnt(ho, cnt)
+        L.yak_ch_setcnt(h, cnt, 4)
+        assert dump() == oracle.dump_bytes(ho)
+        L.yak_ch_hist(h, have, 4)
+        assert have[cnt] == n_keys and sum(have) == n_keys
+    L.yak_ch_destroy(h); O.yko_ch_destroy(ho)

@@ -1172,6 +1172,28 @@ extern "C" int yakamd_get_stats(yak_ch_t *h, yakamd_stats_t *st)
 	return 0;
 }
 
+int yk_ctx_hist(yakamd_ctx *c, int64_t *cnt1024)
+{
+	HIPCK(hipSetDevice(c->dev));
+	u64 *d_h = 0;
+	if (dmalloc(&d_h, 1024)) return -1;
+	HIPCK(hipMemsetAsync(d_h, 0, 1024 * 8, c->st));
+	yk_launch_img_hist(img_view(c), c->n_slots, d_h, c->st);
+	const hipError_t e = hipMemcpyAsync(cnt1024, d_h, 1024 * 8, hipMemcpyDeviceToHost, c->st);
+	const hipError_t e2 = hipStreamSynchronize(c->st);
+	dfree(d_h);
+	return e == hipSuccess && e2 == hipSuccess ? 0 : fail("hist: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+}
+
+int yk_ctx_setcnt(yakamd_ctx *c, int cnt)
+{
+	HIPCK(hipSetDevice(c->dev));
+	yk_launch_img_setcnt(img_view(c), c->n_slots, (u32)cnt & 1023u, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	c->host_valid = false;
+	return 0;
+}
+
 int yk_ctx_clear(yakamd_ctx *c)
 {
 	HIPCK(hipSetDevice(c->dev));

@@ -9,6 +9,8 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift);
 void yk_ctx_destroy(yakamd_ctx *c);
 int  yk_ctx_destroy_bf(yakamd_ctx *c);
 int  yk_ctx_clear(yakamd_ctx *c);
+int  yk_ctx_hist(yakamd_ctx *c, int64_t *cnt1024);
+int  yk_ctx_setcnt(yakamd_ctx *c, int cnt);
 int  yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot);
 int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys);
 int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);

@@ -844,6 +844,28 @@ void k_img_fold(ImgView img, u64 n_slots)                    /* htab.c:68-69,73-
 	}
 }
 
+/* reference htab.c:145-169 (histogram of counts over all stored k-mers) and htab.c:219-235 (setcnt) */
+__global__ __launch_bounds__(256)
+void k_img_hist(ImgView img, u64 n_slots, unsigned long long *hist)
+{
+	__shared__ u32 s_h[1024];
+	for (u32 i = threadIdx.x; i < 1024; i += 256) s_h[i] = 0;
+	__syncthreads();
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride)
+		if (img.used[i >> 5] >> (i & 31) & 1) atomicAdd(&s_h[img.keys[i] & 1023u], 1u);
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < 1024; i += 256) if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+}
+
+__global__ __launch_bounds__(256)
+void k_img_setcnt(ImgView img, u64 n_slots, u32 cnt)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride)
+		if (img.used[i >> 5] >> (i & 31) & 1) img.keys[i] = (img.keys[i] & ~1023ull) | cnt;
+}
+
 __global__ __launch_bounds__(256)
 void k_img_clear(ImgView img, u64 n_slots)                   /* reference htab.c:116-125 */
 {
@@ -2505,6 +2527,16 @@ void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st)
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st)
 {
 	if (n_slots) hipLaunchKernelGGL(k_img_clear, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots);
+}
+
+void yk_launch_img_hist(ImgView img, u64 n_slots, u64 *hist, hipStream_t st)
+{
+	if (n_slots) hipLaunchKernelGGL(k_img_hist, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots, (unsigned long long*)hist);
+}
+
+void yk_launch_img_setcnt(ImgView img, u64 n_slots, u32 cnt, hipStream_t st)
+{
+	if (n_slots) hipLaunchKernelGGL(k_img_setcnt, dim3(grid_for(n_slots)), dim3(256), 0, st, img, n_slots, cnt);
 }
 
 void yk_launch_lastput(const Rec *rec, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,

@@ -210,12 +210,13 @@ void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread) /* 
 {
 	(void)n_thread;
 	memset(cnt, 0, YAK_N_COUNTS * sizeof(int64_t));
-	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, (yak_ch_t*)h)) return;
-	for (int p = 0; p < 1 << h->pre; ++p) {
-		const yak_ht_t *g = h->h[p].h;
-		for (uint32_t i = 0, n = ht_cap(g); i < n; ++i)
-			if (g->used[i >> 5] >> (i & 31) & 1) ++cnt[g->keys[i] & YAK_MAX_COUNT];
-	}
+	if (yk_ctx_hist(((yak_ch_ext*)h)->ctx, cnt)) fprintf(stderr, "[E::yak_ch_hist] %s\n", yakamd_last_error());
+}
+
+void yak_ch_setcnt(yak_ch_t *h, int cnt, int n_thread)        /* reference htab.c:219-235: every stored k-mer gets count `cnt` */
+{
+	(void)n_thread;
+	if (yk_ctx_setcnt(((yak_ch_ext*)h)->ctx, cnt)) fprintf(stderr, "[E::yak_ch_setcnt] %s\n", yakamd_last_error());
 }
 
 static uint64_t hash64_inv(uint64_t x, uint64_t m)           /* reference yak-priv.h:41-68 */

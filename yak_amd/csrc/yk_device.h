@@ -93,6 +93,8 @@ void yk_launch_qv_reduce(const unsigned short *t, const u64 *roff, const u32 *rl
 int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
+void yk_launch_img_hist(ImgView img, u64 n_slots, u64 *hist, hipStream_t st);
+void yk_launch_img_setcnt(ImgView img, u64 n_slots, u32 cnt, hipStream_t st);
 void yk_launch_img_clear(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_lastput(const Rec *rec, int64_t n, u64 t0, u64 t_from, AccTab tab, ImgView img,
                        int img_nonempty, int bloom_mode, const u32 *only_missing, u64 *lp_batch, hipStream_t st);
