@@ -97,6 +97,10 @@ yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n);   /* reference 
 void yak_ch_clear(yak_ch_t *h, int n_thread);                     /* reference htab.c:127 */
 void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread); /* htab.c:156 */
 void yak_ch_setcnt(yak_ch_t *h, int cnt, int n_thread);            /* htab.c:225: set every stored count */
+void yak_ch_tighten(yak_ch_t *h);                                 /* htab.c:102 */
+void yak_ch_merge(yak_ch_t *h0, yak_ch_t *h1, int min, int max, int n_thread, int pre_resize); /* htab.c:272; destroys h1 */
+void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread); /* htab.c:309 */
+void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread);     /* htab.c:340 */
 void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread);  /* reference htab.c:199 */
 
 int yak_ch_dump(const yak_ch_t *h, const char *fn);               /* reference htab.c:373 */

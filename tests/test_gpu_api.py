@@ -172,3 +172,68 @@ def test_hist_and_setcnt_on_the_device(ya, oracle, synth):
         L.yak_ch_hist(h, have, 4)
         assert have[cnt] == n_keys and sum(have) == n_keys
     L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+def _two_tables(ya, oracle, synth, tmp_path, k=25):
+    """a and b: tables of two read sets over the same genome (b with more errors and fewer reads)"""
+    import subprocess
+    L, O = ya.lib(), oracle.lib()
+    imgs = [synth(9000, g=50000, s=17, e=0.004), synth(4000, g=50000, s=17, e=0.02, first=9000)]
+    out = []
+    for j, img in enumerate(imgs):
+        o = oracle.copt(k=k)
+        ho = O.yko_count_protocol_mem(img, len(img), None, 0, C.byref(o))
+        fn = str(tmp_path / f"t{j}.yak")
+        assert O.yko_ch_dump(ho, fn.encode()) == 0
+        O.yko_ch_destroy(ho)
+        out.append(fn)
+    return out
+
+
+def _dump(L, h):
+    out = C.POINTER(C.c_uint8)()
+    n = L.yakamd_dump_mem(h, C.byref(out))
+    data = C.string_at(out, n)
+    C.CDLL(None).free(out)
+    return data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["subtract", "isec", "tighten", "shrink_tighten", "merge", "merge_presize", "merge_range", "setcnt_merge"])
+def test_set_operations_on_the_device(op, ya, oracle, synth, tmp_path):
+    """yak_ch_subtract / isec / tighten / merge (htab.c:102-110, 246-347) against the same calls on the
+    oracle, starting from restored tables (what `yak cntasm / subtract / isec` do, main.c:90-284)"""
+    L, O = ya.lib(), oracle.lib()
+    O.yko_ch_merge.argtypes = [C.POINTER(oracle.Ch), C.POINTER(oracle.Ch), C.c_int, C.c_int, C.c_int]
+    O.yko_ch_subtract.argtypes = [C.POINTER(oracle.Ch)] * 2
+    O.yko_ch_isec.argtypes = [C.POINTER(oracle.Ch)] * 2
+    O.yko_ch_tighten.argtypes = [C.POINTER(oracle.Ch)]
+    O.yko_ch_shrink.argtypes = [C.POINTER(oracle.Ch), C.c_int, C.c_int]
+    fa, fb = _two_tables(ya, oracle, synth, tmp_path)
+    h0, h1 = L.yak_ch_restore(fa.encode()), L.yak_ch_restore(fb.encode())
+    o0, o1 = O.yko_ch_restore(fa.encode()), O.yko_ch_restore(fb.encode())
+    assert h0 and h1
+    h1_alive = True
+    if op == "subtract":
+        L.yak_ch_subtract(h0, h1, 4); O.yko_ch_subtract(o0, o1)
+    elif op == "isec":
+        L.yak_ch_isec(h0, h1, 4); O.yko_ch_isec(o0, o1)
+    elif op == "tighten":
+        L.yak_ch_tighten(h0); O.yko_ch_tighten(o0)
+    elif op == "shrink_tighten":
+        L.yak_ch_shrink(h0, 3, 1023, 4); O.yko_ch_shrink(o0, 3, 1023)
+        assert _dump(L, h0) == oracle.dump_bytes(o0)
+        L.yak_ch_tighten(h0); O.yko_ch_tighten(o0)
+    elif op in ("merge", "merge_presize", "merge_range", "setcnt_merge"):
+        if op == "setcnt_merge":                              # main.c:144-150: presence counting across samples
+            L.yak_ch_setcnt(h0, 1, 4); O.yko_ch_setcnt(o0, 1)
+        lo, hi = (2, 5) if op == "merge_range" else (0, 1023)
+        L.yak_ch_merge(h0, h1, lo, hi, 4, 1 if op == "merge_presize" else 0)
+        O.yko_ch_merge(o0, o1, lo, hi, 1 if op == "merge_presize" else 0)
+        h1_alive = False
+    assert _dump(L, h0) == oracle.dump_bytes(o0)
+    assert h0.contents.tot == o0.contents.tot
+    L.yak_ch_destroy(h0); O.yko_ch_destroy(o0)
+    if h1_alive:
+        assert _dump(L, h1) == oracle.dump_bytes(o1)          # the second operand is left alone
+        L.yak_ch_destroy(h1); O.yko_ch_destroy(o1)

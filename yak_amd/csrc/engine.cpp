@@ -167,7 +167,7 @@ struct yakamd_ctx {
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
-	bool in_pass; int create_new; bool bloom_mode;
+	bool in_pass; int create_new; bool bloom_mode; bool gate_off;   /* gate_off: puts of a merge never consult the filter */
 	AccTab acc; u64 acc_count;
 	u64 *d_counters, *d_lastput, *d_lpbatch;
 	u32 *d_missing, *d_nmissing;
@@ -246,7 +246,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
 	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
 	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false;
-	c->in_pass = false; c->acc.s = 0; c->acc_count = 0;
+	c->in_pass = false; c->gate_off = false; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
 	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
@@ -364,7 +364,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	if (c->in_pass) return fail("pass already open");
 	HIPCK(hipSetDevice(c->dev));
 	c->create_new = create_new;
-	c->bloom_mode = create_new && c->has_bloom;
+	c->bloom_mode = create_new && c->has_bloom && !c->gate_off;
 	c->in_pass = true;
 	c->t_end = 0;
 	memset(&c->st_cur, 0, sizeof(c->st_cur));
@@ -1204,21 +1204,26 @@ int yk_ctx_clear(yakamd_ctx *c)
 }
 
 /* reference htab.c:180-208 */
-int yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot)
+/* htab.c:171-197 (shrink), 287-347 (subtract / isec): per sub-table, a new set resized for the old
+ * key count receives, in old slot order, the keys that pass the test.  which: 0 count range only,
+ * 1 and absent from `other`, 2 and present in `other` */
+static int rebuild(yakamd_ctx *c, int cmin, int cmax, int which, yakamd_ctx *other, u64 *tot)
 {
 	HIPCK(hipSetDevice(c->dev));
 	const int P = c->P;
+	if (other && (other->pre != c->pre || other->k != c->k)) return fail("tables of different k / prefix length");
+	const ImgView ov = other ? img_view(other) : img_view(c);
 	std::vector<u32> m(P), init(P);
 	std::vector<u64> seg_off(P + 1, 0);
 	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
 	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
-	yk_launch_shrink_count(img_view(c), P, cmin, cmax, d_segcnt, c->st);
+	yk_launch_shrink_count(img_view(c), P, cmin, cmax, which, ov, d_segcnt, c->st);
 	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	for (int p = 0; p < P; ++p) { seg_off[p + 1] = seg_off[p] + m[p]; init[p] = kh_bits_for(c->h_count[p]); }
 	if (dmalloc(&d_kc, seg_off[P])) return -1;
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, d_segoff, d_kc, c->st);
+	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, which, ov, d_segoff, d_kc, c->st);
 	EvTimer tm(c->st);
 	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
 	c->st_last.ms_shrink = tm.stop();
@@ -1227,6 +1232,113 @@ int yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot)
 	*tot = c->img_keys_total;
 	return 0;
 }
+
+int yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot) { return rebuild(c, cmin, cmax, 0, 0, tot); }
+int yk_ctx_subtract(yakamd_ctx *c, yakamd_ctx *other, u64 *tot) { return rebuild(c, 0, 1023, 1, other, tot); }
+int yk_ctx_isec(yakamd_ctx *c, yakamd_ctx *other, u64 *tot) { return rebuild(c, 0, 1023, 2, other, tot); }
+
+/* khashl resize of every sub-table whose entry in new_bits differs from YK_NOCAP-as-"leave alone"
+ * (new_bits[p] == 0xfffffffe); the table image moves to a fresh arena */
+#define YK_LEAVE 0xfffffffeu
+static int resize_tables(yakamd_ctx *c, const std::vector<u32> &new_bits)
+{
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	std::vector<ResizeTask> tasks(P);
+	std::vector<u64> new_off(P);
+	std::vector<u32> bits_after(P);
+	u64 tot = 0;
+	for (int p = 0; p < P; ++p) {
+		ResizeTask &t = tasks[p];
+		t.old_bits = c->h_bits[p]; t.old_off = c->h_off[p]; t.pad = 0;
+		t.rehash = new_bits[p] != YK_LEAVE;
+		t.new_bits = t.rehash ? new_bits[p] : c->h_bits[p];
+		bits_after[p] = t.new_bits;
+		const u64 n = t.old_bits == YK_NOCAP ? 0 : (u64)1 << t.old_bits, N = t.new_bits == YK_NOCAP ? 0 : (u64)1 << t.new_bits;
+		t.new_off = new_off[p] = tot;
+		tot += std::max<u64>(32, std::max(n, N));
+	}
+	u64 *nk = 0; u32 *nu = 0, *su = 0, *nd = 0; ResizeTask *d_tasks = 0;
+	if (dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&nd, tot) || dmalloc(&d_tasks, P)) return -1;
+	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
+	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
+	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
+	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ResizeTask), hipMemcpyHostToDevice, c->st));
+	yk_launch_resize(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	dfree(su); dfree(d_tasks);
+	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
+	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
+	c->h_off = new_off; c->h_bits = bits_after;
+	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	c->host_valid = false;
+	return 0;
+}
+
+/* new_bits of khashl's resize(want) on a set of (cap, count), or YK_LEAVE when it refuses (khashl.h:155-160) */
+static u32 resize_target(u32 count, u32 want)
+{
+	const u32 nb = kh_bits_for(want);
+	const u64 N = (u64)1 << nb;
+	return count > (N >> 1) + (N >> 2) ? YK_LEAVE : nb;
+}
+
+/* htab.c:102-110: sub-tables filled to less than a third are resized to 3 x their key count */
+int yk_ctx_tighten(yakamd_ctx *c)
+{
+	const int P = c->P;
+	std::vector<u32> nb(P, YK_LEAVE);
+	bool any = false;
+	for (int p = 0; p < P; ++p) {
+		const u64 cap = c->h_bits[p] == YK_NOCAP ? 0 : (u64)1 << c->h_bits[p];
+		if ((u64)c->h_count[p] * 3 < cap) { nb[p] = resize_target(c->h_count[p], c->h_count[p] * 3); any = any || nb[p] != YK_LEAVE; }
+	}
+	return any ? resize_tables(c, nb) : 0;
+}
+
+/* htab.c:262-266: before a merge, grow sub-table p for count0 + count1 keys at 75 % load */
+int yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other)
+{
+	const int P = c->P;
+	std::vector<u32> nb(P, YK_LEAVE);
+	bool any = false;
+	for (int p = 0; p < P; ++p) {
+		const u64 cap = c->h_bits[p] == YK_NOCAP ? 0 : (u64)1 << c->h_bits[p];
+		const u64 want = ((u64)c->h_count[p] + other->h_count[p]) * 4 / 3 + 1;
+		if (want > cap) { nb[p] = resize_target(c->h_count[p], (u32)want); any = any || nb[p] != YK_LEAVE; }
+	}
+	return any ? resize_tables(c, nb) : 0;
+}
+
+/* keys of `c` with cmin <= count <= cmax, sub-table by sub-table in slot order, as full hashes +
+ * list positions on the device (caller frees both with yakamd_dev_free-compatible pool_free) */
+int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n)
+{
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	std::vector<u32> m(P);
+	std::vector<u64> seg_off(P + 1, 0);
+	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
+	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
+	yk_launch_shrink_count(img_view(c), P, cmin, cmax, 0, img_view(c), d_segcnt, c->st);
+	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	for (int p = 0; p < P; ++p) seg_off[p + 1] = seg_off[p] + m[p];
+	*n = seg_off[P];
+	*d_hash = 0; *d_t = 0;
+	if (dmalloc(&d_kc, seg_off[P]) || dmalloc(d_hash, seg_off[P]) || dmalloc(d_t, seg_off[P])) return -1;
+	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, 0, img_view(c), d_segoff, d_kc, c->st);
+	yk_launch_keys_to_hashes(d_kc, d_segoff, P, c->pre, *d_hash, *d_t, c->st);
+	HIPCK(hipStreamSynchronize(c->st));
+	dfree(d_segcnt); dfree(d_segoff); dfree(d_kc);
+	return 0;
+}
+void yk_pool_release(void *p) { if (p) pool_free(p); }
+void yk_ctx_gate(yakamd_ctx *c, bool on) { c->gate_off = !on; }
+u64 yk_ctx_keys_total(yakamd_ctx *c) { return c->img_keys_total; }
 
 /* reference htab.c:441-447: resize each sub-table to its saved capacity, then put in file order */
 int yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys)

@@ -12,6 +12,14 @@ int  yk_ctx_clear(yakamd_ctx *c);
 int  yk_ctx_hist(yakamd_ctx *c, int64_t *cnt1024);
 int  yk_ctx_setcnt(yakamd_ctx *c, int cnt);
 int  yk_ctx_shrink(yakamd_ctx *c, int cmin, int cmax, u64 *tot);
+int  yk_ctx_subtract(yakamd_ctx *c, yakamd_ctx *other, u64 *tot);
+int  yk_ctx_isec(yakamd_ctx *c, yakamd_ctx *other, u64 *tot);
+int  yk_ctx_tighten(yakamd_ctx *c);
+int  yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other);
+int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n);
+void yk_pool_release(void *p);
+void yk_ctx_gate(yakamd_ctx *c, bool on);
+u64  yk_ctx_keys_total(yakamd_ctx *c);
 int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys);
 int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
 u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);

@@ -1811,15 +1811,21 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 /* ------------------------------------------------------------------------------------------
  * shrink (reference htab.c:180-197): keys with min <= count <= max, in ascending OLD slot order
  * ------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ bool shrink_keep(const ImgView &img, u64 a, int cmin, int cmax)
+/* which == 0: count range only (yak_ch_shrink); 1: and absent from `other` (yak_ch_subtract,
+ * htab.c:287-316); 2: and present in `other` (yak_ch_isec, htab.c:318-347) */
+__device__ __forceinline__ bool shrink_keep(const ImgView &img, u64 a, int cmin, int cmax, int which, const ImgView &other, u32 p)
 {
 	if (!(img.used[a >> 5] >> (a & 31) & 1)) return false;
-	const int c = (int)(img.keys[a] & 1023);
-	return c >= cmin && c <= cmax;
+	const u64 kc = img.keys[a];
+	const int c = (int)(kc & 1023);
+	if (c < cmin || c > cmax) return false;
+	if (which == 0) return true;
+	const bool present = img_find(other, (kc >> 10) << img.pre | p) >= 0;
+	return which == 1 ? !present : present;
 }
 
 __global__ __launch_bounds__(256)
-void k_shrink_count(ImgView img, int cmin, int cmax, u32 *seg_cnt)
+void k_shrink_count(ImgView img, int cmin, int cmax, int which, ImgView other, u32 *seg_cnt)
 {
 	__shared__ u32 s_tot;
 	const u32 bits = img.bits[blockIdx.x];
@@ -1828,7 +1834,7 @@ void k_shrink_count(ImgView img, int cmin, int cmax, u32 *seg_cnt)
 	if (bits != YK_NOCAP) {
 		const u64 off = img.off[blockIdx.x];
 		u32 c = 0;
-		for (u32 i = threadIdx.x; i < 1u << bits; i += 256) c += shrink_keep(img, off + i, cmin, cmax);
+		for (u32 i = threadIdx.x; i < 1u << bits; i += 256) c += shrink_keep(img, off + i, cmin, cmax, which, other, blockIdx.x);
 		for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
 		if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_tot, c);
 	}
@@ -1837,7 +1843,7 @@ void k_shrink_count(ImgView img, int cmin, int cmax, u32 *seg_cnt)
 }
 
 __global__ __launch_bounds__(256)
-void k_shrink_scatter(ImgView img, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc)
+void k_shrink_scatter(ImgView img, int cmin, int cmax, int which, ImgView other, const u64 *seg_off, u64 *rec_kc)
 {
 	__shared__ u32 s_w[4];
 	const u32 bits = img.bits[blockIdx.x];
@@ -1847,7 +1853,7 @@ void k_shrink_scatter(ImgView img, int cmin, int cmax, const u64 *seg_off, u64 *
 	u64 out = seg_off[blockIdx.x];
 	for (u32 base = 0; base < 1u << bits; base += 256) {
 		const u32 i = base + threadIdx.x;
-		const bool keep = i < 1u << bits && shrink_keep(img, off + i, cmin, cmax);
+		const bool keep = i < 1u << bits && shrink_keep(img, off + i, cmin, cmax, which, other, blockIdx.x);
 		const u64 b = __ballot(keep);
 		if (lane == 0) s_w[wave] = __popcll(b);
 		__syncthreads();
@@ -2292,6 +2298,45 @@ static inline int grid_for(u64 n, int per_block = 256, int cap = 256 * 8)
 	return (int)g;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * khashl resize to ANY capacity (khashl.h:152-195; yak_ch_tighten htab.c:102-110 shrinks, the
+ * pre-resize of yak_ch_merge htab.c:262-266 grows by more than one doubling).  These are one-off
+ * maintenance calls, so each sub-table is simply walked by one lane with the literal rule
+ * (replay_double is that rule for any old / new size); the workgroup copies and normalises around it.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256)
+void k_resize(const ResizeTask *tasks, const u64 *__restrict__ old_keys, const u32 *__restrict__ old_used,
+              u64 *new_keys, u32 *new_used, u32 *scr_used)
+{
+	__shared__ u32 s_progress;
+	const ResizeTask T = tasks[blockIdx.x];
+	if (T.old_bits == YK_NOCAP) return;
+	const u32 n = 1u << T.old_bits, tid = threadIdx.x;
+	u64 *keys = new_keys + T.new_off;
+	u32 *nu = new_used + (T.new_off >> 5), *cur = scr_used + (T.new_off >> 5);
+	for (u32 i = tid; i < n; i += 256) keys[i] = old_keys[T.old_off + i];
+	if (T.new_bits == T.old_bits && !T.rehash) {             /* untouched: plain copy */
+		for (u32 w = tid; w < (n + 31) / 32; w += 256) nu[w] = old_used[(T.old_off >> 5) + w];
+		return;
+	}
+	const u32 N = 1u << T.new_bits;
+	for (u32 w = tid; w < (n + 31) / 32; w += 256) cur[w] = old_used[(T.old_off >> 5) + w];
+	for (u32 w = tid; w < (N + 31) / 32; w += 256) nu[w] = 0;
+	__syncthreads();
+	if (tid == 0) replay_double(keys, cur, nu, n, N, T.new_bits, &s_progress);
+	__syncthreads();
+	const u32 span = n > N ? n : N;
+	for (u32 i = tid; i < span; i += 256) if (i >= N || !bm_get(nu, i)) keys[i] = YK_EMPTY;
+}
+
+/* table keys of one sub-table (slot order) -> full hashes + list positions, for a merge pass */
+__global__ __launch_bounds__(256)
+void k_keys_to_hashes(const u64 *__restrict__ kc, const u64 *__restrict__ seg_off, int pre, u64 *__restrict__ hash, u32 *__restrict__ t)
+{
+	const u64 a = seg_off[blockIdx.x], b = seg_off[blockIdx.x + 1];
+	for (u64 i = a + threadIdx.x; i < b; i += 256) { hash[i] = (kc[i] >> 10) << pre | blockIdx.x; t[i] = (u32)i; }
+}
+
 /* ==========================================================================================
  * Count-existing passes on sub-tables too large for k_img_count_lds (its bitmap + rank table + one
  * counter per key must fit one workgroup's LDS: ~70 K keys).  The hashes of a sub-table are split
@@ -2611,14 +2656,24 @@ void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const
 	                   scr_used, scr_owner, scr_par, rec_kc, rec_t, lastput, out_bits, out_count, lds_words);
 }
 
-void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, u32 *seg_cnt, hipStream_t st)
+void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, int which, ImgView other, u32 *seg_cnt, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_shrink_count, dim3(P), dim3(256), 0, st, img, cmin, cmax, seg_cnt);
+	hipLaunchKernelGGL(k_shrink_count, dim3(P), dim3(256), 0, st, img, cmin, cmax, which, other, seg_cnt);
 }
 
-void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, const u64 *seg_off, u64 *rec_kc, hipStream_t st)
+void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, int which, ImgView other, const u64 *seg_off, u64 *rec_kc, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_shrink_scatter, dim3(P), dim3(256), 0, st, img, cmin, cmax, seg_off, rec_kc);
+	hipLaunchKernelGGL(k_shrink_scatter, dim3(P), dim3(256), 0, st, img, cmin, cmax, which, other, seg_off, rec_kc);
+}
+
+void yk_launch_resize(const ResizeTask *tasks, int P, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used, u32 *scr_used, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_resize, dim3(P), dim3(256), 0, st, tasks, old_keys, old_used, new_keys, new_used, scr_used);
+}
+
+void yk_launch_keys_to_hashes(const u64 *kc, const u64 *seg_off, int P, int pre, u64 *hash, u32 *t, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_keys_to_hashes, dim3(P), dim3(256), 0, st, kc, seg_off, pre, hash, t);
 }
 
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, FastParams fp, int P,

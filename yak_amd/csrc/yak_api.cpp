@@ -206,6 +206,54 @@ void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread) /* reference hta
 	if (yk_ctx_shrink(((yak_ch_ext*)h)->ctx, min, hi, &tot) == 0) h->tot = tot;
 }
 
+/* reference htab.c:102-110: resize every sub-table filled to less than a third */
+void yak_ch_tighten(yak_ch_t *h)
+{
+	if (yk_ctx_tighten(((yak_ch_ext*)h)->ctx)) fprintf(stderr, "[E::yak_ch_tighten] %s\n", yakamd_last_error());
+}
+
+/* reference htab.c:287-316 / 318-347: keep the k-mers of h0 that are absent from / present in h1 */
+void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
+{
+	(void)n_thread;
+	unsigned long long tot = 0;
+	if (yk_ctx_subtract(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
+	else fprintf(stderr, "[E::yak_ch_subtract] %s\n", yakamd_last_error());
+}
+
+void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
+{
+	(void)n_thread;
+	unsigned long long tot = 0;
+	if (yk_ctx_isec(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
+	else fprintf(stderr, "[E::yak_ch_isec] %s\n", yakamd_last_error());
+}
+
+/* reference htab.c:246-285: every k-mer of h1 with min <= count <= max is put into h0 (its count in
+ * h0 goes up by one, saturating; new k-mers start at 1), sub-table by sub-table in h1's slot order;
+ * h1 is destroyed.  One counting pass on the device: the list positions are the stream times. */
+void yak_ch_merge(yak_ch_t *h0, yak_ch_t *h1, int min, int max, int n_thread, int pre_resize)
+{
+	(void)n_thread;
+	yakamd_ctx *c0 = ((yak_ch_ext*)h0)->ctx, *c1 = ((yak_ch_ext*)h1)->ctx;
+	const int hi = (max >= min && max <= YAK_MAX_COUNT) ? max : YAK_MAX_COUNT;
+	u64 *d_hash = 0, n = 0; u32 *d_t = 0;
+	int ok = h0->k == h1->k && h0->pre == h1->pre;
+	if (ok && pre_resize) ok = yk_ctx_merge_presize(c0, c1) == 0;
+	ok = ok && yk_ctx_list_hashes(c1, min, hi, &d_hash, &d_t, &n) == 0;
+	if (ok) {
+		yk_ctx_gate(c0, false);
+		ok = yakamd_pass_begin(h0, 1) == 0;
+		if (ok && n) ok = yakamd_feed_hashed_dev(h0, d_hash, d_t, (int64_t)n, 0, n) == 0;
+		if (ok) ok = yakamd_pass_end(h0) >= 0;
+		yk_ctx_gate(c0, true);
+	}
+	yk_pool_release(d_hash); yk_pool_release(d_t);
+	if (ok) h0->tot = yk_ctx_keys_total(c0);                /* htab.c:284: tot = sum of the sub-table sizes */
+	else fprintf(stderr, "[E::yak_ch_merge] %s\n", yakamd_last_error());
+	yak_ch_destroy(h1);
+}
+
 void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread) /* reference htab.c:156-169 */
 {
 	(void)n_thread;
