@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Full-size golden for BASELINE configs[1] FROM THE REFERENCE ITSELF (build container only, ~3 min,
+3 GB of scratch): the bench workload written as FASTQ by tools/yaksynth, counted by the reference
+binary compiled from /root/reference (oracle/_ref/yak), md5 + size of its .yak stored in
+tests/golden/cfg2_full.json.  bench.py compares the device result of the same workload with it."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "yak")
+SYN = os.path.join(ROOT, "tools", "yaksynth")
+N, L, G, SEED, K, BF = 10_000_000, 150, 50_000_000, 42, 31, 37
+
+
+def main():
+    tmp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/cfg2"
+    os.makedirs(tmp, exist_ok=True)
+    fq, out = os.path.join(tmp, "r.fq"), os.path.join(tmp, "ref.yak")
+    if not os.path.exists(fq):
+        subprocess.check_call([SYN, "-n", str(N), "-l", str(L), "-g", str(G), "-s", str(SEED), "-t", "8", "-o", fq])
+    subprocess.run([REF, "count", f"-k{K}", f"-b{BF}", "-t8", "-o", out, fq], check=True, stderr=subprocess.DEVNULL)
+    h = hashlib.md5()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    desc = {"workload": f"yak count -k{K} -b{BF} on yaksynth -n {N} -l {L} -g {G} -s {SEED} (e=0.5%, N=0.05%)",
+            "reads": N, "read_len": L, "genome": G, "seed": SEED, "k": K, "bf_shift": BF,
+            "md5": h.hexdigest(), "size": os.path.getsize(out), "produced_by": "oracle/_ref/yak (the reference, compiled from /root/reference)"}
+    json.dump(desc, open(os.path.join(ROOT, "tests", "golden", "cfg2_full.json"), "w"), indent=1)
+    print(desc)
+
+
+if __name__ == "__main__":
+    main()
