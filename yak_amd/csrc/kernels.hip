@@ -1238,6 +1238,7 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
  *   * growth happens at the next put-call once count >= 0.75 capacity (khashl.h:202), including a
  *     trailing put-call on an existing key (lastput vs. time of the last new key).
  * ------------------------------------------------------------------------------------------ */
+#define RP_U 1
 #define RP_PAR_MIN  2048                                 /* doublings from this size on try the exact parallel routine */
 #define RP_LDS_WORDS 4096                                 /* doublings up to 131072 slots keep their bitmaps in LDS */
 __device__ __forceinline__ bool bm_get(const u32 *u, u32 i) { return u[i >> 5] >> (i & 31) & 1; }
@@ -1753,23 +1754,34 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 #define RP_PLACE(INIT, AMIN, LOAD)                                                                      \
 		for (u32 i = tid; i < n; i += blockDim.x) { INIT(i, bm_get(cur, i)); }                              \
 		__syncthreads();                                                                                    \
-		for (u32 q = tid; q < batch; q += blockDim.x) {                                                     \
-			u32 r = q + 1, slot = yk_h2b((u32)(src[q] >> 10), bits);                                        \
-			for (;;) {                                                                                      \
-				u32 old; AMIN(old, slot, r);                                                                \
-				if (old == EMPTYV) break;                                                                   \
-				if (old > r) r = old;               /* we took the slot; carry the displaced later key on */ \
-				slot = (slot + 1) & nmask;                                                                  \
+		for (u32 q0 = tid; q0 < batch; q0 += RP_U * blockDim.x) {       /* RP_U independent keys per lane in flight */ \
+			u32 r[RP_U], slot[RP_U], old[RP_U], act = 0;                                                    \
+			_Pragma("unroll")                                                                               \
+			for (int u = 0; u < RP_U; ++u) {                                                                \
+				const u32 q = q0 + u * blockDim.x;                                                          \
+				if (q < batch) { r[u] = q + 1; slot[u] = yk_h2b((u32)(src[q] >> 10), bits); act |= 1u << u; } \
+			}                                                                                               \
+			while (act) {                                                                                   \
+				_Pragma("unroll")                                                                           \
+				for (int u = 0; u < RP_U; ++u) if (act >> u & 1) { AMIN(old[u], slot[u], r[u]); }           \
+				_Pragma("unroll")                                                                           \
+				for (int u = 0; u < RP_U; ++u)                                                              \
+					if (act >> u & 1) {                                                                     \
+						if (old[u] == EMPTYV) { act &= ~(1u << u); continue; }                              \
+						if (old[u] > r[u]) r[u] = old[u];   /* we took the slot; carry the displaced later key on */ \
+						slot[u] = (slot[u] + 1) & nmask;                                                    \
+					}                                                                                       \
 			}                                                                                               \
 		}                                                                                                   \
 		__syncthreads();                                                                                    \
-		for (u32 w = tid; w < (n + 31) / 32; w += blockDim.x) {   /* one lane per bitmap word: no atomics on the bitmap */ \
-			u32 bw = cur[w];                                                                                \
-			for (u32 b = 0; b < 32 && w * 32 + b < n; ++b) {                                                \
-				const u32 i = w * 32 + b; u32 o; LOAD(o, i);                                                \
-				if (o != 0 && o != EMPTYV) { keys[i] = src[o - 1]; bw |= 1u << b; }                         \
-			}                                                                                               \
-			cur[w] = bw;                                                                                    \
+		for (u32 i0 = 0; i0 < n; i0 += blockDim.x) {          /* one slot per lane; a wave's ballot is two bitmap words */ \
+			const u32 i = i0 + tid;                                                                         \
+			u32 o = 0;                                                                                      \
+			if (i < n) { LOAD(o, i); }                                                                      \
+			const bool fresh = i < n && o != 0 && o != EMPTYV;                                              \
+			if (fresh) keys[i] = src[o - 1];                                                                \
+			const u64 b = __ballot(fresh);                                                                  \
+			if ((tid & 63) == 0 && i < n) { cur[i >> 5] |= (u32)b; if (i + 32 < n) cur[(i >> 5) + 1] |= (u32)(b >> 32); } \
 		}                                                                                                   \
 		__syncthreads();
 		if (n <= lds_words) {
