@@ -280,8 +280,10 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100")],
-                         ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow"])
+                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
+                                 dict(YAKAMD_REPLAY_LDS="2048"), dict(YAKAMD_REPLAY_LDS="1024", YAKAMD_REPLAY_THREADS="256"), dict(YAKAMD_REPLAY_LDS="2048", YAKAMD_DBG="256")],
+                         ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow",
+                              "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
 def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
     """~7 M distinct k-mers (1x coverage): every sub-table grows to 16 Ki slots, so the layout replay
     goes through LDS-resident keys, 32- and 16-bit LDS owner ranks, global ranks, and the parallel

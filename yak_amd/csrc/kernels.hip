@@ -1800,6 +1800,53 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 #define LOAD16(o, i) o = ((unsigned short*)s_dyn)[i]
 			RP_PLACE(INIT16, AMIN16, LOAD16)
 #undef EMPTYV
+		} else if (scr_par && lds_words >= 1024 && (lds_words & (lds_words - 1)) == 0 && !(T.dbg & 256)) {
+			/* larger tables: the same ordered probing, one segment of lds_words slots at a time with the
+			 * ranks in LDS; a walk that reaches the end of its segment is parked as (rank, next slot) and
+			 * finished afterwards on the written-back global array -- the fixed point of min-rank
+			 * probing does not depend on the order in which the walks are made */
+			const u32 SEG = lds_words, nseg = n / SEG;
+			u64 *spill = scr_par + 2 * T.new_off;                    /* free between doublings; 2 x capacity entries */
+			if (tid == 0) s_par[6] = 0;
+			for (u32 seg = 0; seg < nseg; ++seg) {
+				const u32 base = seg * SEG;
+				for (u32 i = tid; i < SEG; i += blockDim.x) s_dyn[i] = bm_get(cur, base + i) ? 0u : 0xffffffffu;
+				__syncthreads();
+				for (u32 q = tid; q < batch; q += blockDim.x) {
+					const u32 home = yk_h2b((u32)(src[q] >> 10), bits);
+					if (home / SEG != seg) continue;
+					u32 r = q + 1, li = home - base;
+					for (;;) {
+						const u32 old = atomicMin(&s_dyn[li], r);
+						if (old == 0xffffffffu) break;
+						if (old > r) r = old;
+						if (++li == SEG) { spill[atomicAdd(&s_par[6], 1u)] = (u64)r << 32 | ((base + SEG) & nmask); break; }
+					}
+				}
+				__syncthreads();
+				for (u32 i = tid; i < SEG; i += blockDim.x) owner[base + i] = s_dyn[i];
+				__syncthreads();
+			}
+			const u32 ns = s_par[6];
+			for (u32 j = tid; j < ns; j += blockDim.x) {
+				u32 r = (u32)(spill[j] >> 32), slot = (u32)spill[j];
+				for (;;) {
+					const u32 old = atomicMin(&owner[slot], r);
+					if (old == 0xffffffffu) break;
+					if (old > r) r = old;
+					slot = (slot + 1) & nmask;
+				}
+			}
+			__syncthreads();
+			for (u32 i0 = 0; i0 < n; i0 += blockDim.x) {
+				const u32 i = i0 + tid;
+				const u32 o = __hip_atomic_load(&owner[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const bool fresh = o != 0 && o != 0xffffffffu;
+				if (fresh) keys[i] = src[o - 1];
+				const u64 b = __ballot(fresh);
+				if ((tid & 63) == 0) { cur[i >> 5] |= (u32)b; cur[(i >> 5) + 1] |= (u32)(b >> 32); }
+			}
+			__syncthreads();
 		} else {
 #define EMPTYV 0xffffffffu
 #define INITG(i, used) owner[i] = (used) ? 0u : EMPTYV
