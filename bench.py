@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not queue the pass-2 exchange behind pass 1's computation")
+    ap.add_argument("--job-md5", action="store_true", help="also report the md5 of the whole job's .yak bytes (sub-tables gathered from all ranks)")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
@@ -254,6 +255,27 @@ def main():
         tot_all, inst_all = float(tot), float(s1["n_instances"] + (s2["n_instances"] if s2 else 0))
     ms_step = dt / a.steps * 1e3
 
+    job_md5 = None
+    if a.job_md5:
+        # bytes of the whole job's .yak: every rank dumps the sub-tables it owns, rank 0 concatenates them in
+        # prefix order behind the 16-byte header (htab.c:373-394) -- must equal the single-rank file
+        import struct
+        t_m, _, _, _ = step(keep=True)
+        data = t_m.dump_bytes(); t_m.close()
+        plo_, phi_ = (lo, hi) if sharded else (0, P)
+        off, parts = 16, []
+        for p_ in range(P):
+            n_ = struct.unpack_from("<I", data, off + 4)[0]
+            if plo_ <= p_ < phi_:
+                parts.append(data[off:off + 8 + 8 * n_])
+            off += 8 + 8 * n_
+        blob = b"".join(parts)
+        if sharded and world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, blob)
+            blob = b"".join(gathered)
+        job_md5 = hashlib.md5(data[:16] + blob).hexdigest()
+
     verify = None
     if not a.no_verify and not sharded:
         # full-size property: the .yak bytes do not depend on how the stream is cut into device
@@ -388,6 +410,7 @@ def main():
                      "f_ins": f_ins, "f_hit": f_hit,
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
         "verify": verify,
+        "job_yak_md5": job_md5,
         "qv_lookup_probe": qv_probe,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }

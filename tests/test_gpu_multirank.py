@@ -1,0 +1,46 @@
+"""The N > 1 path of bench.py on ONE device: two ranks (torch.distributed.run, gloo instead of RCCL so
+that both may use GPU 0) shard the prefixes, exchange their k-mers and count; the job's result must
+equal the single-rank run on the same logical input (rank 0's reads followed by rank 1's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(args, nproc=1, port=29547):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, check=True, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT).stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("bf", [34, 0])
+def test_two_ranks_equal_one_rank(bf):
+    common = ["--bf-shift", str(bf), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--no-qv", "--job-md5"]
+    two = run_bench(["--gpus", "2", "--backend", "gloo", "--reads", "150000"] + common, nproc=2, port=29547 + bf)
+    one = run_bench(["--reads", "300000"] + common)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["final_distinct"] == one["final_distinct"] and one["final_distinct"] > 0
+    assert two["job_yak_md5"] == one["job_yak_md5"] and one["job_yak_md5"]        # the .yak bytes, not just the size
+    assert two["kmer_instances_per_s"] > 0 and two["scaling"] == "weak"
+
+
+def test_single_rank_exchange_path_matches_direct_path():
+    """--force-exchange: partition + (self) all-to-all + pre-partitioned feed, against the direct feed"""
+    common = ["--reads", "400000", "--bf-shift", "35", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--no-qv", "--job-md5"]
+    a = run_bench(common)
+    b = run_bench(common + ["--force-exchange"])
+    c = run_bench(common + ["--force-exchange", "--no-overlap"])
+    assert a["final_distinct"] == b["final_distinct"] == c["final_distinct"] > 0
+    assert a["job_yak_md5"] == b["job_yak_md5"] == c["job_yak_md5"]
