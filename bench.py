@@ -414,7 +414,7 @@ def main():
         "qv_lookup_probe": qv_probe,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:                      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, min(os.cpu_count() or 8, 32))
     print(json.dumps(out))
     if sharded:
