@@ -344,7 +344,7 @@ def main():
     f_ins = s1["n_new_keys"] / max(1, n1)
     b_insert = (8.0 + 128.0 + 16.0 * f_ins) if (a.bf_shift > PRE and s1["ms_part2"] > 0) else B_INSERT
     f_hit = (qv_probe["present"] / max(1, qv_probe["kmers_looked_up"])) if qv_probe else 0.9
-    dev_batch = int(os.environ.get("YAKAMD_BATCH", 1 << 30))
+    dev_batch = int(os.environ.get("YAKAMD_BATCH", 1 << 31))
     n_batches = -(-n_bytes // dev_batch)
     kern = [
         {"kernel": "k_xpart (extract + level-1 partition, both passes)", "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),

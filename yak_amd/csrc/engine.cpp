@@ -657,7 +657,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	if (c->k >= 64 || c->k < 1) return fail("k must be in [1, 63]");
 	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
 	HIPCK(hipSetDevice(c->dev));
-	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 30);
+	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 31);
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
 	const int hash_only = !c->create_new;                  /* counting existing keys needs no stream positions */
 	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
