@@ -237,3 +237,84 @@ def test_set_operations_on_the_device(op, ya, oracle, synth, tmp_path):
     if h1_alive:
         assert _dump(L, h1) == oracle.dump_bytes(o1)          # the second operand is left alone
         L.yak_ch_destroy(h1); O.yko_ch_destroy(o1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pre_resize", [0, 1], ids=["plain", "resize_before_merge"])
+def test_cntasm_protocol_equals_reference_cli(pre_resize, ya, oracle, tmp_path):
+    """`yak cntasm` (main.c:90-161) -- count each assembly, keep its unique k-mers, merge sample after
+    sample, shrink, tighten, dump -- as the same call sequence on the library; the file must equal the
+    one the reference binary writes (oracle/_ref/yak, where it travelled) and the oracle's"""
+    import subprocess
+    from conftest import ROOT
+    L, O = ya.lib(), oracle.lib()
+    syn, ref = os.path.join(ROOT, "tools", "yaksynth"), os.path.join(ROOT, "oracle", "_ref", "yak")
+    fas = []
+    for j, (seed, e) in enumerate(((31, 0.0), (31, 0.004), (31, 0.008))):           # three "assemblies" of one genome
+        fa = str(tmp_path / f"asm{j}.fa")
+        subprocess.check_call([syn, "-a", "-n", "12", "-l", "20000", "-g", "150000", "-s", str(seed), "-e", str(e), "-N", "0.0002", "-o", fa])
+        if j:                                                                        # different contigs per sample
+            txt = open(fa).read().split(">")[1:]
+            open(fa, "w").write("".join(">" + r for r in txt[j:] + txt[:j]))
+        fas.append(fa)
+    K, min_cnt, max_cnt, max_out, check_n = 21, 1, 1, 0, 10
+    o = ya.CoptT(); L.yak_copt_init(C.byref(o)); o.k = K; o.chunk_size = 1900000000
+    h = None
+    oo = oracle.copt(k=K, chunk=1900000000); ho = None
+    O.yko_ch_merge.argtypes = [C.POINTER(oracle.Ch), C.POINTER(oracle.Ch), C.c_int, C.c_int, C.c_int]
+    O.yko_ch_shrink.argtypes = [C.POINTER(oracle.Ch), C.c_int, C.c_int]
+    O.yko_ch_tighten.argtypes = [C.POINTER(oracle.Ch)]
+    for i, fa in enumerate(fas):
+        h1 = L.yak_count(fa.encode(), C.byref(o), None)
+        g1 = O.yko_count_file(fa.encode(), C.byref(oo), None)
+        assert h1 and g1
+        if h is None:
+            h, ho = h1, g1
+            L.yak_ch_shrink(h, min_cnt, max_cnt, 4); L.yak_ch_setcnt(h, 1, 4)
+            O.yko_ch_shrink(ho, min_cnt, max_cnt); O.yko_ch_setcnt(ho, 1)
+        else:
+            L.yak_ch_merge(h, h1, min_cnt, max_cnt, 4, pre_resize)
+            O.yko_ch_merge(ho, g1, min_cnt, max_cnt, pre_resize)
+        if i == len(fas) - 1 or (i + 1 > max_out and (i + 1) % check_n == 0):
+            L.yak_ch_shrink(h, i + 1 - max_out, 1023, 4)
+            O.yko_ch_shrink(ho, i + 1 - max_out, 1023)
+    L.yak_ch_tighten(h); O.yko_ch_tighten(ho)
+    got, want = _dump(L, h), oracle.dump_bytes(ho)
+    assert got == want and h.contents.tot == ho.contents.tot and h.contents.tot > 1000
+    if os.path.exists(ref):
+        out = str(tmp_path / "ref.yak")
+        subprocess.run([ref, "cntasm", f"-k{K}"] + (["-r"] if pre_resize else []) + ["-o", out] + fas, check=True, stderr=subprocess.DEVNULL)
+        assert open(out, "rb").read() == got
+    L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cmd", ["subtract", "isec"])
+def test_subtract_and_isec_protocols_equal_reference_cli(cmd, ya, oracle, synth, tmp_path):
+    """`yak subtract` / `yak isec` (main.c:217-284): restore, set operation, tighten, dump"""
+    import subprocess
+    from conftest import ROOT
+    L = ya.lib()
+    ref = os.path.join(ROOT, "oracle", "_ref", "yak")
+    fa, fb = _two_tables(ya, oracle, synth, tmp_path)
+    h0, h1 = L.yak_ch_restore(fa.encode()), L.yak_ch_restore(fb.encode())
+    (L.yak_ch_subtract if cmd == "subtract" else L.yak_ch_isec)(h0, h1, 8)
+    L.yak_ch_destroy(h1)
+    L.yak_ch_tighten(h0)
+    out = str(tmp_path / "dev.yak")
+    assert L.yak_ch_dump(h0, out.encode()) == 0
+    L.yak_ch_destroy(h0)
+    want = str(tmp_path / "want.yak")
+    tool = ref if os.path.exists(ref) else None
+    if tool:
+        subprocess.run([tool, cmd, "-o", want, fa, fb], check=True, stderr=subprocess.DEVNULL)
+    else:                                                     # the oracle's own call sequence
+        O = oracle.lib()
+        O.yko_ch_subtract.argtypes = [C.POINTER(oracle.Ch)] * 2; O.yko_ch_isec.argtypes = [C.POINTER(oracle.Ch)] * 2
+        O.yko_ch_tighten.argtypes = [C.POINTER(oracle.Ch)]
+        o0, o1 = O.yko_ch_restore(fa.encode()), O.yko_ch_restore(fb.encode())
+        (O.yko_ch_subtract if cmd == "subtract" else O.yko_ch_isec)(o0, o1)
+        O.yko_ch_tighten(o0)
+        assert O.yko_ch_dump(o0, want.encode()) == 0
+    a, b = open(out, "rb").read(), open(want, "rb").read()
+    assert a == b and len(a) > 16 + 8 * 1024

@@ -35,3 +35,58 @@ def test_two_input_files(tmp_path, oracle):
     subprocess.run([REF, "count", "-b24", "-o", a, f1, f2], check=True, stderr=subprocess.DEVNULL)
     subprocess.run([YKO, "count", "-b24", "-o", b, f1, f2], check=True, stderr=subprocess.DEVNULL)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("pre_resize", [0, 1], ids=["plain", "resize_before_merge"])
+def test_cntasm_sequence_on_the_oracle_equals_reference_cli(pre_resize, tmp_path, oracle):
+    """pins the oracle's shrink / setcnt / merge / tighten (htab.c:102-110, 171-285) on `yak cntasm`
+    (main.c:90-161): three assemblies, unique k-mers per sample, merged, shrunk, tightened, dumped"""
+    import ctypes as C
+    O = oracle.lib()
+    O.yko_ch_merge.argtypes = [C.POINTER(oracle.Ch), C.POINTER(oracle.Ch), C.c_int, C.c_int, C.c_int]
+    O.yko_ch_shrink.argtypes = [C.POINTER(oracle.Ch), C.c_int, C.c_int]
+    O.yko_ch_tighten.argtypes = [C.POINTER(oracle.Ch)]
+    fas = []
+    for j, e in enumerate((0.0, 0.004, 0.008)):
+        fa = str(tmp_path / f"asm{j}.fa")
+        subprocess.check_call([SYN, "-a", "-n", "10", "-l", "15000", "-g", "100000", "-s", "9", "-e", str(e), "-N", "0.0002", "-o", fa])
+        fas.append(fa)
+    K = 21
+    oo = oracle.copt(k=K, chunk=1900000000)
+    ho = None
+    for i, fa in enumerate(fas):
+        g1 = O.yko_count_file(fa.encode(), C.byref(oo), None)
+        if ho is None:
+            ho = g1
+            O.yko_ch_shrink(ho, 1, 1); O.yko_ch_setcnt(ho, 1)
+        else:
+            O.yko_ch_merge(ho, g1, 1, 1, pre_resize)
+        if i == len(fas) - 1:
+            O.yko_ch_shrink(ho, i + 1, 1023)
+    O.yko_ch_tighten(ho)
+    out = str(tmp_path / "ref.yak")
+    subprocess.run([REF, "cntasm", f"-k{K}"] + (["-r"] if pre_resize else []) + ["-o", out] + fas, check=True, stderr=subprocess.DEVNULL)
+    assert open(out, "rb").read() == oracle.dump_bytes(ho)
+    O.yko_ch_destroy(ho)
+
+
+@pytest.mark.parametrize("cmd", ["subtract", "isec"])
+def test_subtract_isec_sequence_on_the_oracle_equals_reference_cli(cmd, tmp_path, oracle):
+    """`yak subtract` / `yak isec` (main.c:217-284) against the oracle's restore + set operation + tighten"""
+    import ctypes as C
+    O = oracle.lib()
+    O.yko_ch_subtract.argtypes = [C.POINTER(oracle.Ch)] * 2; O.yko_ch_isec.argtypes = [C.POINTER(oracle.Ch)] * 2
+    O.yko_ch_tighten.argtypes = [C.POINTER(oracle.Ch)]
+    tabs = []
+    for j, (n, e) in enumerate(((9000, 0.004), (4000, 0.02))):
+        fq, t = str(tmp_path / f"r{j}.fq"), str(tmp_path / f"t{j}.yak")
+        subprocess.check_call([SYN, "-n", str(n), "-l", "150", "-g", "50000", "-s", "17", "-e", str(e), "-o", fq])
+        subprocess.run([REF, "count", "-k25", "-o", t, fq], check=True, stderr=subprocess.DEVNULL)
+        tabs.append(t)
+    out = str(tmp_path / "ref.yak")
+    subprocess.run([REF, cmd, "-o", out] + tabs, check=True, stderr=subprocess.DEVNULL)
+    o0, o1 = O.yko_ch_restore(tabs[0].encode()), O.yko_ch_restore(tabs[1].encode())
+    (O.yko_ch_subtract if cmd == "subtract" else O.yko_ch_isec)(o0, o1)
+    O.yko_ch_tighten(o0)
+    assert open(out, "rb").read() == oracle.dump_bytes(o0)
+    O.yko_ch_destroy(o0); O.yko_ch_destroy(o1)
