@@ -20,6 +20,13 @@
 #define YAK_MAX_KMER     31
 #define YAK_COUNTER_BITS 10
 #define YAK_N_COUNTS     (1<<YAK_COUNTER_BITS)
+
+#define YAK_LOAD_ALL       1      /* reference yak.h:16-21 */
+#define YAK_LOAD_TRIOBIN1  2
+#define YAK_LOAD_TRIOBIN2  3
+#define YAK_LOAD_SEXCHR1   4
+#define YAK_LOAD_SEXCHR2   5
+#define YAK_LOAD_SEXCHR3   6
 #define YAK_MAX_COUNT    ((1<<YAK_COUNTER_BITS)-1)
 #define YAK_BLK_SHIFT    9
 #define YAK_BLK_MASK     ((1<<(YAK_BLK_SHIFT)) - 1)
@@ -105,6 +112,8 @@ void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread);  /* reference h
 
 int yak_ch_dump(const yak_ch_t *h, const char *fn);               /* reference htab.c:373 */
 yak_ch_t *yak_ch_restore(const char *fn);                         /* reference htab.c:478 */
+/* reference htab.c:396: mode = YAK_LOAD_*; the two trio-binning modes take (int min_cnt, int mid_cnt) */
+yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...);
 
 /* reference count.c:147: count the k-mers of a FASTA/FASTQ(.gz) file ("-"/NULL = stdin).
  * h0 == NULL: create a table (bloom-gated if opt->bf_shift > pre) and return it;

@@ -82,6 +82,8 @@ void      yko_ch_isec(yko_ch_t *h0, const yko_ch_t *h1);
 yko_knt_t *yko_ch_getseq(const yko_ch_t *h, int w, uint32_t *n);
 int       yko_ch_dump(const yko_ch_t *h, const char *fn);
 yko_ch_t *yko_ch_restore(const char *fn);
+/* htab.c:396-476; mode as YAK_LOAD_* (yak.h:16-21); min_cnt / mid_cnt only in modes 2, 3 */
+yko_ch_t *yko_ch_restore_core(yko_ch_t *ch0, const char *fn, int mode, int min_cnt, int mid_cnt);
 /* serialise to memory in .yak format; caller frees *out */
 size_t    yko_ch_dump_mem(const yko_ch_t *h, uint8_t **out);
 /* sub-table introspection for tests */

@@ -459,28 +459,48 @@ int yko_ch_dump(const yko_ch_t *h, const char *fn)
 	return 0;
 }
 
-yko_ch_t *yko_ch_restore(const char *fn)                     /* htab.c:396-481, mode YAK_LOAD_ALL */
+/* htab.c:396-476.  mode 1 = all keys as stored; 2 / 3 = trio binning flags (counts >= mid_cnt -> 2,
+ * >= min_cnt -> 1, below -> dropped; shifted left by 2 in mode 3); 4 / 5 / 6 = sex chromosome flags
+ * 1 / 2 / 4.  In the flag modes the low 10 bits of a stored key are a flag set: a key already in the
+ * table gets the new flag ORed in.  Modes 3, 5, 6 need an existing table. */
+yko_ch_t *yko_ch_restore_core(yko_ch_t *ch0, const char *fn, int mode, int min_cnt, int mid_cnt)
 {
-	FILE *fp = fopen(fn, "rb");
+	FILE *fp;
 	char magic[4];
 	uint32_t t[3];
 	yko_ch_t *h;
 	int p;
+	const uint64_t mask = (1ULL << YKO_COUNTER_BITS) - 1;
+	if (mode < 1 || mode > 6) return 0;
+	if (ch0 == 0 && (mode == 3 || mode == 5 || mode == 6)) return 0;
+	fp = fopen(fn, "rb");
 	if (!fp) return 0;
 	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "YAK\2", 4) != 0) { fclose(fp); return 0; }
 	if (fread(t, 4, 3, fp) != 3 || t[2] != YKO_COUNTER_BITS) { fclose(fp); return 0; }
-	h = yko_ch_init((int)t[0], (int)t[1], 0, 0);
+	h = ch0 ? ch0 : yko_ch_init((int)t[0], (int)t[1], 0, 0);
 	for (p = 0; p < 1 << h->pre; ++p) {
 		uint32_t j, u[2];
 		if (fread(u, 4, 2, fp) != 2) break;
 		yko_set_resize(h->h[p].h, u[0]);                      /* to the saved capacity (htab.c:441) */
 		for (j = 0; j < u[1]; ++j) {
-			uint64_t key; int absent;
+			uint64_t key; int absent, x = -1;
+			uint32_t k;
 			if (fread(&key, 8, 1, fp) != 1) break;
-			yko_set_put(h->h[p].h, key, &absent);              /* file order (htab.c:447) */
+			if (mode == 1) { yko_set_put(h->h[p].h, key, &absent); continue; }   /* file order (htab.c:447) */
+			if (mode == 2 || mode == 3) {
+				const int cnt = (int)(key & mask), shift = mode == 2 ? 0 : 2;
+				if (cnt >= mid_cnt) x = 2 << shift;
+				else if (cnt >= min_cnt) x = 1 << shift;
+			} else x = 1 << (mode - 4);
+			if (x < 0) continue;
+			key = (key & ~mask) | (uint64_t)x;
+			k = yko_set_put(h->h[p].h, key, &absent);
+			if (!absent) h->h[p].h->keys[k] |= (uint64_t)x;
 		}
 	}
 	fclose(fp);
-	h->tot = 0;          /* the reference leaves tot = 0 after restore: it is not serialised */
+	if (!ch0) h->tot = 0;          /* the reference leaves tot = 0 after restore: it is not serialised */
 	return h;
 }
+
+yko_ch_t *yko_ch_restore(const char *fn) { return yko_ch_restore_core(0, fn, 1, 0, 0); }   /* htab.c:478 */

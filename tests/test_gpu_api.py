@@ -318,3 +318,31 @@ def test_subtract_and_isec_protocols_equal_reference_cli(cmd, ya, oracle, synth,
         assert O.yko_ch_dump(o0, want.encode()) == 0
     a, b = open(out, "rb").read(), open(want, "rb").read()
     assert a == b and len(a) > 16 + 8 * 1024
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["triobin", "sexchr"])
+def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_path):
+    """yak_ch_restore_core modes 2-6 (htab.c:396-476): flag sets of several .yak files ORed into one
+    table -- the loads of `yak triobin` (main.c) and `yak sexchr`; bytes against the oracle (itself pinned
+    on the reference's library, tests/test_oracle_vs_ref.py)"""
+    L, O = ya.lib(), oracle.lib()
+    O.yko_ch_restore_core.restype = C.POINTER(oracle.Ch)
+    O.yko_ch_restore_core.argtypes = [C.POINTER(oracle.Ch), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    fa, fb = _two_tables(ya, oracle, synth, tmp_path)
+    img = synth(5000, g=50000, s=18, e=0.006)
+    o = oracle.copt(k=25)
+    hc = O.yko_count_protocol_mem(img, len(img), None, 0, C.byref(o))
+    fc = str(tmp_path / "t2.yak")
+    assert O.yko_ch_dump(hc, fc.encode()) == 0
+    O.yko_ch_destroy(hc)
+    steps = [(2, fa), (3, fb)] if family == "triobin" else [(4, fa), (5, fb), (6, fc)]
+    h, ho = None, None
+    for mode, fn in steps:
+        h = L.yak_ch_restore_core(h, fn.encode(), C.c_int(mode), C.c_int(2), C.c_int(5))
+        ho = O.yko_ch_restore_core(ho, fn.encode(), mode, 2, 5)
+        assert h and ho
+        assert _dump(L, h) == oracle.dump_bytes(ho), (family, mode)
+    assert not L.yak_ch_restore_core(None, fa.encode(), C.c_int(3), C.c_int(2), C.c_int(5))     # htab.c:413: needs a table
+    assert L.yak_ch_get(h, 0) in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15)                       # lookups work on the flag table
+    L.yak_ch_destroy(h); O.yko_ch_destroy(ho)

@@ -90,3 +90,38 @@ def test_subtract_isec_sequence_on_the_oracle_equals_reference_cli(cmd, tmp_path
     O.yko_ch_tighten(o0)
     assert open(out, "rb").read() == oracle.dump_bytes(o0)
     O.yko_ch_destroy(o0); O.yko_ch_destroy(o1)
+
+
+def _three_tables(tmp_path):
+    tabs = []
+    for j, (n, e, s) in enumerate(((9000, 0.004, 17), (6000, 0.01, 17), (5000, 0.006, 18))):
+        fq, t = str(tmp_path / f"r{j}.fq"), str(tmp_path / f"t{j}.yak")
+        subprocess.check_call([SYN, "-n", str(n), "-l", "150", "-g", "50000", "-s", str(s), "-e", str(e), "-o", fq])
+        subprocess.run([REF, "count", "-k25", "-o", t, fq], check=True, stderr=subprocess.DEVNULL)
+        tabs.append(t)
+    return tabs
+
+
+@pytest.mark.parametrize("family", ["triobin", "sexchr"])
+def test_restore_core_flag_modes_equal_reference_library(family, tmp_path, oracle):
+    """yak_ch_restore_core modes 2-6 (htab.c:396-476) called in the reference's own shared library
+    (oracle/_ref/libyakref.so) against the oracle's restatement: flag sets ORed into one table"""
+    import ctypes as C
+    from oracle.pyoracle import REF_LIB
+    R, O = C.CDLL(REF_LIB), oracle.lib()
+    R.yak_ch_restore_core.restype = C.c_void_p
+    R.yak_ch_dump.argtypes = [C.c_void_p, C.c_char_p]
+    O.yko_ch_restore_core.restype = C.POINTER(oracle.Ch)
+    O.yko_ch_restore_core.argtypes = [C.POINTER(oracle.Ch), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    tabs = _three_tables(tmp_path)
+    steps = [(2, tabs[0]), (3, tabs[1])] if family == "triobin" else [(4, tabs[0]), (5, tabs[1]), (6, tabs[2])]
+    hr, ho = None, None
+    for mode, fn in steps:
+        hr = R.yak_ch_restore_core(C.c_void_p(hr), fn.encode(), C.c_int(mode), C.c_int(2), C.c_int(5))
+        ho = O.yko_ch_restore_core(ho, fn.encode(), mode, 2, 5)
+        assert hr and ho
+    out = str(tmp_path / "ref.yak")
+    assert R.yak_ch_dump(C.c_void_p(hr), out.encode()) == 0
+    data = open(out, "rb").read()
+    assert data == oracle.dump_bytes(ho) and len(data) > 16 + 8 * 1024
+    assert O.yko_ch_restore_core(None, tabs[0].encode(), 3, 2, 5) is None or not O.yko_ch_restore_core(None, tabs[0].encode(), 3, 2, 5)

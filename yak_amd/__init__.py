@@ -21,7 +21,7 @@ YAK_H_SYMBOLS = [
     "yak_ch_init", "yak_ch_destroy", "yak_ch_destroy_bf", "yak_ch_insert_list", "yak_ch_get",
     "yak_ch_inc", "yak_ch_getseq", "yak_ch_clear", "yak_ch_hist", "yak_ch_shrink", "yak_ch_dump",
     "yak_ch_restore", "yak_count", "yak_verbose", "seq_nt4_table", "yak_qopt_init", "yak_qv", "yak_recount", "yak_ch_setcnt",
-    "yak_ch_tighten", "yak_ch_merge", "yak_ch_subtract", "yak_ch_isec",
+    "yak_ch_tighten", "yak_ch_merge", "yak_ch_subtract", "yak_ch_isec", "yak_ch_restore_core",
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
@@ -123,6 +123,7 @@ def lib():
     L.yakamd_host_image.restype = C.c_int64
     L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
     L.yak_ch_setcnt.argtypes = [P(ChT), C.c_int, C.c_int]
+    L.yak_ch_restore_core.restype = P(ChT)
     L.yak_ch_tighten.argtypes = [P(ChT)]
     L.yak_ch_merge.argtypes = [P(ChT), P(ChT), C.c_int, C.c_int, C.c_int, C.c_int]
     L.yak_ch_subtract.argtypes = [P(ChT), P(ChT), C.c_int]

@@ -167,7 +167,7 @@ struct yakamd_ctx {
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
-	bool in_pass; int create_new; bool bloom_mode; bool gate_off;   /* gate_off: puts of a merge never consult the filter */
+	bool in_pass; int create_new; bool bloom_mode; bool gate_off; bool or_mode;   /* gate_off: puts of a merge never consult the filter */
 	AccTab acc; u64 acc_count;
 	u64 *d_counters, *d_lastput, *d_lpbatch;
 	u32 *d_missing, *d_nmissing;
@@ -246,7 +246,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
 	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
 	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false;
-	c->in_pass = false; c->gate_off = false; c->acc.s = 0; c->acc_count = 0;
+	c->in_pass = false; c->gate_off = false; c->or_mode = false; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
 	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
@@ -945,6 +945,7 @@ static int fast_finish(yakamd_ctx *c)
 	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
 	fp.dbg = (int)env_i64("YAKAMD_DBG", 0);
+	fp.or_mode = c->or_mode;
 	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them */
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + 599) / 600) : 0;
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
@@ -1093,6 +1094,9 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		c->host_valid = false;
+	} else if (c->or_mode && !(c->fast && !c->acc.s)) {
+		pass_free(c);
+		return fail("flag-mode loads need the exclusive-ownership path (prefix length <= 13, input within the device budget)");
 	} else if (c->fast && !c->acc.s) {
 		const u64 before = c->img_keys_total;
 		if (fast_finish(c)) return -1;
@@ -1338,6 +1342,17 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 }
 void yk_pool_release(void *p) { if (p) pool_free(p); }
 void yk_ctx_gate(yakamd_ctx *c, bool on) { c->gate_off = !on; }
+void yk_ctx_or_mode(yakamd_ctx *c, bool on) { c->or_mode = on; }
+
+/* khashl resize(want[p]) on every sub-table (htab.c:441 on an existing table): same size re-places in place */
+int yk_ctx_resize_to(yakamd_ctx *c, const uint32_t *want)
+{
+	const int P = c->P;
+	std::vector<u32> nb(P, YK_LEAVE);
+	bool any = false;
+	for (int p = 0; p < P; ++p) { nb[p] = resize_target(c->h_count[p], want[p]); any = any || nb[p] != YK_LEAVE; }
+	return any ? resize_tables(c, nb) : 0;
+}
 u64 yk_ctx_keys_total(yakamd_ctx *c) { return c->img_keys_total; }
 
 /* reference htab.c:441-447: resize each sub-table to its saved capacity, then put in file order */

@@ -2169,7 +2169,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			const int64_t idx = img_find(img, T.K[s]);
 			if (idx >= 0) {
 				const u64 kc = img.keys[idx], c = (kc & 1023) + (T.CN[s] & LC_CMASK);
-				img.keys[idx] = (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+				img.keys[idx] = fp.or_mode ? kc | (T.T1[s] & 15u) : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
 				T.CN[s] |= LC_EXIST;
 			}
 		}
@@ -2288,6 +2288,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 		else if (T.T2[s] != T32_INF) { *Tt = T.T2[s]; c -= 1; }
 		else return false;
 		if (c > 1023) c = 1023;
+		if (fp.or_mode) c = T.T1[s] & 15u;                        /* a key seen once per load: its flag travels in the time's low bits */
 		*kc = (T.K[s] >> fp.pre) << 10 | c;
 		return true;
 	};

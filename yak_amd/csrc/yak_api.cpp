@@ -16,6 +16,7 @@
 #include <sys/resource.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <cstdarg>
 #include <vector>
 #include <string>
 #include <cmath>
@@ -344,24 +345,22 @@ int yak_ch_dump(const yak_ch_t *h, const char *fn)
 
 /* reference htab.c:396-481 (mode YAK_LOAD_ALL): every sub-table is pre-sized to the saved
  * capacity and the keys are put back in file order -- the same staged FCFS replay as shrink */
-yak_ch_t *yak_ch_restore(const char *fn)
+/* reads a .yak file (htab.c:413-433): header checks, then per sub-table capacity, size and keys */
+static bool read_yak(const char *fn, uint32_t hdr[3], std::vector<uint32_t> &caps, std::vector<uint32_t> &sizes, std::vector<uint64_t> &keys)
 {
 	FILE *fp = fopen(fn, "rb");
 	char magic[4];
-	uint32_t t[3];
-	if (fp == 0) return 0;
-	if (fread(magic, 1, 4, fp) != 4) { fclose(fp); return 0; }
-	if (strncmp(magic, YAK_MAGIC, 4) != 0) { fprintf(stderr, "ERROR: wrong file magic.\n"); fclose(fp); return 0; }
-	if (fread(t, 4, 3, fp) != 3) { fclose(fp); return 0; }
-	if (t[2] != YAK_COUNTER_BITS) {
-		fprintf(stderr, "ERROR: saved counter bits: %d; compile-time counter bits: %d\n", t[2], YAK_COUNTER_BITS);
-		fclose(fp); return 0;
+	if (fp == 0) return false;
+	if (fread(magic, 1, 4, fp) != 4) { fclose(fp); return false; }
+	if (strncmp(magic, YAK_MAGIC, 4) != 0) { fprintf(stderr, "ERROR: wrong file magic.\n"); fclose(fp); return false; }
+	if (fread(hdr, 4, 3, fp) != 3) { fclose(fp); return false; }
+	if (hdr[2] != YAK_COUNTER_BITS) {
+		fprintf(stderr, "ERROR: saved counter bits: %d; compile-time counter bits: %d\n", hdr[2], YAK_COUNTER_BITS);
+		fclose(fp); return false;
 	}
-	yak_ch_t *h = yak_ch_init((int)t[0], (int)t[1], 0, 0);
-	if (h == 0) { fclose(fp); return 0; }
-	const int P = 1 << h->pre;
-	std::vector<uint32_t> caps(P, 0), sizes(P, 0);
-	std::vector<uint64_t> keys;
+	if (hdr[1] < YAK_COUNTER_BITS || hdr[1] > 24) { fclose(fp); return false; }
+	const int P = 1 << hdr[1];
+	caps.assign(P, 0); sizes.assign(P, 0); keys.clear();
 	for (int p = 0; p < P; ++p) {
 		uint32_t u[2];
 		if (fread(u, 4, 2, fp) != 2) break;
@@ -371,10 +370,75 @@ yak_ch_t *yak_ch_restore(const char *fn)
 		if (u[1] && fread(&keys[at], 8, u[1], fp) != u[1]) break;
 	}
 	fclose(fp);
-	if (yk_ctx_load(((yak_ch_ext*)h)->ctx, caps.data(), sizes.data(), keys.data()) != 0) { yak_ch_destroy(h); return 0; }
-	fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", "yak_ch_restore_core", (long)keys.size(), (long)keys.size());
+	return true;
+}
+
+/* reference htab.c:396-476.  YAK_LOAD_ALL builds the table from the file; the flag modes (trio binning
+ * 2 / 3 with min_cnt, mid_cnt; sex chromosomes 4 / 5 / 6) put every selected key with a flag in its low
+ * bits, ORing the flag into keys already present -- one counting pass on the device whose records
+ * carry the flag in the low 4 bits of their list position. */
+yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...)
+{
+	int min_cnt = 0, mid_cnt = 0;
+	va_list ap;
+	va_start(ap, mode);
+	if (mode == YAK_LOAD_TRIOBIN1 || mode == YAK_LOAD_TRIOBIN2) { min_cnt = va_arg(ap, int); mid_cnt = va_arg(ap, int); }
+	va_end(ap);
+	if (mode < YAK_LOAD_ALL || mode > YAK_LOAD_SEXCHR3) return 0;
+	if (ch0 == 0 && (mode == YAK_LOAD_TRIOBIN2 || mode == YAK_LOAD_SEXCHR2 || mode == YAK_LOAD_SEXCHR3)) return 0;   /* htab.c:413-420 */
+	uint32_t hdr[3];
+	std::vector<uint32_t> caps, sizes;
+	std::vector<uint64_t> keys;
+	if (!read_yak(fn, hdr, caps, sizes, keys)) return 0;
+	if (mode == YAK_LOAD_ALL) {
+		if (ch0) { fprintf(stderr, "[E::%s] YAK_LOAD_ALL into an existing table is not supported\n", __func__); return 0; }
+		yak_ch_t *h = yak_ch_init((int)hdr[0], (int)hdr[1], 0, 0);
+		if (h == 0) return 0;
+		if (yk_ctx_load(((yak_ch_ext*)h)->ctx, caps.data(), sizes.data(), keys.data()) != 0) { yak_ch_destroy(h); return 0; }
+		fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", __func__, (long)keys.size(), (long)keys.size());
+		return h;
+	}
+	yak_ch_t *h = ch0 ? ch0 : yak_ch_init((int)hdr[0], (int)hdr[1], 0, 0);
+	if (h == 0) return 0;
+	assert((int)hdr[0] == h->k && (int)hdr[1] == h->pre);       /* htab.c:437 */
+	yakamd_ctx *c = ((yak_ch_ext*)h)->ctx;
+	const int P = 1 << h->pre;
+	const uint64_t mask = (1ULL << YAK_COUNTER_BITS) - 1;
+	std::vector<uint64_t> hashes;
+	std::vector<uint32_t> times;
+	size_t at = 0;
+	for (int p = 0; p < P; ++p)
+		for (uint32_t j = 0; j < sizes[p]; ++j, ++at) {
+			const uint64_t key = keys[at];
+			int x;
+			if (mode == YAK_LOAD_TRIOBIN1 || mode == YAK_LOAD_TRIOBIN2) {
+				const int cnt = (int)(key & mask), shift = mode == YAK_LOAD_TRIOBIN1 ? 0 : 2;
+				x = cnt >= mid_cnt ? 2 << shift : cnt >= min_cnt ? 1 << shift : -1;
+			} else x = 1 << (mode - YAK_LOAD_SEXCHR1);
+			if (x < 0) continue;
+			hashes.push_back((key >> YAK_COUNTER_BITS) << h->pre | (uint64_t)p);
+			times.push_back((uint32_t)(hashes.size() - 1) << 4 | (uint32_t)x);
+		}
+	const size_t n = hashes.size();
+	bool ok = n < ((size_t)1 << 28) && yk_ctx_resize_to(c, caps.data()) == 0;     /* htab.c:441 */
+	long n_new = 0;
+	if (ok && n) {
+		void *d_h = yakamd_dev_alloc(n * 8), *d_t = yakamd_dev_alloc(n * 4);
+		ok = d_h && d_t && yakamd_memcpy_h2d(d_h, hashes.data(), n * 8) == 0 && yakamd_memcpy_h2d(d_t, times.data(), n * 4) == 0;
+		if (ok) {
+			yk_ctx_gate(c, false); yk_ctx_or_mode(c, true);
+			ok = yakamd_pass_begin(h, 1) == 0 && yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)n, 0, (uint64_t)n << 4) == 0;
+			if (ok) { const int64_t r = yakamd_pass_end(h); ok = r >= 0; n_new = (long)r; }
+			yk_ctx_gate(c, true); yk_ctx_or_mode(c, false);
+		}
+		yakamd_dev_free(d_h); yakamd_dev_free(d_t);
+	}
+	if (!ok) { fprintf(stderr, "[E::%s] %s\n", __func__, n < ((size_t)1 << 28) ? yakamd_last_error() : "more than 2^28 k-mers in one file"); if (!ch0) yak_ch_destroy(h); return 0; }
+	fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", __func__, (long)n, n_new);
 	return h;
 }
+
+yak_ch_t *yak_ch_restore(const char *fn) { return yak_ch_restore_core(0, fn, YAK_LOAD_ALL); }   /* reference htab.c:478 */
 
 /* ------------------------------------------------------------------------------------------
  * FASTA/FASTQ record reader with the observable behaviour of the reference's parser as driven by

@@ -152,6 +152,7 @@ struct FastParams {
 	int img_nonempty;
 	int plo, phi;
 	int dbg, bf_virgin;             /* dbg: timing ablations only (YAKAMD_DBG); bf_virgin: filter never written (all zero) */
+	int or_mode;                    /* flag-set loads (htab.c:449-470): the low 4 bits of a record's time are a flag, ORed into the key's low bits instead of counting */
 	u64 t_pass0;
 };
 
