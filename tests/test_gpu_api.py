@@ -346,3 +346,29 @@ def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_pa
     assert not L.yak_ch_restore_core(None, fa.encode(), C.c_int(3), C.c_int(2), C.c_int(5))     # htab.c:413: needs a table
     assert L.yak_ch_get(h, 0) in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15)                       # lookups work on the flag table
     L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+@pytest.mark.gpu
+def test_concurrent_get_after_restore(ya, oracle, synth, tmp_path):
+    """yak_ch_get from several threads at once, the first calls racing on the host-mirror refresh
+    (the reference's kt_for workers do exactly that: qv.c:59, triobin.c)"""
+    import threading
+    import numpy as np
+    L, O = ya.lib(), oracle.lib()
+    fa, _ = _two_tables(ya, oracle, synth, tmp_path)
+    h, ho = L.yak_ch_restore(fa.encode()), O.yko_ch_restore(fa.encode())
+    img = synth(300, g=50000, s=17, e=0.01)
+    hh = np.empty(len(img), dtype=np.uint64); tt = np.empty(len(img), dtype=np.uint32)
+    m = O.yko_extract_pos(25, img, len(img), hh.ctypes.data, tt.ctypes.data)
+    want = [O.yko_ch_get(ho, int(x)) for x in hh[:m]]
+    got = [None] * 8
+
+    def work(j):
+        got[j] = [L.yak_ch_get(h, int(x)) for x in hh[:m]]
+    th = [threading.Thread(target=work, args=(j,)) for j in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(g == want for g in got) and any(v > 0 for v in want) and any(v < 0 for v in want)
+    L.yak_ch_destroy(h); O.yko_ch_destroy(ho)

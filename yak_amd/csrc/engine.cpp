@@ -1378,6 +1378,11 @@ struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };   /* 
 
 int yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h)
 {
+	/* yak_ch_get() is called concurrently by the reference's kt_for workers (qv.c:59, triobin.c): the
+	 * first callers serialise on the refresh, later ones only read the flag */
+	if (__atomic_load_n(&c->host_valid, __ATOMIC_ACQUIRE)) return 0;
+	static std::mutex mu;
+	std::lock_guard<std::mutex> lk(mu);
 	if (c->host_valid) return 0;
 	HIPCK(hipSetDevice(c->dev));
 	if (c->hm_slots < c->n_slots) {
@@ -1401,7 +1406,7 @@ int yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h)
 		g->used = c->hm_used + c->h_off[p] / 32;
 		if (h) h->h[p].h = g;
 	}
-	c->host_valid = true;
+	__atomic_store_n(&c->host_valid, true, __ATOMIC_RELEASE);
 	return 0;
 }
 
