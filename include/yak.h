@@ -56,6 +56,13 @@ typedef struct {                    /* reference yak.h:33-40 */
 	int64_t chunk_size;
 } yak_qopt_t;
 
+typedef struct {                    /* reference yak.h:42-47 */
+	int64_t tot;
+	double qv_raw, qv, cov, err;
+	double fpr_lower, fpr_upper;
+	double adj_cnt[1<<YAK_COUNTER_BITS];
+} yak_qstat_t;
+
 typedef struct {
 	int n_shift, n_hashes;
 	uint8_t *b;
@@ -127,6 +134,7 @@ void yak_recount(const char *fn, yak_ch_t *h);                  /* reference cou
  * least min_len bases, the table count of every k-mer; sequences whose fraction of present k-mers is
  * >= min_frac add their counts to cnt[YAK_N_COUNTS].  Runs on the device-resident table. */
 void yak_qopt_init(yak_qopt_t *opt);
+int yak_qv_solve(const int64_t *hist, const int64_t *cnt, int kmer, double fpr, yak_qstat_t *qs); /* qv.c:146: host arithmetic */
 void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *cnt);
 
 #ifdef __cplusplus

@@ -145,3 +145,47 @@ def test_lookup_and_reduce_entry_points(ya, oracle, synth, tmp_path):
     for p_ in (d_b, d_t, d_off, d_len, d_tot, d_non0, d_hist):
         L.yakamd_dev_free(p_)
     L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+# ------------------------------------------------------------------------------------------ host statistics
+@pytest.mark.skipif(not os.path.exists(REF), reason="prebuilt reference binary not present")
+@pytest.mark.parametrize("cov,e_asm", [(40, 0.002), (25, 0.0005), (60, 0.01), (3, 0.002)], ids=["40x", "25x_clean", "60x_noisy", "3x_low"])
+def test_qv_solve_prints_what_the_reference_prints(cov, e_asm, tmp_path):
+    """yak_qv_solve (qv.c:146-244) is host arithmetic: fed with the very histograms the reference
+    printed (CT columns 3 and 4), it must reproduce the reference's CT / FR / ER / CV / QV lines"""
+    import yak_amd
+    L = yak_amd.lib()
+    G = 200000
+    fq, fa, tab = str(tmp_path / "r.fq"), str(tmp_path / "a.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([SYN, "-n", str(G * cov // 150), "-l", "150", "-g", str(G), "-s", "23", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "40", "-l", "10000", "-g", str(G), "-s", "23", "-e", str(e_asm), "-N", "0.0001", "-o", fa])
+    subprocess.run([REF, "count", "-k21", "-b28", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+    out = subprocess.run([REF, "qv", tab, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().splitlines()
+    ct = {int(f[1]): f for f in (l.split("\t") for l in out if l.startswith("CT\t"))}
+    hist = (C.c_int64 * 1024)(*[int(ct[i][2]) for i in range(1024)])
+    cnt = (C.c_int64 * 1024)(*[int(ct[i][3]) for i in range(1024)])
+    qs = yak_amd.QstatT()
+    L.yak_qv_solve(hist, cnt, 21, 0.00004, C.byref(qs))
+    import math
+
+    def f3(x):                                                # C's printf keeps the sign of a NaN, Python's % does not
+        return ("-nan" if math.copysign(1.0, x) < 0 else "nan") if math.isnan(x) else "%.3f" % x
+    mine = ["CT\t%d\t%d\t%d\t%s" % (i, hist[i], cnt[i], f3(qs.adj_cnt[i])) for i in range(1023, -1, -1)]
+    mine += ["FR\t%.3g\t%.3g" % (qs.fpr_lower, qs.fpr_upper), "ER\t%d\t%s" % (qs.tot, f3(qs.err)), "CV\t%s" % f3(qs.cov),
+             "QV\t%s\t%s" % (f3(qs.qv_raw), f3(qs.qv))]
+    assert mine == [l for l in out if l[:2] in ("CT", "FR", "ER", "CV", "QV")]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF), reason="prebuilt reference binary not present")
+def test_yak_amd_qv_full_output_equals_reference(ya, tmp_path):
+    """`yak-amd qv -p` against `yak qv -p`: every line, SQ lines as a sorted set"""
+    G = 150000
+    fq, fa, tab = str(tmp_path / "r.fq"), str(tmp_path / "a.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([SYN, "-n", str(G * 35 // 150), "-l", "150", "-g", str(G), "-s", "29", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "30", "-l", "8000", "-g", str(G), "-s", "29", "-e", "0.003", "-N", "0.0001", "-o", fa])
+    subprocess.run([REF, "count", "-k21", "-b28", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+    a = subprocess.run([REF, "qv", "-p", tab, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().splitlines()
+    b = subprocess.run([YAM, "qv", "-p", tab, fa], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().splitlines()
+    assert sorted(l for l in a if l.startswith("SQ")) == sorted(l for l in b if l.startswith("SQ"))
+    assert [l for l in a if not l.startswith("SQ")] == [l for l in b if not l.startswith("SQ")] and any(l.startswith("QV") for l in a)

@@ -21,7 +21,7 @@ YAK_H_SYMBOLS = [
     "yak_ch_init", "yak_ch_destroy", "yak_ch_destroy_bf", "yak_ch_insert_list", "yak_ch_get",
     "yak_ch_inc", "yak_ch_getseq", "yak_ch_clear", "yak_ch_hist", "yak_ch_shrink", "yak_ch_dump",
     "yak_ch_restore", "yak_count", "yak_verbose", "seq_nt4_table", "yak_qopt_init", "yak_qv", "yak_recount", "yak_ch_setcnt",
-    "yak_ch_tighten", "yak_ch_merge", "yak_ch_subtract", "yak_ch_isec", "yak_ch_restore_core",
+    "yak_ch_tighten", "yak_ch_merge", "yak_ch_subtract", "yak_ch_isec", "yak_ch_restore_core", "yak_qv_solve",
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
@@ -47,6 +47,11 @@ class ChT(C.Structure):                        # yak_ch_t (reference yak.h:61-65
 class QoptT(C.Structure):                      # yak_qopt_t (reference yak.h:33-40)
     _fields_ = [("print_each", C.c_int32), ("print_err_kmer", C.c_int32), ("min_len", C.c_int32),
                 ("n_threads", C.c_int32), ("min_frac", C.c_double), ("fpr", C.c_double), ("chunk_size", C.c_int64)]
+
+
+class QstatT(C.Structure):                     # yak_qstat_t (reference yak.h:42-47)
+    _fields_ = [("tot", C.c_int64), ("qv_raw", C.c_double), ("qv", C.c_double), ("cov", C.c_double), ("err", C.c_double),
+                ("fpr_lower", C.c_double), ("fpr_upper", C.c_double), ("adj_cnt", C.c_double * 1024)]
 
 
 class StatsT(C.Structure):                     # yakamd_stats_t
@@ -124,6 +129,8 @@ def lib():
     L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
     L.yak_ch_setcnt.argtypes = [P(ChT), C.c_int, C.c_int]
     L.yak_ch_restore_core.restype = P(ChT)
+    L.yak_qv_solve.restype = C.c_int
+    L.yak_qv_solve.argtypes = [P(C.c_int64), P(C.c_int64), C.c_int, C.c_double, P(QstatT)]
     L.yak_ch_tighten.argtypes = [P(ChT)]
     L.yak_ch_merge.argtypes = [P(ChT), P(ChT), C.c_int, C.c_int, C.c_int, C.c_int]
     L.yak_ch_subtract.argtypes = [P(ChT), P(ChT), C.c_int]

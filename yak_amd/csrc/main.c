@@ -20,15 +20,15 @@ static long long parse_num(const char *s)                    /* K/M/G suffixes a
 	return (long long)(x + .499);
 }
 
-/* `yak-amd qv`: the table side of reference main.c:163-215 (main_qv) -- restore, histogram, the
- * device lookup of every k-mer of <seq.fa>.  The statistics of yak_qv_solve (FR/ER/CV/QV lines and
- * the fourth CT column) are host arithmetic outside this library; a reference build keeps them. */
+/* `yak-amd qv`: reference main.c:163-215 (main_qv) -- restore, histogram, the device lookup of every
+ * k-mer of <seq.fa>, then the host statistics of yak_qv_solve; same output lines as the reference. */
 static int main_qv(int argc, char *argv[])
 {
 	yak_qopt_t opt;
 	yak_ch_t *ch;
 	int64_t cnt[YAK_N_COUNTS], hist[YAK_N_COUNTS];
-	int c, i;
+	static yak_qstat_t qs;
+	int c, i, kmer;
 	yak_qopt_init(&opt);
 	while ((c = getopt(argc, argv, "K:t:l:f:pe:E")) >= 0) {
 		if (c == 'K') opt.chunk_size = parse_num(optarg);
@@ -45,9 +45,22 @@ static int main_qv(int argc, char *argv[])
 	}
 	ch = yak_ch_restore(argv[optind]);
 	if (ch == 0) { fprintf(stderr, "ERROR: failed to load '%s' (or no MI355X visible)\n", argv[optind]); return 1; }
+	kmer = ch->k;
 	yak_ch_hist(ch, hist, opt.n_threads);
+	printf("CC\tCT  kmer_occurrence    short_read_kmer_count  raw_input_kmer_count  adjusted_input_kmer_count\n");
+	printf("CC\tFR  fpr_lower_bound    fpr_upper_bound\n");
+	printf("CC\tER  total_input_kmers  adjusted_error_kmers\n");
+	printf("CC\tCV  coverage\n");
+	printf("CC\tQV  raw_quality_value  adjusted_quality_value\n");
+	printf("CC\n");
 	yak_qv(&opt, argv[optind + 1], ch, cnt);
-	for (i = YAK_N_COUNTS - 1; i >= 0; --i) printf("CT\t%d\t%ld\t%ld\n", i, (long)hist[i], (long)cnt[i]);
+	yak_qv_solve(hist, cnt, kmer, opt.fpr, &qs);
+	for (i = YAK_N_COUNTS - 1; i >= 0; --i)
+		printf("CT\t%d\t%ld\t%ld\t%.3f\n", i, (long)hist[i], (long)cnt[i], qs.adj_cnt[i]);
+	printf("FR\t%.3g\t%.3g\n", qs.fpr_lower, qs.fpr_upper);
+	printf("ER\t%ld\t%.3f\n", (long)qs.tot, qs.err);
+	printf("CV\t%.3f\n", qs.cov);
+	printf("QV\t%.3f\t%.3f\n", qs.qv_raw, qs.qv);
 	yak_ch_destroy(ch);
 	return 0;
 }

@@ -729,4 +729,113 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 	fx.close_file();
 }
 
+/* n x n linear system a x = b by Gauss-Jordan elimination with full pivoting (the solver the
+ * reference links as 6gjdn.c); the solution replaces b.  false if the matrix is singular. */
+static bool solve_full_pivot(double *a, double *b, int n)
+{
+	std::vector<int> col_of(n);
+	for (int k = 0; k < n; ++k) {
+		int pr = k, pc = k;
+		double big = 0.0;
+		for (int i = k; i < n; ++i)
+			for (int j = k; j < n; ++j)
+				if (fabs(a[i * n + j]) > big) { big = fabs(a[i * n + j]); pr = i; pc = j; }
+		if (big + 1.0 == 1.0) return false;
+		col_of[k] = pc;
+		if (pc != k) for (int i = 0; i < n; ++i) std::swap(a[i * n + k], a[i * n + pc]);
+		if (pr != k) { for (int j = k; j < n; ++j) std::swap(a[k * n + j], a[pr * n + j]); std::swap(b[k], b[pr]); }
+		const double piv = a[k * n + k];
+		for (int j = k + 1; j < n; ++j) a[k * n + j] /= piv;
+		b[k] /= piv;
+		for (int j = k + 1; j < n; ++j)
+			for (int i = 0; i < n; ++i)
+				if (i != k) a[i * n + j] -= a[i * n + k] * a[k * n + j];
+		for (int i = 0; i < n; ++i)
+			if (i != k) b[i] -= a[i * n + k] * b[k];
+	}
+	for (int k = n - 1; k >= 0; --k)                          /* undo the column exchanges */
+		if (col_of[k] != k) std::swap(b[k], b[col_of[k]]);
+	return true;
+}
+
+/* reference qv.c:146-244 -- host arithmetic on two 1024-bin histograms (hist: k-mer occurrence in the
+ * short reads, cnt: occurrences looked up for the assembly's k-mers): raw QV from the share of absent
+ * k-mers; coverage at the histogram peak; bounds on the false-positive rate of "absent"; error-corrected
+ * counts between the trough and the peak; a quadratic least-squares fit of the successive ratios
+ * extrapolated down to count 0; adjusted QV.  Returns -1 when the data cannot support the adjustment. */
+int yak_qv_solve(const int64_t *hist, const int64_t *cnt, int kmer, double fpr, yak_qstat_t *qs)
+{
+	const int n_cnt = YAK_N_COUNTS, deg = 2;
+	const double ln10_10 = 4.3429448190325175;              /* 10 / ln 10 */
+	memset(qs, 0, sizeof(*qs));
+	qs->qv = -1.0; qs->err = (double)cnt[0];
+	for (int c = 0; c < n_cnt; ++c) { qs->tot += cnt[c]; qs->adj_cnt[c] = (double)cnt[c]; }
+	qs->qv_raw = (qs->tot > 0 && qs->tot > cnt[0]) ? -ln10_10 * log(log((double)qs->tot / (qs->tot - cnt[0])) / kmer) : -1.0;
+
+	int peak = -1, trough = -1;
+	int32_t peak_cnt = 0;
+	for (int c = 2; c < n_cnt - 1; ++c) if (peak_cnt < cnt[c]) { peak_cnt = (int32_t)cnt[c]; peak = c; }
+	if (peak < 0) return -1;                                 /* nothing beyond count 1 */
+	int32_t trough_cnt = peak_cnt;
+	for (int c = 2; c < peak; ++c) if (trough_cnt > cnt[c]) { trough_cnt = (int32_t)cnt[c]; trough = c; }
+	qs->cov = (double)cnt[peak] / hist[peak];
+
+	qs->fpr_upper = 1.0;
+	for (int c = 2; c < peak; ++c) { const double e = cnt[c] / (qs->cov * hist[c]); if (qs->fpr_upper > e) qs->fpr_upper = e; }
+	if (fpr > qs->fpr_upper) fpr = qs->fpr_upper * 0.5;
+	qs->fpr_lower = 0.0;
+	if (trough > 2 && hist[2] > hist[trough]) {
+		const double e = (cnt[2] - cnt[trough]) / (qs->cov * (hist[2] - hist[trough]));
+		if (qs->fpr_lower < e) qs->fpr_lower = e;
+	}
+	if (fpr < qs->fpr_lower) fpr = qs->fpr_lower;
+	if (qs->fpr_lower >= qs->fpr_upper)
+		fprintf(stderr, "Warning: the FPR upper bound is smaller than the lower bound. Trust the lower bound.\n");
+
+	if (peak <= 4) return -1;                                /* not high-coverage data */
+	const int n_fit = peak - trough + 1 < 8 ? peak - trough + 1 : 8;
+	if (n_fit < 3) return -1;
+
+	for (int c = peak - 1; c >= trough; --c) {               /* remove the expected false "present" calls */
+		const double wrong = (hist[c] - cnt[c] / qs->cov) / (1.0 - fpr);
+		qs->adj_cnt[c] = cnt[c] - wrong * qs->cov * fpr;
+		if (qs->adj_cnt[c] < 0.0) qs->adj_cnt[c] = 0.0;
+	}
+
+	/* ratios adj[c+1] / adj[c] at c = trough .. trough + n_fit - 1, fitted by a + b c + c c^2 */
+	double xs[8], ys[8], pw[(2 * deg + 1) * 8], A[(deg + 1) * (deg + 1)], B[deg + 1];
+	for (int k = 0; k < n_fit; ++k) { xs[k] = trough + k; ys[k] = qs->adj_cnt[trough + k + 1] / qs->adj_cnt[trough + k]; }
+	for (int k = 0; k < n_fit; ++k) { double t = 1.0; for (int i = 0; i <= 2 * deg; ++i) { pw[i * n_fit + k] = t; t *= xs[k]; } }
+	for (int i = 0; i <= deg; ++i) {
+		for (int j = 0; j <= i; ++j) {
+			double sum = 0.0;
+			for (int k = 0; k < n_fit; ++k) sum += pw[(i + j) * n_fit + k];
+			A[i * (deg + 1) + j] = A[j * (deg + 1) + i] = sum;
+		}
+		double sum = 0.0;
+		for (int k = 0; k < n_fit; ++k) sum += pw[i * n_fit + k] * ys[k];
+		B[i] = sum;
+	}
+	if (!solve_full_pivot(A, B, deg + 1)) fprintf(stderr, "ERROR: fail\n");
+
+	for (int c = trough - 1; c >= 0; --c) {                  /* extrapolate below the trough */
+		double r = 0.0, t = 1.0;
+		for (int i = 0; i <= deg; ++i) { r += B[i] * t; t *= c; }
+		if (r < 1.01) r = 1.01;
+		qs->adj_cnt[c] = qs->adj_cnt[c + 1] / r;
+	}
+
+	double adj_sum = 0.0;
+	for (int c = 0; c < n_cnt; ++c) adj_sum += qs->adj_cnt[c];
+	if (adj_sum <= (double)qs->tot) {
+		qs->err = qs->tot - adj_sum;
+		qs->qv = -ln10_10 * log(log(qs->tot / adj_sum) / kmer);
+	} else {
+		fprintf(stderr, "WARNING: failed to estimate the calibrated QV\n");
+		qs->err = 0;
+		qs->qv = qs->qv_raw;
+	}
+	return 0;
+}
+
 } /* extern "C" */
