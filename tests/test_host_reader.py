@@ -15,10 +15,22 @@ SYN = os.path.join(ROOT, "tools", "yaksynth")
 
 
 def same(fn, oracle, k=0):
+    """general reader, in-buffer fast path, and the speculative parallel parser (several thread counts,
+    windows small enough that guesses fall into every kind of line) all give the oracle's image"""
     import yak_amd
     want = oracle.read_image(fn, k)
     assert yak_amd.host_image(fn, k, fast=True) == want
     assert yak_amd.host_image(fn, k, fast=False) == want
+    try:
+        for thr, win in ((2, 0), (3, 70001), (8, 0), (5, 1 << 20), (7, 333 if os.path.getsize(fn) < 300000 else 40009)):
+            os.environ["YAKAMD_PARSE_THREADS"] = str(thr)
+            if win:
+                os.environ["YAKAMD_PARSE_WINDOW"] = str(win)
+            else:
+                os.environ.pop("YAKAMD_PARSE_WINDOW", None)
+            assert yak_amd.host_image(fn, k, fast=True) == want, (thr, win)
+    finally:
+        os.environ.pop("YAKAMD_PARSE_THREADS", None); os.environ.pop("YAKAMD_PARSE_WINDOW", None)
     return want
 
 

@@ -17,6 +17,10 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <cstdarg>
+#include <thread>
+#include <functional>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <vector>
 #include <string>
 #include <cmath>
@@ -450,7 +454,7 @@ struct FxReader {
 	gzFile fp; int fd; unsigned char *buf; int beg, end, eof, last;
 	std::vector<char> seq, name; size_t qlen; int qlast;
 	enum { BUF = 1 << 20, NOT_FAST = -3 };
-	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0) {}
+	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0), mem(false), pfd(-1), poff(0), pos0(0) {}
 	/* open `fn` (NULL or "-": stdin); a plain (not gzip) regular file is then read with read(2), skipping zlib's copy */
 	bool open_file(const char *fn) {
 		const bool is_stdin = fn == 0 || strcmp(fn, "-") == 0;
@@ -461,12 +465,29 @@ struct FxReader {
 		buf = (unsigned char*)malloc(BUF);
 		return true;
 	}
-	void close_file() { if (fd >= 0) ::close(fd); if (fp) gzclose(fp); free(buf); fp = 0; fd = -1; buf = 0; }
+	void close_file() { if (fd >= 0) ::close(fd); if (fp) gzclose(fp); if (!mem) free(buf); fp = 0; fd = -1; buf = 0; }
+	/* positional mode for the parallel parser: read a plain file from offset `from` with pread(2) on a shared descriptor */
+	bool mem; int pfd; int64_t poff, pos0;
+	void open_at(int shared_fd, int64_t from) { pfd = shared_fd; poff = pos0 = from; buf = (unsigned char*)malloc(BUF); beg = end = 0; eof = 0; last = 0; }
+	void close_at() { free(buf); buf = 0; }
+	/* consume up to the next record marker ('>' or '@', kseq.h:196-199) so that `last` holds it; false at EOF */
+	bool seek_marker() {
+		if (last != 0) return true;
+		int c;
+		while ((c = getc()) != -1 && c != '>' && c != '@') {}
+		if (c == -1) return false;
+		last = c;
+		return true;
+	}
+	int64_t marker_pos() const { return pos0 + (last != 0 ? beg - 1 : end); }   /* file offset of the marker `last` was read from (positional mode) */
 	bool fill() {
 		if (beg < end) return true;
 		if (eof) return false;
 		beg = 0;
-		if (fd >= 0) {                                       /* read(2) may return short counts before EOF */
+		if (pfd >= 0) {
+			pos0 = poff; end = 0;
+			while (end < BUF) { const ssize_t r = ::pread(pfd, buf + end, BUF - end, poff); if (r <= 0) break; end += (int)r; poff += r; }
+		} else if (fd >= 0) {                                /* read(2) may return short counts before EOF */
 			end = 0;
 			while (end < BUF) { const ssize_t r = ::read(fd, buf + end, BUF - end); if (r <= 0) break; end += (int)r; }
 		} else end = gzread(fp, buf, BUF);
@@ -557,6 +578,103 @@ struct FxReader {
 	}
 };
 
+/* ------------------------------------------------------------------------------------------
+ * Parallel parsing of a plain (uncompressed, mapped) file.  A window of the file is cut into one
+ * segment per thread.  Segment 0 starts at a verified record boundary; the others start at a GUESS
+ * (first line after the cut that begins with '>' or, for '@', whose third line begins with '+').
+ * Every thread parses records with the ordinary reader until the next record would start at or
+ * beyond its segment's end and reports where that is.  A segment's output is accepted only if the
+ * previous accepted segment stopped exactly at its start -- so the accepted stream is, by induction,
+ * what the single reader would have produced; the next window starts where the last accepted
+ * segment stopped.  A wrong guess costs time, never correctness.
+ * ------------------------------------------------------------------------------------------ */
+static int64_t env_threads_window() { const char *e = getenv("YAKAMD_PARSE_WINDOW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)1 << 30; }
+static int parse_threads(int n_thread)
+{
+	const char *e = getenv("YAKAMD_PARSE_THREADS");
+	int n = e ? atoi(e) : n_thread;
+	const int hw = (int)std::thread::hardware_concurrency();
+	if (hw > 0 && n > hw) n = hw;
+	return n < 1 ? 1 : n > 32 ? 32 : n;
+}
+
+struct ParSeg { int64_t start, end, stop; std::vector<char> img; int64_t n_seq, sum_len; bool hard_end; };
+
+static int64_t guess_record_start(int fd, int64_t from, int64_t limit)
+{
+	std::vector<unsigned char> tmp((size_t)(limit - from));
+	int64_t got = 0;
+	while (got < (int64_t)tmp.size()) { const ssize_t r = ::pread(fd, tmp.data() + got, tmp.size() - got, from + got); if (r <= 0) break; got += r; }
+	const unsigned char *base = tmp.data(), *p = base, *e = base + got;
+	p = (const unsigned char*)memchr(p, '\n', e - p);
+	if (!p) return -1;
+	for (++p; p < e; ) {
+		const unsigned char *l1 = (const unsigned char*)memchr(p, '\n', e - p);
+		if (*p == '>') return from + (p - base);
+		if (*p == '@' && l1) {
+			const unsigned char *l2 = l1 + 1 < e ? (const unsigned char*)memchr(l1 + 1, '\n', e - (l1 + 1)) : 0;
+			if (l2 && l2 + 1 < e && l2[1] == '+') return from + (p - base);
+		}
+		if (!l1) return -1;
+		p = l1 + 1;
+	}
+	return -1;
+}
+
+static void parse_segment(int fd, int64_t file_end, ParSeg *sg, int min_len)
+{
+	FxReader r;
+	r.open_at(fd, sg->start);
+	sg->n_seq = sg->sum_len = 0; sg->hard_end = false;
+	sg->img.clear();
+	int64_t l;
+	for (;;) {
+		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = true; break; }
+		if (r.marker_pos() >= sg->end) { sg->stop = r.marker_pos(); break; }
+		if ((l = r.fast(sg->img, min_len)) == FxReader::NOT_FAST) {
+			if ((l = r.next()) < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
+			if (l >= min_len) { sg->img.insert(sg->img.end(), r.seq.begin(), r.seq.end()); sg->img.push_back('\n'); }
+		}
+		if (l >= min_len) { ++sg->n_seq; sg->sum_len += l; }
+	}
+	r.close_at();
+}
+
+/* calls sink(image, n_seq) for consecutive pieces of the input, in order; false if sink failed */
+static bool parse_parallel(int fd, int64_t size, int min_len, int n_thr, const std::function<bool(const std::vector<char>&, int64_t)> &sink)
+{
+	const int64_t WIN = (int64_t)env_threads_window();
+	std::vector<ParSeg> seg(n_thr);
+	int64_t pos = 0;
+	bool done = false;
+	while (!done && pos < size) {
+		const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
+		int n_seg = 0;
+		for (int i = 0; i < n_thr; ++i) {
+			const int64_t cut = pos + i * step;
+			if (cut >= wend) break;
+			const int64_t st = i == 0 ? pos : guess_record_start(fd, cut, std::min(size, cut + ((int64_t)1 << 18)));
+			if (i && (st < 0 || st >= wend)) continue;
+			if (n_seg && st <= seg[n_seg - 1].start) continue;
+			seg[n_seg].start = st; ++n_seg;
+		}
+		for (int i = 0; i < n_seg; ++i) seg[i].end = i + 1 < n_seg ? seg[i + 1].start : wend;
+		std::vector<std::thread> th;
+		for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len);
+		parse_segment(fd, size, &seg[0], min_len);
+		for (auto &t : th) t.join();
+		int64_t at = pos;
+		for (int i = 0; i < n_seg; ++i) {
+			if (seg[i].start != at) break;                       /* wrong guess: the rest of the window is parsed again */
+			if (!sink(seg[i].img, seg[i].n_seq)) return false;
+			at = seg[i].stop;
+			if (seg[i].hard_end) { done = true; break; }
+		}
+		pos = at;
+	}
+	return true;
+}
+
 /* reference count.c:147-166 */
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 {
@@ -578,6 +696,21 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	chunk.reserve((size_t)std::min<int64_t>(opt->chunk_size + (opt->chunk_size >> 3) + 65536, (int64_t)1 << 31));
 	uint64_t t0 = 0;
 	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
+	/* a plain regular file is mapped and parsed by several threads; anything else (gzip, a pipe) streams through the reader */
+	const int n_thr = parse_threads(opt->n_thread);
+	int64_t par_size = -1;
+	if (fx.fd >= 0 && n_thr > 1) {
+		struct stat sb;
+		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) par_size = sb.st_size;
+	}
+	if (ok && par_size >= 0) {
+		ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, [&](const std::vector<char> &img, int64_t ns) {
+			bool good = img.empty() || yakamd_feed_bases_host(h, img.data(), (int64_t)img.size(), t0) == 0;
+			t0 += img.size(); n_seq_tot += ns;
+			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
+			return good;
+		});
+	}
 	auto flush = [&]() {
 		if (!chunk.empty() && ok) ok = yakamd_feed_bases_host(h, chunk.data(), (int64_t)chunk.size(), t0) == 0;
 		t0 += chunk.size();
@@ -585,7 +718,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq);
 		chunk.clear(); sum_len = 0; n_seq = 0;
 	};
-	while (ok) {                                             /* count.c:93 */
+	while (ok && par_size < 0) {                             /* count.c:93 */
 		if ((l = fx.fast(chunk, opt->k)) == FxReader::NOT_FAST) {
 			if ((l = fx.next()) < 0) break;
 			if (l >= opt->k) { chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end()); chunk.push_back('\n'); }   /* a non-ACGT byte ends the read (count.c:41) */
@@ -630,7 +763,19 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 	std::vector<char> img;
 	int64_t l;
 	const double t_ = yk_realtime();
-	if (getenv("YAKAMD_VERBOSE")) img.reserve((size_t)1 << 29);
+	const int n_thr = use_fast_path ? parse_threads(1) : 1;    /* tests set YAKAMD_PARSE_THREADS */
+	if (fx.fd >= 0 && n_thr > 1) {
+		struct stat sb;
+		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+			size_t total = 0;
+			parse_parallel(fx.fd, (int64_t)sb.st_size, min_len, n_thr, [&](const std::vector<char> &part, int64_t) { total += part.size(); if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part.begin(), part.end()); return true; });
+			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes\n", yk_realtime() - t_, n_thr, total);
+			fx.close_file();
+			*out = (char*)malloc(img.size() + 1);
+			memcpy(*out, img.data(), img.size());
+			return (int64_t)img.size();
+		}
+	}
 	for (;;) {
 		if (!use_fast_path || (l = fx.fast(img, min_len)) == FxReader::NOT_FAST) {
 			if ((l = fx.next()) < 0) break;
