@@ -564,7 +564,14 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 				return r;
 			}
 		}
-		if (!lds || yk_launch_img_count_lds(c->d_rec, hash_only, d_bstart, img, c->plo, c->phi, lds, c->st) != 0) {
+		u64 *d_ck = 0; u32 ck_stride = 1;
+		if (lds) {
+			for (int p = c->plo; p < c->phi; ++p) ck_stride = std::max(ck_stride, c->h_count[p]);
+			if (dmalloc(&d_ck, (size_t)(c->phi - c->plo) * ck_stride)) return -1;
+		}
+		const bool lds_done = lds && yk_launch_img_count_lds(c->d_rec, hash_only, d_bstart, img, c->plo, c->phi, lds, d_ck, ck_stride, c->st) == 0;
+		if (d_ck) { HIPCK(hipStreamSynchronize(c->st)); dfree(d_ck); }
+		if (!lds_done) {
 			if (hash_only) yk_launch_img_count_h((const u64*)c->d_rec, n_rec, img, c->st);
 			else yk_launch_img_count(c->d_rec, n_rec, img, c->st);
 		}

@@ -90,7 +90,7 @@ size_t yk_img_count_lds_bytes(u32 cap, u32 count);
 void yk_launch_lookup(const uint8_t *bases, int64_t n, int k, ImgView img, unsigned short *out, hipStream_t st);
 void yk_launch_qv_reduce(const unsigned short *t, const u64 *roff, const u32 *rlen, int64_t n_reads, int min_len, double min_frac,
                          u32 *tot_out, u32 *non0_out, u64 *hist, hipStream_t st);
-int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, hipStream_t st);
+int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, u64 *compact, u32 stride, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_hist(ImgView img, u64 n_slots, u64 *hist, hipStream_t st);
