@@ -295,3 +295,28 @@ def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch)
         got, tot = ya.count_protocol_host(img, **opt)
         want, wtot = oracle.count_protocol_mem(img, **opt)
         assert (got == want, tot) == (True, wtot), opt
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
+    """seeded random points of the option space (k, prefix length, filter size, number of probes, read
+    length, error and N rates, coverage) and of the engine's knobs: the protocol's bytes against the oracle"""
+    import random
+    rnd = random.Random(1000 + seed)
+    k = rnd.choice([5, 11, 15, 21, 27, 31, 31, 31, 32, 33, 47, 63])
+    pre = rnd.choice([10, 10, 10, 11, 12, 13, 14])
+    bf = rnd.choice([0, 0, pre + 9, pre + 10, pre + 12, pre + 16, pre + 22, pre + 3])
+    n_hash = rnd.choice([1, 2, 4, 4, 4, 7, 33])
+    L_ = rnd.choice([max(k, 30), 75, 150, 150, 400])
+    n = rnd.randrange(40, 6000)
+    g = rnd.choice([300, 2000, 20000, n * L_ // 4 + 100])
+    img = synth(n, l=L_, g=max(g, L_), s=seed + 5, e=rnd.choice([0.0, 0.005, 0.05]), N=rnd.choice([0.0, 0.0005, 0.02]))
+    for key, vals in (("YAKAMD_BATCH", [None, None, "4096", "65536", "1048576"]), ("YAKAMD_S2_BITS", [None, None, None, "0", "2", "5", "9"]),
+                      ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
+                      ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_XP_WC", [None, None, "0", "1", "2"]), ("YAKAMD_FAST", [None, None, None, "0"])):
+        v = rnd.choice(vals)
+        if v is not None:
+            monkeypatch.setenv(key, v)
+    got, tot = ya.count_protocol_host(img, k=k, pre=pre, n_hash=n_hash, bf_shift=bf)
+    want, wtot = oracle.count_protocol_mem(img, k=k, pre=pre, n_hash=n_hash, bf_shift=bf)
+    assert (got == want, tot) == (True, wtot), dict(k=k, pre=pre, bf=bf, n_hash=n_hash, n=n, L=L_, g=g)
