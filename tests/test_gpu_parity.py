@@ -242,11 +242,13 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_COUNT_LDS="0"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6"),
                                  dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="5", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6", YAKAMD_XLIST_CAP="7"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0")],
+                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0"),
+                                 dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
+                                 dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
                               "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
-                              "count_with_device_atomics"])
+                              "count_with_device_atomics", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""

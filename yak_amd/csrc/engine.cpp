@@ -178,7 +178,7 @@ struct yakamd_ctx {
 	/* fast path: level-1 partitioned batches kept until pass_end */
 	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; bool owned; };
 	std::vector<Kept> kept;
-	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set;
+	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set; u64 keys_at_begin;
 	double ms_part2, ms_lds;
 	u64 t_end;
 	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
@@ -373,7 +373,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	c->st_cur.ms_total = now_ms();
 	/* exclusive-ownership LDS counting needs level-1 buckets == sub-tables and 2-bit k-mers */
 	c->fast = create_new && env_i64("YAKAMD_FAST", 1) != 0 && c->nb_bits == c->pre && (!c->has_bloom || c->nb <= 42);
-	c->kept_bytes = 0; c->t_pass0_set = false; c->ms_part2 = c->ms_lds = 0;
+	c->kept_bytes = 0; c->t_pass0_set = false; c->ms_part2 = c->ms_lds = 0; c->keys_at_begin = c->img_keys_total;
 	if (c->fast) {
 		size_t fr = 0, tot = 0;
 		HIPCK(hipMemGetInfo(&fr, &tot));
@@ -628,13 +628,31 @@ static int fast_abandon(yakamd_ctx *c)
 	return r;
 }
 
+static int fast_finish(yakamd_ctx *c);
+static int fast_flush_slice(yakamd_ctx *c)
+{
+	if (fast_finish(c)) return -1;
+	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));      /* the put-calls of the slice are accounted for */
+	HIPCK(hipMemsetAsync(c->d_counters, 0, YKC_N * 8, c->st));
+	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] slice of the pass counted early (budget / 2^32-position limit): %llu keys in the table\n", (unsigned long long)c->img_keys_total);
+	return 0;
+}
+
 /* may this batch (n_pos stream positions starting at time t) stay on the fast path?  If so,
  * allocate its level-1 output buffers */
 static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec *borrowed = 0)
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
 	const u64 cost = borrowed ? 0 : n_cap * 16;                  /* a borrowed buffer is the caller's memory */
-	const bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + cost <= c->fast_budget;
+	bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + cost <= c->fast_budget;
+	if (!fits && !c->kept.empty() && t >= c->t_end && n_pos < 0xfffffff0ull && cost <= c->fast_budget && !c->acc.s) {
+		/* the kept batches are a complete prefix of the stream: count them now, exactly as if the pass
+		 * ended here (table, filter and counts carry over; the next slice meets them as existing state --
+		 * what the reference does chunk after chunk), and start a new slice with times relative to t */
+		if (fast_flush_slice(c)) return -1;
+		c->t_pass0 = t;
+		fits = true;
+	}
 	if (!fits) { if (fast_abandon(c)) return -1; return 0; }
 	yakamd_ctx::Kept k;
 	k.d_rec = borrowed; k.n = 0; k.t0 = t; k.span = n_pos; k.owned = !borrowed;
@@ -1007,7 +1025,7 @@ static int fast_finish(yakamd_ctx *c)
 		EvTimer tm(c->st);
 		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
 		c->ms_part2 = tm.stop();
-		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 = c->ms_part2;
+		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 += c->ms_part2;
 	}
 	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
@@ -1062,7 +1080,7 @@ static int fast_finish(yakamd_ctx *c)
 		HIPCK(hipMemcpy(nd.data(), d_ndist, P * 4, hipMemcpyDeviceToHost));
 		u64 tot_d = 0;
 		for (int p = 0; p < P; ++p) tot_d += nd[p];
-		c->st_cur.n_distinct_seen = (int64_t)tot_d;
+		c->st_cur.n_distinct_seen += (int64_t)tot_d;
 	}
 	dfree(d_ovf2); dfree(d_ndist);
 	dfree(d_r2); dfree(d_sbstart); dfree(d_ovf);
@@ -1105,13 +1123,12 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 		pass_free(c);
 		return fail("flag-mode loads need the exclusive-ownership path (prefix length <= 13, input within the device budget)");
 	} else if (c->fast && !c->acc.s) {
-		const u64 before = c->img_keys_total;
 		if (fast_finish(c)) return -1;
-		n_ins = (int64_t)(c->img_keys_total - before);
+		n_ins = (int64_t)(c->img_keys_total - c->keys_at_begin);   /* earlier slices of the pass included */
 		c->st_cur.n_new_keys = n_ins;
 	} else {
 		if (c->fast && fast_abandon(c)) return -1;          /* cannot happen today; keeps the invariant explicit */
-		const u64 before = c->img_keys_total;
+		const u64 before = c->keys_at_begin;                 /* slices counted earlier in this pass included */
 		if (c->img_keys_total) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* put-calls that hit existing keys */
 		std::vector<u32> m(P, 0);
 		std::vector<u64> seg_off(P + 1, 0);
