@@ -16,12 +16,24 @@ N, L, G, SEED, K, BF = 10_000_000, 150, 50_000_000, 42, 31, 37
 
 
 def main():
-    tmp = sys.argv[1] if len(sys.argv) > 1 else "/tmp/cfg2"
+    tmp = next((a for a in sys.argv[1:] if not a.startswith("--")), "/tmp/cfg2")
     os.makedirs(tmp, exist_ok=True)
     fq, out = os.path.join(tmp, "r.fq"), os.path.join(tmp, "ref.yak")
     if not os.path.exists(fq):
         subprocess.check_call([SYN, "-n", str(N), "-l", str(L), "-g", str(G), "-s", str(SEED), "-t", "8", "-o", fq])
     res = {}
+    if "--with-30m" in sys.argv:                              # 9.4 GB of FASTQ, ~10 min: the sliced-pass case
+        fq3, out3 = os.path.join(tmp, "r30.fq"), os.path.join(tmp, "ref30.yak")
+        if not os.path.exists(fq3):
+            subprocess.check_call([SYN, "-n", str(3 * N), "-l", str(L), "-g", str(3 * G), "-s", str(SEED), "-t", "8", "-o", fq3])
+        subprocess.run([REF, "count", f"-k{K}", f"-b{BF}", "-t8", "-o", out3, fq3], check=True, stderr=subprocess.DEVNULL)
+        h = hashlib.md5()
+        with open(out3, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        res["b37_30M_sliced"] = {"workload": f"yak count -k{K} -b{BF} on yaksynth -n {3 * N} -l {L} -g {3 * G} -s {SEED}", "reads": 3 * N, "read_len": L,
+                                 "genome": 3 * G, "seed": SEED, "k": K, "bf_shift": BF, "md5": h.hexdigest(), "size": os.path.getsize(out3),
+                                 "produced_by": "oracle/_ref/yak (the reference, compiled from /root/reference)"}
     for name, bf in (("b37", BF), ("no_filter", 0)):
         subprocess.run([REF, "count", f"-k{K}"] + ([f"-b{bf}"] if bf else []) + ["-t8", "-o", out, fq], check=True, stderr=subprocess.DEVNULL)
         h = hashlib.md5()
