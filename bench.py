@@ -366,10 +366,10 @@ def main():
         k_["achieved_GBs"] = k_["bytes"] / (k_["ms"] * 1e-3) / 1e9 if k_["ms"] > 0 else 0.0
         k_["frac"] = k_["achieved_GBs"] / HBM_PEAK_GBS
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (profiles/r01j_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
+    # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")))
     except Exception:
         pass
     for k_ in kern:
@@ -399,7 +399,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS,
                      "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
-                     "traffic_source": "profiles/r01j_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
+                     "traffic_source": "profiles/r01k_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,
                      "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),
