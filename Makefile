@@ -26,7 +26,7 @@ yak_amd/yak-amd: $(CSRC)/main.c include/yak.h yak_amd/libyak_amd.so
 
 tools:
 	$(MAKE) -C tools
-oracle:
+oracle: lib
 	$(MAKE) -C oracle all ref
 
 clean:

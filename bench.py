@@ -9,6 +9,10 @@ every rank brings its own 10 M reads of a genome N times as long, the 1024 sub-t
 by hash prefix over the ranks and the hashed k-mers travel to their owner with one RCCL
 all-to-all per pass.
 
+`--gpus N` without a torch.distributed environment re-launches itself as N ranks (torch.distributed.run
+on 127.0.0.1).  `--config nofilter|cfg4|cfg5` run the other BASELINE.json configurations (no filter;
+the long-contig k = 21 assembly; the lookup-only path of `yak qv`) with the same output contract.
+
 Prints ONE JSON line (rank 0).  `value` = distinct k-mers in the final table (h->tot, the number
 the reference logs) per second, whole job over all ranks; `kmer_instances_per_s` = k-mer windows
 consumed per second (both passes).  `roofline` is for the dominant kernel, timed with HIP events on
@@ -51,41 +55,72 @@ def make_reads(n_reads, genome, seed, first, torch, threads):
     return t
 
 
-def cpu_baseline(sample_reads, threads):
-    """the reference binary (oracle/_ref/yak) if it travelled, else the oracle port, on a sample"""
+def _ref_count(fq, bits, threads, k=K):
     from oracle import pyoracle
-    genome = max(sample_reads * READ_LEN // 30, 1000)
-    # bloom scaled like -b37 for 1.2 G instances: ~114 bits per instance
-    bits = 37
-    while (1 << bits) > 114 * sample_reads * 120 * 2 and bits > 20:
-        bits -= 1
-    tmp = tempfile.mkdtemp(prefix="ykb")
+    t0 = time.time()
+    r = subprocess.run([pyoracle.REF_BIN, "count", f"-k{k}"] + ([f"-b{bits}"] if bits else []) + [f"-t{threads}", "-o", "/dev/null", fq],
+                       stderr=subprocess.PIPE, check=True)
+    dt = time.time() - t0
+    m = re.findall(rb"(\d+) distinct k-mers", r.stderr)
+    return dt, (int(m[-1]) if m else 0)
+
+
+def cpu_baseline(n_reads, genome, bf_shift, threads, t1_reads=500_000):
+    """The reference itself (oracle/_ref/yak, compiled in the build container, carried as a prebuilt file) on
+    the SAME reads as the device run (tools/yaksynth writes them as FASTQ: same seed, same order), all host
+    cores; plus a -t1 figure on a stated fraction.  Without the prebuilt reference: the oracle port (1 core)
+    on a bounded sample."""
+    from oracle import pyoracle
+    tmp = tempfile.mkdtemp(prefix="ykb", dir=os.environ.get("YAKAMD_TMP", None))
     try:
         if pyoracle.have_ref():
             fq = os.path.join(tmp, "s.fq")
-            subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(sample_reads), "-l", str(READ_LEN),
-                                   "-g", str(genome), "-s", "4242", "-o", fq])
-            t0 = time.time()
-            r = subprocess.run([pyoracle.REF_BIN, "count", f"-k{K}", f"-b{bits}", f"-t{threads}", fq],
-                               stderr=subprocess.PIPE, check=True)
-            dt = time.time() - t0
-            m = re.search(rb"(\d+) distinct k-mers after shrinking", r.stderr)
-            tot = int(m.group(1)) if m else 0
-            kind, cores = "reference", threads
-        else:
-            import __graft_entry__ as ge
-            reads = ge._synth(sample_reads, READ_LEN, genome, 4242)
-            t0 = time.time()
-            _, tot = pyoracle.count_protocol_mem(reads, k=K, bf_shift=bits)
-            dt = time.time() - t0
-            kind, cores = "port", 1
+            subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(n_reads), "-l", str(READ_LEN),
+                                   "-g", str(genome), "-s", "42", "-t", str(min(threads, 32)), "-o", fq])
+            dt, tot = _ref_count(fq, bf_shift, threads)
+            inst = n_reads * (READ_LEN - K + 1) * (2 if bf_shift else 1)
+            out = {"value": tot / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "reference",
+                   "kmer_instances_per_s": inst / dt, "seconds": round(dt, 2),
+                   "sample": f"yak count -k{K}" + (f" -b{bf_shift}" if bf_shift else "") + f" -t{threads} on the SAME {n_reads} x {READ_LEN} bp reads as the device run "
+                             f"(tools/yaksynth -g {genome} -s 42 written as FASTQ, file in page cache), " + ("both passes" if bf_shift else "one pass")}
+            # one core: a fraction of the reads (same genome), the filter scaled with the instances
+            f1 = os.path.join(tmp, "s1.fq")
+            subprocess.check_call(["head", "-n", str(4 * t1_reads), fq], stdout=open(f1, "wb"))
+            bits1 = bf_shift
+            while bits1 > 20 and (1 << bits1) > (1 << bf_shift) * t1_reads * 2 // n_reads:
+                bits1 -= 1
+            dt1, tot1 = _ref_count(f1, bits1 if bf_shift else 0, 1)
+            out["t1"] = {"value": tot1 / dt1, "cores": 1, "seconds": round(dt1, 2), "kmer_instances_per_s": t1_reads * (READ_LEN - K + 1) * (2 if bf_shift else 1) / dt1,
+                         "sample": f"first {t1_reads} of those reads, -t1" + (f" -b{bits1}" if bf_shift else "")}
+            return out
+        import __graft_entry__ as ge
+        sample = min(n_reads, 200_000)
+        g = max(sample * READ_LEN // 30, 1000)
+        bits = bf_shift
+        while bits > 20 and (1 << bits) > 114 * sample * 120 * 2:
+            bits -= 1
+        reads = ge._synth(sample, READ_LEN, g, 4242)
+        t0 = time.time()
+        _, tot = pyoracle.count_protocol_mem(reads, k=K, bf_shift=bits if bf_shift else 0)
+        dt = time.time() - t0
+        return {"value": tot / dt, "unit": "distinct k-mers/s", "cores": 1, "kind": "port", "seconds": round(dt, 2),
+                "kmer_instances_per_s": sample * (READ_LEN - K + 1) * (2 if bf_shift else 1) / dt,
+                "sample": f"oracle restatement on {sample} x {READ_LEN} bp synthetic reads (G={g}), -b{bits}"}
     finally:
         subprocess.call(["rm", "-rf", tmp])
-    inst = sample_reads * (READ_LEN - K + 1) * 2
-    return {"value": tot / dt, "unit": "distinct k-mers/s", "cores": cores, "kind": kind,
-            "kmer_instances_per_s": inst / dt, "seconds": round(dt, 2),
-            "sample": f"yak count -k{K} -b{bits} -t{cores} on {sample_reads} x {READ_LEN} bp synthetic reads "
-                      f"(G={genome}, e=0.5%), both passes, file in page cache"}
+
+
+def maybe_spawn(a):
+    """`python bench.py --gpus N` run bare: become N ranks (one process per GPU, RCCL over xGMI)"""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def main():
@@ -94,8 +129,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--batch-reads", type=int, default=10_000_000, help="N > 1: reads per exchange round and rank (the job's input is dealt to the ranks in chunks of this size)")
     ap.add_argument("--bf-shift", type=int, default=37)
-    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "nofilter", "cfg4", "cfg5"],
+                    help="BASELINE.json configuration: cfg2 = configs[1] (default, the metric's workload); nofilter = same reads, no bloom filter, one pass; "
+                         "cfg4 = configs[3], yak count -k21 on a synthetic assembly (long contigs, singletons kept); cfg5 = configs[4], lookup-only path of yak qv")
+    ap.add_argument("--contigs", type=int, default=50, help="cfg4: number of contigs")
+    ap.add_argument("--contig-len", type=int, default=100_000_000, help="cfg4: bases per contig")
+    ap.add_argument("--qv-reads", type=int, default=75_000, help="cfg5: number of 20 kb query reads")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: reads per GPU fixed (weak) or --total-reads fixed (strong)")
+    ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job (BASELINE configs[2]: 600000000)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
@@ -104,6 +148,16 @@ def main():
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
+    maybe_spawn(a)
+    if a.config == "nofilter":
+        a.bf_shift = 0
+    if a.config in ("cfg4", "cfg5"):
+        import bench_configs
+        return bench_configs.run(a)
+    if a.scaling == "strong":
+        if a.total_reads <= 0:
+            raise SystemExit("--scaling strong needs --total-reads")
+        a.reads = a.total_reads // max(1, a.gpus)
 
     import torch
     import torch.distributed as dist
@@ -113,7 +167,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -136,27 +190,40 @@ def main():
     lo, hi = rank * P // world, (rank + 1) * P // world
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     genome = 5 * a.reads * world                    # 30x coverage of the whole job
-    h_reads = make_reads(a.reads, genome, 42, rank * a.reads, torch, min(threads, 64))
-    d_reads = h_reads.to(dev, non_blocking=True)
+    # The logical input of the whole job is cut into chunks of `batch_reads` reads, dealt round-robin to the
+    # ranks: chunk c = b * world + r is batch b of rank r.  A single rank therefore sees the same stream as N
+    # ranks do (N-GPU bytes == 1-GPU bytes), and every rank is busy in every round however long the input.
+    batch_reads = a.reads if world == 1 else min(a.reads, a.batch_reads)
+    n_batches = -(-a.reads // batch_reads)
+    rec_len = READ_LEN + 1
+    B = batch_reads * rec_len                       # bytes (= stream positions) of a full chunk
+    d_reads = torch.empty(a.reads * rec_len, dtype=torch.uint8, device=dev)
+    h_reads = None
+    for b in range(n_batches):
+        nb_reads = min(batch_reads, a.reads - b * batch_reads)
+        h_reads = make_reads(nb_reads, genome, 42, (b * world + rank) * batch_reads, torch, min(threads, 64))
+        d_reads[b * B:b * B + nb_reads * rec_len].copy_(h_reads, non_blocking=False)
     torch.cuda.synchronize()
     n_bytes = d_reads.numel()
+    batch_span = [(b * B, min(B, n_bytes - b * B)) for b in range(n_batches)]
 
     # exchange buffers (sharded path only): 16-byte records {hash, position} grouped by prefix
     if sharded:
-        s_rec = torch.empty((n_bytes, 2), dtype=torch.int64, device=dev)
-        s_hash = torch.empty(n_bytes, dtype=torch.int64, device=dev)
+        s_rec = torch.empty((min(B, n_bytes), 2), dtype=torch.int64, device=dev)
+        s_hash = torch.empty(min(B, n_bytes), dtype=torch.int64, device=dev)
         h_bstart = (C.c_uint64 * (P + 1))()
 
-    def exchange(create_new, async_op=False):
-        """partition this rank's k-mers by sub-table prefix once, then one all-to-all per pass moves
-        every record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI).  async_op:
-        the all-to-all is queued and a function that waits for it is returned."""
+    def exchange(b, create_new, async_op=False):
+        """partition this rank's k-mers of batch b by sub-table prefix once, then one all-to-all moves every
+        record (pass 2: only its hash) to the owner of its prefix (RCCL over xGMI).  async_op: the
+        all-to-all is queued and a function that waits for it is returned."""
         from yak_amd import shard
+        off, nb = batch_span[b]
         if create_new:
-            n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_rec.data_ptr(), h_bstart)
+            n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr() + off, nb, s_rec.data_ptr(), h_bstart)
             send = s_rec[:n]
         else:                                               # counting existing keys only needs the hashes: 8-byte records
-            n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr(), n_bytes, s_hash.data_ptr(), h_bstart)
+            n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr() + off, nb, s_hash.data_ptr(), h_bstart)
             send = s_hash[:n]
         if n < 0:
             raise RuntimeError("partition failed")
@@ -171,30 +238,34 @@ def main():
         if not sharded:
             t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
-        if create_new:
-            segs = exchange(1)
-            # both passes read the same input (main.c:53-57), so the second pass's k-mers can travel while
-            # the first pass is still counting: queue that all-to-all now, wait for it when pass 2 starts
-            if a.bf_shift > 0 and not a.no_overlap:
-                pending[0] = exchange(0, async_op=True)
-        else:
-            segs = pending[0]() if pending[0] is not None else exchange(0)
-            pending[0] = None
-            torch.cuda.synchronize()
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
-        for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job
-            if rec.shape[0]:
-                ob = (C.c_uint64 * (P + 1))(*offs)
-                if create_new:
-                    if L.yakamd_feed_partitioned_lent_dev(t.h, rec.data_ptr(), rec.shape[0], ob, src * n_bytes, n_bytes) != 0:   # `segs` outlives pass_end
-                        raise RuntimeError("feed_partitioned")
-                elif L.yakamd_count_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob) != 0:
-                    raise RuntimeError("count_partitioned")
+        held = []
+        for b in range(n_batches):
+            if create_new:
+                segs = exchange(b, 1)
+                # both passes read the same input (main.c:53-57), so the second pass's k-mers can travel while
+                # the first pass is still counting: queue that all-to-all now, wait for it when pass 2 starts
+                if n_batches == 1 and a.bf_shift > 0 and not a.no_overlap:
+                    pending[0] = exchange(0, 0, async_op=True)
+            else:
+                segs = pending[0]() if pending[0] is not None else exchange(b, 0)
+                pending[0] = None
+                torch.cuda.synchronize()
+            held.append(segs)                                   # lent buffers must outlive pass_end
+            for src, (rec, offs) in enumerate(segs):            # by source rank = stream order of the job
+                if rec.shape[0]:
+                    ob = (C.c_uint64 * (P + 1))(*offs)
+                    if create_new:
+                        if L.yakamd_feed_partitioned_lent_dev(t.h, rec.data_ptr(), rec.shape[0], ob, (b * world + src) * B, B) != 0:
+                            raise RuntimeError("feed_partitioned: " + yak_amd._err())
+                    elif L.yakamd_count_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob) != 0:
+                        raise RuntimeError("count_partitioned: " + yak_amd._err())
         n_ins = L.yakamd_pass_end(t.h)
         if n_ins < 0:
-            raise RuntimeError("pass_end")
+            raise RuntimeError("pass_end: " + yak_amd._err())
         t.h.contents.tot += n_ins
+        del held
 
     wall = {}
     last_stats = [None]
@@ -383,7 +454,7 @@ def main():
         "metric": "distinct k-mers counted/sec (k=31), yak count -b37 two-pass protocol, .yak bit-exact",
         "value": tot_all / (dt / a.steps), "unit": "distinct k-mers/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"yak count -k{K} -b{a.bf_shift} on {a.reads} x {READ_LEN} bp synthetic reads per GPU "
                                f"(G={genome}, e=0.5%, N=0.05%), 30x, bloom prefilter on, both passes + shrink",
@@ -415,7 +486,7 @@ def main():
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }
     if not a.no_cpu_baseline and world == 1:                      # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, min(os.cpu_count() or 8, 32))
+        out["cpu_baseline"] = cpu_baseline(a.reads, genome, a.bf_shift, min(os.cpu_count() or 8, 32))
     print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()

@@ -239,16 +239,21 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6"),
                                  dict(YAKAMD_S2_BITS="6"), dict(YAKAMD_S2_BITS="11", YAKAMD_CH2="4096"), dict(YAKAMD_S2_BITS="13"),
                                  dict(YAKAMD_XP_WC="0", YAKAMD_P2_WC="0", YAKAMD_S2_BITS="6"),
-                                 dict(YAKAMD_COUNT_LDS="0"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="5", YAKAMD_XLIST_CAP="0"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6", YAKAMD_XLIST_CAP="7"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0"),
+                                 dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6"),
+                                 dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="5", YAKAMD_XLIST_CAP="0"),
+                                 dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6", YAKAMD_XLIST_CAP="7"),
+                                 dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0"), dict(YAKAMD_COUNT_OWN="0"),
+                                 dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="0"),
+                                 dict(YAKAMD_OWN_LDS="19500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_LC2="0"), dict(YAKAMD_LC2="0", YAKAMD_S2_BITS="4"),
+                                 dict(YAKAMD_LC2_WGS="3"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
                               "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
-                              "count_with_device_atomics", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
+                              "count_with_device_atomics", "count_lds_rank_kernel",
+                              "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
+                              "lc2_three_persistent_workgroups", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""
@@ -282,9 +287,11 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0"),
-                                 dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
+                                 dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
+                                 dict(YAKAMD_OWN_LDS="30000", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64"), dict(YAKAMD_REPLAY_LDS="32768"),
                                  dict(YAKAMD_REPLAY_LDS="2048"), dict(YAKAMD_REPLAY_LDS="1024", YAKAMD_REPLAY_THREADS="256"), dict(YAKAMD_REPLAY_LDS="2048", YAKAMD_DBG="256")],
                          ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow",
+                              "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "lds_keys_for_small_stages",
                               "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
 def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
     """~7 M distinct k-mers (1x coverage): every sub-table grows to 16 Ki slots, so the layout replay
@@ -314,7 +321,8 @@ def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
     g = rnd.choice([300, 2000, 20000, n * L_ // 4 + 100])
     img = synth(n, l=L_, g=max(g, L_), s=seed + 5, e=rnd.choice([0.0, 0.005, 0.05]), N=rnd.choice([0.0, 0.0005, 0.02]))
     for key, vals in (("YAKAMD_BATCH", [None, None, "4096", "65536", "1048576"]), ("YAKAMD_S2_BITS", [None, None, None, "0", "2", "5", "9"]),
-                      ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
+                      ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096", "32768"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
+                      ("YAKAMD_COUNT_OWN", [None, None, "0"]), ("YAKAMD_OWN_LDS", [None, None, "18500", "24000"]), ("YAKAMD_OWN_MAXRB", [None, "12"]), ("YAKAMD_LC2", [None, None, None, "0"]),
                       ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_XP_WC", [None, None, "0", "1", "2"]), ("YAKAMD_FAST", [None, None, None, "0"])):
         v = rnd.choice(vals)
         if v is not None:

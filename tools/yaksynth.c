@@ -94,21 +94,66 @@ int64_t yaksynth_reads(uint8_t *out, int64_t n_reads, int read_len, int64_t geno
 	return n_reads * (int64_t)(read_len + 1);
 }
 
+/* "assembly" image (BASELINE configs[3]): contig i is genome[i * contig_len, (i + 1) * contig_len), every
+ * contig followed by one '\n' -- a gap-free tiling of an n_contigs * contig_len genome, so nearly every
+ * k-mer is distinct (the long-contig, singletons-kept regime).  Bytes [out, out + n * (len + 1)). */
+typedef struct { uint8_t *out; int64_t b0, b1, clen; uint64_t seed; } tjob_t;
+static void *tile_thread(void *a)
+{
+	const tjob_t *j = (const tjob_t*)a;
+	int64_t x;
+	for (x = j->b0; x < j->b1; ++x) {                    /* x = byte index in the image */
+		const int64_t c = x / (j->clen + 1), o = x % (j->clen + 1);
+		j->out[x] = o == j->clen ? '\n' : (uint8_t)"ACGT"[genome_base(j->seed, c * j->clen + o)];
+	}
+	return 0;
+}
+int64_t yaksynth_tiles(uint8_t *out, int64_t n_contigs, int64_t contig_len, uint64_t seed, int n_threads)
+{
+	tjob_t jobs[256];
+	pthread_t tid[256];
+	const int64_t tot = n_contigs * (contig_len + 1);
+	int t;
+	if (n_threads < 1) n_threads = 1;
+	if (n_threads > 256) n_threads = 256;
+	for (t = 0; t < n_threads; ++t) { jobs[t].out = out; jobs[t].clen = contig_len; jobs[t].seed = seed; jobs[t].b0 = tot * t / n_threads; jobs[t].b1 = tot * (t + 1) / n_threads; }
+	for (t = 1; t < n_threads; ++t) pthread_create(&tid[t], 0, tile_thread, &jobs[t]);
+	tile_thread(&jobs[0]);
+	for (t = 1; t < n_threads; ++t) pthread_join(tid[t], 0);
+	return tot;
+}
+
 #ifdef YAKSYNTH_MAIN
 int main(int argc, char *argv[])
 {
 	int64_t n = 1000, g = 100000, i;
-	int l = 150, c, fasta = 0, thr = 4;
+	int l = 150, c, fasta = 0, thr = 4, tiles = 0, wrap = 0;
+	int64_t ll = 150;
 	uint64_t seed = 42;
 	double e = 0.005, nr = 0.0005;
 	uint8_t *buf;
 	FILE *fp = stdout;
-	while ((c = getopt(argc, argv, "n:l:g:s:e:N:o:at:")) >= 0) {
-		if (c == 'n') n = atoll(optarg); else if (c == 'l') l = atoi(optarg);
+	while ((c = getopt(argc, argv, "n:l:g:s:e:N:o:at:Tw:")) >= 0) {
+		if (c == 'n') n = atoll(optarg); else if (c == 'l') { ll = atoll(optarg); l = (int)ll; }
+		else if (c == 'T') tiles = fasta = 1; else if (c == 'w') wrap = atoi(optarg);
 		else if (c == 'g') g = atoll(optarg); else if (c == 's') seed = strtoull(optarg, 0, 10);
 		else if (c == 'e') e = atof(optarg); else if (c == 'N') nr = atof(optarg);
 		else if (c == 'a') fasta = 1; else if (c == 't') thr = atoi(optarg);
 		else if (c == 'o') { fp = fopen(optarg, "wb"); if (!fp) { perror(optarg); return 1; } }
+	}
+	if (tiles) {                                        /* -T: n contigs of l bases tiling a genome of n * l bases, FASTA, -w columns per line (0 = one line) */
+		buf = (uint8_t*)malloc((size_t)n * (ll + 1));
+		yaksynth_tiles(buf, n, ll, seed, thr);
+		for (i = 0; i < n; ++i) {
+			const uint8_t *sq = buf + i * (ll + 1);
+			int64_t o;
+			fprintf(fp, ">ctg%ld\n", (long)i);
+			if (wrap <= 0) fwrite(sq, 1, ll + 1, fp);
+			else for (o = 0; o < ll; o += wrap) { fwrite(sq + o, 1, ll - o < wrap ? ll - o : wrap, fp); fputc('\n', fp); }
+		}
+		if (fp != stdout) fclose(fp);
+		free(buf);
+		return 0;
 	}
 	buf = (uint8_t*)malloc((size_t)n * (l + 1));
 	if (yaksynth_reads(buf, n, l, g, seed, e, nr, 0, thr) < 0) return 1;

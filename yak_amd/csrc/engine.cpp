@@ -20,6 +20,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include "yk_device.h"
 #include "engine.h"
 
@@ -544,6 +545,50 @@ static int count_by_ranges(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart)
 	return r;
 }
 
+/* count-existing pass, records grouped by prefix: one workgroup per slot range with the range's keys in LDS
+ * (k_img_count_own).  Returns 0 done, -1 error, 1 not applicable. */
+static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash_only)
+{
+	if (env_i64("YAKAMD_COUNT_OWN", 1) == 0 || c->nb_bits != c->pre) return 1;
+	const size_t budget = (size_t)env_i64("YAKAMD_OWN_LDS", 156000);     /* one workgroup per CU with as few ranges as possible: every range re-reads the sub-table's records (measured: 8 ranges x 1 WG/CU 16.9 ms, 16 ranges x 2 WG/CU 24.8 ms) */
+	u32 bmax = 0;
+	for (int p = c->plo; p < c->phi; ++p) if (c->h_bits[p] != YK_NOCAP) bmax = std::max(bmax, c->h_bits[p]);
+	if (bmax == 0) return 0;                                         /* no sub-table has a slot: nothing can be found */
+	int rng_log = -1; u32 kmax = 0;
+	for (int rl = (int)bmax; rl >= 5 && rng_log < 0; --rl) {
+		u32 km = 1;
+		for (int p = c->plo; p < c->phi; ++p) {
+			if (c->h_bits[p] == YK_NOCAP) continue;
+			const int rbp = (int)c->h_bits[p] > rl ? (int)c->h_bits[p] - rl : 0;
+			const u32 e = (c->h_count[p] + (1u << rbp) - 1) >> rbp;
+			km = std::max(km, rbp ? e + e / 8 + 192 : c->h_count[p]);   /* a range's share of the keys + 12 % + 6 sigma at small counts */
+		}
+		if (yk_count_own_lds(1u << rl, km) <= budget) { rng_log = rl; kmax = km; }
+	}
+	const int rb = rng_log < 0 ? 99 : (int)bmax - rng_log;
+	if (rb > (int)env_i64("YAKAMD_OWN_MAXRB", 4)) return 1;        /* every range's workgroup streams the whole sub-table: too redundant beyond 16 ranges */
+	u64 *d_list = 0; u32 *d_ln = 0;
+	const u32 list_cap = (u32)std::min<int64_t>(env_i64("YAKAMD_XLIST_CAP", 1 << 22), 1 << 22);   /* the knob is for tests */
+	if (dmalloc(&d_list, (size_t)1 << 22) || dmalloc(&d_ln, 2)) { dfree(d_list); return -1; }
+	int r = 0;
+	const ImgView img = img_view(c);
+	const size_t lds = yk_count_own_lds(1u << rng_log, kmax);
+	if (hipMemsetAsync(d_ln, 0, 8, c->st) != hipSuccess) r = fail("memset");
+	if (!r && yk_launch_img_count_own(c->d_rec, hash_only, 0, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st)) r = fail("key-owning count kernel could not be configured");
+	u32 xn[2] = { 0, 0 };
+	if (!r && (hipMemcpyAsync(xn, d_ln, 8, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)) r = fail("key-owning count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+	if (!r) {
+		if (xn[1]) yk_launch_img_count_own(c->d_rec, hash_only, 1, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st);   /* list too small: second sweep */
+		else if (xn[0]) yk_launch_img_count_h(d_list, (int64_t)xn[0], img, c->st);
+		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] key-owning count: 2^%d slots per range (up to 2^%d ranges per sub-table), %u keys of LDS room, %zu B of LDS, %u boundary-crossing instances%s\n",
+		                                          rng_log, rb, kmax, lds, xn[0], xn[1] ? " (list overflow: second sweep)" : "");
+		if (hipStreamSynchronize(c->st) != hipSuccess) r = fail("count sweep failed");
+	}
+	(void)n_rec;
+	dfree(d_list); dfree(d_ln);
+	return r;
+}
+
 static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart, int hash_only)
 {
 	if (n_rec <= 0) return 0;
@@ -554,6 +599,14 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		EvTimer tm(c->st);
 		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
 		 * exclusive-ownership counting, no global atomics */
+		if (d_bstart) {
+			const int r = count_own(c, n_rec, d_bstart, hash_only);
+			if (r <= 0) {
+				const double ms = tm.stop();
+				c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+				return r;
+			}
+		}
 		const size_t lds = d_bstart ? count_lds_bytes(c) : 0;
 		if (!lds && d_bstart && hash_only && c->nb_bits == c->pre && env_i64("YAKAMD_COUNT_RNG", 1) != 0) {
 			/* sub-tables too large for one workgroup's LDS: split each one's hashes by home-slot range first */
@@ -931,7 +984,7 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	/* owner ranks of the placement stages in LDS: 32-bit up to lds_words slots, 16-bit up to twice that */
 	u32 cap_top = 0;
 	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
-	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 32768));   /* 0: owner ranks in global scratch */
+	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 16384));   /* 64 KB: two workgroups per CU (measured 18.5 ms against 20.5 with 128 KB); 0: owner ranks in global scratch */
 	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
 	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
 	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
@@ -1012,14 +1065,21 @@ static int fast_finish(yakamd_ctx *c)
 	chunk_first[P] = (u32)chunks.size();
 	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
 
-	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0; u64 *d_bbase = 0, *d_sbstart = 0; Rec *d_r2 = 0;
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0; Rec *d_r2 = 0;
 	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
+	LcOut lo; lo.kc = 0; lo.T = 0; lo.nsel = 0; lo.lp = 0; lo.nd = 0;
+	u64 *d_scr = 0, *d_scroff = 0;
+	/* every device buffer of this function is released here, whichever way it is left */
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
+		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_segcur); dfree(d_ovf); dfree(d_ovf2); dfree(d_ndist); dfree(d_bbase); dfree(d_sbstart);
+		dfree(d_segbase); dfree(d_r2); dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd);
+		dfree(d_scr); dfree(d_scroff);
+	} };
 	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2) ||
-	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb)) return -1;
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
 	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
 	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));   /* NOVF, NOVF2 */
 	{
 		EvTimer tm(c->st);
@@ -1030,25 +1090,28 @@ static int fast_finish(yakamd_ctx *c)
 	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
-	if (dmalloc(&kc[0], n_total) || dmalloc(&tt[0], n_total)) return -1;
-	u64 h_cnt[YKC_N];
-	u32 *d_ovf2 = 0, *d_ndist = 0;
-	if (dmalloc(&d_ovf2, n_sb) || dmalloc(&d_ndist, P)) return -1;
+	/* the keys a sub-bucket selects are written over the front of its own record range in lo.kc / lo.T */
+	if (dmalloc(&lo.kc, n_total) || dmalloc(&lo.T, n_total) || dmalloc(&lo.nsel, n_sb) || dmalloc(&lo.lp, n_sb) || dmalloc(&lo.nd, n_sb) || dmalloc(&d_ndist, P)) return -1;
+	if (c->plo > 0 || c->phi < P) {                              /* sub-buckets outside the shard are never visited */
+		HIPCK(hipMemsetAsync(lo.nsel, 0, n_sb * 4, c->st)); HIPCK(hipMemsetAsync(lo.lp, 0, n_sb * 4, c->st)); HIPCK(hipMemsetAsync(lo.nd, 0, n_sb * 4, c->st));
+	}
 	HIPCK(hipMemsetAsync(d_ndist, 0, P * 4, c->st));
+	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
+	u64 h_cnt[YKC_N];
+	const bool lc2 = yk_lc2_ok(fp) != 0;
 	{
 		EvTimer tm(c->st);
-		yk_launch_lds_count(0, fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
-		                    c->d_lastput, d_ndist, c->d_counters, 0, 0, d_ovf, c->st);
+		if (lc2) yk_launch_lc2(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, d_ovf2, c->st);
+		else yk_launch_lds_count(0, fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, 0, 0, d_ovf, c->st);
 		c->ms_lds = tm.stop();
 		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
 	}
 	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] lds tier G: %.2f ms, %llu of %zu sub-buckets passed on\n", c->ms_lds, (unsigned long long)h_cnt[YKC_NOVF], n_sb);
+	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] %s: %.2f ms, %llu of %zu sub-buckets passed on\n", lc2 ? "k_lc2" : "lds tier G", c->ms_lds, (unsigned long long)(h_cnt[YKC_NOVF] + h_cnt[YKC_NOVF2]), n_sb);
 	if (h_cnt[YKC_NOVF]) {      /* crowded bloom blocks / un-staged range: the tier with sort arrays */
 		EvTimer tm(c->st);
-		yk_launch_lds_count(1, fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
-		                    c->d_lastput, d_ndist, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
+		yk_launch_lds_count(1, fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
 		c->st_cur.ms_insert += tm.stop();
 		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 		HIPCK(hipStreamSynchronize(c->st));
@@ -1065,15 +1128,29 @@ static int fast_finish(yakamd_ctx *c)
 			u64 cap = 4096; while (cap < 2 * n) cap <<= 1;
 			off[i] = words; words += 5 * cap;               /* 40 B per slot = 5 u64 */
 		}
-		u64 *d_scr = 0, *d_off = 0;
-		if (dmalloc(&d_scr, words) || dmalloc(&d_off, n_ovf)) return -1;
-		HIPCK(hipMemcpyAsync(d_off, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
+		if (dmalloc(&d_scr, words) || dmalloc(&d_scroff, n_ovf)) return -1;
+		HIPCK(hipMemcpyAsync(d_scroff, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
 		EvTimer tm(c->st);
-		yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), d_bbase, d_segcur, kc[0], tt[0],
-		                        c->d_lastput, d_ndist, d_ovf2, n_ovf, d_off, d_scr, c->st);
+		yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, d_ovf2, n_ovf, d_scroff, d_scr, c->st);
 		c->st_cur.ms_insert += tm.stop();
 		HIPCK(hipStreamSynchronize(c->st));
-		dfree(d_scr); dfree(d_off);
+		dfree(d_scr); dfree(d_scroff);
+	}
+	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
+	/* gather the fragments: keys per sub-table, then one contiguous list each */
+	std::vector<u32> m(P, 0);
+	std::vector<u64> ro(P + 1, 0);
+	yk_launch_lc_sum(lo.nsel, s2, c->plo, c->phi, d_segcur, c->st);
+	HIPCK(hipMemcpyAsync(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	for (int p = 0; p < P; ++p) ro[p + 1] = ro[p] + m[p];
+	const u64 n_sel = ro[P];
+	if (dmalloc(&kc[0], n_sel) || dmalloc(&tt[0], n_sel) || dmalloc(&kc[1], n_sel) || dmalloc(&tt[1], n_sel) || dmalloc(&d_segbase, P + 1)) return -1;
+	HIPCK(hipMemcpyAsync(d_segbase, ro.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	{
+		EvTimer tm(c->st);
+		yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, c->t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
+		c->st_cur.ms_select += tm.stop();
 	}
 	{
 		std::vector<u32> nd(P);
@@ -1082,28 +1159,23 @@ static int fast_finish(yakamd_ctx *c)
 		for (int p = 0; p < P; ++p) tot_d += nd[p];
 		c->st_cur.n_distinct_seen += (int64_t)tot_d;
 	}
-	dfree(d_ovf2); dfree(d_ndist);
-	dfree(d_r2); dfree(d_sbstart); dfree(d_ovf);
-	std::vector<u32> m(P);
-	HIPCK(hipMemcpy(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost));
-	if (dmalloc(&kc[1], n_total) || dmalloc(&tt[1], n_total)) return -1;
+	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist);
 	int cur = 0;
 	{
 		EvTimer tm(c->st);
 		const int tbits = std::max(1, ceil_log2_u64(c->t_end + 1));
 		for (int shift = 0; shift < tbits; shift += 8) {
-			yk_launch_seg_sort_pass2(d_bbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
+			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
 			cur ^= 1;
 		}
 		c->st_cur.ms_sort += tm.stop();
 	}
 	{
 		EvTimer tm(c->st);
-		std::vector<u64> ro(bbase.begin(), bbase.begin() + P);
+		ro.resize(P);
 		if (run_replay(c, m, 0, kc[cur], tt[cur], c->d_lastput, 0, false, &ro)) return -1;
 		c->st_cur.ms_replay += tm.stop();
 	}
-	dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); dfree(d_bbase); dfree(d_segcur);
 	return 0;
 }
 

@@ -1674,7 +1674,7 @@ __device__ bool replay_double_par(u64 *keys, const u32 *cur, u32 *oth, u32 n, u3
 	return true;
 }
 
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used,
               u32 *scr_used, u32 *scr_owner, u64 *scr_par, const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
               u32 *out_bits, u32 *out_count, u32 lds_words)
@@ -2092,8 +2092,7 @@ __device__ __forceinline__ BfSeq lc_seq(u64 key, const FastParams &fp)       /* 
 /* Returns false when this tier cannot handle the sub-bucket (nothing observable has been modified). */
 template <int MODE>
 __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 *__restrict__ sbstart,
-                        const Rec *__restrict__ rec, u32 *bloom32, const ImgView &img,
-                        const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p,
+                        const Rec *__restrict__ rec, u32 *bloom32, const ImgView &img, const LcOut &O,
                         u32 *s_misc /* [8] in LDS */)
 {
 	constexpr bool GLB = MODE == LC_X;
@@ -2106,9 +2105,10 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	if (fp.bloom_mode) gw = bloom32 + ((((u64)p << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5);
 	if (lo == hi) {
 		if (stage_bloom && fp.bf_virgin) for (u32 i = tid; i < (16u << lb); i += 256) gw[i] = 0;   /* nothing maps here */
+		if (tid == 0) { O.nsel[sb] = 0; O.lp[sb] = 0; O.nd[sb] = 0; }
 		return true;
 	}
-	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_nsel = s_misc + 4, *s_base = s_misc + 5, *s_run = s_misc + 7;
+	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_run = s_misc + 7;
 	const bool pre0 = lo + tid < hi, pre1 = lo + 256 + tid < hi, pre2 = lo + 512 + tid < hi;
 	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
 	if (pre0) r0 = rec[lo + tid];
@@ -2306,30 +2306,20 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 		*kc = (T.K[s] >> fp.pre) << 10 | c;
 		return true;
 	};
-	u32 mine = 0;
-	for (u32 s = tid; s < T.cap; s += 256) { u64 kc; u32 Tt; mine += selected(s, &kc, &Tt); }
-	if (mine) atomicAdd(s_nsel, mine);
-	lc_sync<MODE>();
-	if (tid == 0) {
-		const u32 nsel = *s_nsel;
-		const u64 b = nsel ? (u64)atomicAdd(&seg_cur[p], nsel) : 0;
-		s_base[0] = (u32)b; s_base[1] = (u32)(b >> 32);
-		if (*s_lp) atomicMax(&lastput[p], fp.t_pass0 + (u64)(*s_lp - 1) + 1);
-		atomicAdd(&ndist_p[p], *s_ndist);
-	}
-	__syncthreads();
-	const u64 base = seg_base[p] + ((u64)s_base[0] | (u64)s_base[1] << 32);
+	/* the selected keys go to the front of the sub-bucket's own record range in the output arrays (a
+	 * sub-bucket never selects more keys than it has records); k_lc_compact gathers the fragments */
 	for (u32 s = tid; s < T.cap; s += 256) {
 		u64 kc; u32 Tt;
-		if (selected(s, &kc, &Tt)) { const u32 r = atomicAdd(s_run, 1u); out_kc[base + r] = kc; out_T[base + r] = fp.t_pass0 + Tt; }
+		if (selected(s, &kc, &Tt)) { const u32 r = atomicAdd(s_run, 1u); O.kc[lo + r] = kc; O.T[lo + r] = fp.t_pass0 + Tt; }
 	}
+	lc_sync<MODE>();
+	if (tid == 0) { O.nsel[sb] = *s_run; O.lp[sb] = *s_lp; O.nd[sb] = *s_ndist; }
 	return true;
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256)
-void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
-                 const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, u64 *counters,
+void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters,
                  const u32 *in_list, u32 *ovf_list, int ovf_counter)
 {
 	__shared__ u64 s_K[YK_LDS_C];
@@ -2341,13 +2331,12 @@ void k_lds_count(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32
 	__shared__ u32 s_misc[8];
 	LcTab T; T.K = s_K; T.T1 = s_T1; T.T2 = s_T2; T.CN = s_CN; T.TM = s_TM; T.SO = s_SO; T.SP = 0; T.BL = s_BL; T.GC = s_GC; T.G = s_G; T.cap = YK_LDS_C;
 	const u32 sb = in_list ? in_list[blockIdx.x] : ((u32)fp.plo << fp.s2_bits) + blockIdx.x;   /* only the sub-tables of this shard */
-	if (!lc_body<MODE>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, s_misc))
-		if (threadIdx.x == 0) ovf_list[atomicAdd(&counters[ovf_counter], 1ull)] = sb;
+	if (!lc_body<MODE>(fp, T, sb, sbstart, rec, bloom32, img, O, s_misc))
+		if (threadIdx.x == 0) { ovf_list[atomicAdd(&counters[ovf_counter], 1ull)] = sb; O.nsel[sb] = 0; O.lp[sb] = 0; O.nd[sb] = 0; }
 }
 
 __global__ __launch_bounds__(256)
-void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img,
-                     const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p,
+void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O,
                      const u32 *ovf_list, const u64 *scr_off, u64 *scr)
 {
 	__shared__ u32 s_misc[8];
@@ -2358,7 +2347,297 @@ void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *blo
 	LcTab T; T.cap = cap; T.BL = 0; T.GC = 0; T.G = 0;
 	T.K = base; T.SO = base + cap;
 	T.T1 = (u32*)(base + 2 * (u64)cap); T.T2 = T.T1 + cap; T.CN = T.T2 + cap; T.SP = T.CN + cap; T.TM = T.SP + cap;
-	lc_body<LC_X>(fp, T, sb, sbstart, rec, bloom32, img, seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, s_misc);
+	lc_body<LC_X>(fp, T, sb, sbstart, rec, bloom32, img, O, s_misc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_lc2: the first tier of the exclusive-ownership counting, built for latency: a sub-bucket's ~560
+ * records keep a workgroup busy for a few thousand cycles only, nearly all of them waiting (global
+ * loads, dependent LDS atomics, barriers).  So
+ *   * workgroups are PERSISTENT: each walks every gridDim-th sub-bucket and requests the next one's
+ *     records while it counts the current one (the global latency disappears behind the LDS work);
+ *   * the LDS table is organised by bloom block: the home slot of a key is (block inside the staged
+ *     range) x (slots per block) + a few hash bits, so the keys of one 512-bit block sit in one probe
+ *     cluster and "the other keys of my block" is a short scan from the block's first slot -- no
+ *     grouping passes, no per-block lists, no limit on the keys per block;
+ *   * the gate of bbf.c:25-42 / htab.c:63-65 is evaluated per key, all keys in parallel: a key passes at
+ *     its first occurrence iff each of its probe bits is set in the filter as it was before this
+ *     sub-bucket or belongs to a key of the same block whose first occurrence is earlier (every
+ *     instance sets its bits whatever the gate says); then all bits are ORed in (order-free);
+ *   * nothing is reserved with global atomics: the selected keys go to the front of the sub-bucket's
+ *     own record range in the output arrays (LcOut), k_lc_compact gathers them per sub-table.
+ * Three barriers per sub-bucket.  Sub-buckets this tier cannot take (too many distinct k-mers for the
+ * LDS table) are listed for k_lds_count_ovf untouched.  Needs n_hash <= 32 and, with a filter, a
+ * staged range (<= 128 blocks per sub-bucket); the host falls back to k_lds_count otherwise.
+ * ------------------------------------------------------------------------------------------ */
+#define LC2_CAP 1024
+#define LC2_FULL 768                      /* distinct k-mers a sub-bucket may hold without a filter (the slot list borrows the bloom stage) ... */
+#define LC2_FULL_BF 624                   /* ... and with one: 32000 B of LDS per workgroup = 25 allocation granules, 5 workgroups per CU */
+#define LC2_FP    0x8000u                 /* 16-bit per-key word: occurrences (12 bits, clamped) | flags */
+#define LC2_EXIST 0x4000u
+#define LC2_CMASK 0x0fffu
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict__ rec, u32 *bloom32, ImgView img, LcOut O,
+           u64 *counters, u32 *ovf_list, u32 n_sb)
+{
+	__shared__ u64 s_K[LC2_CAP];
+	__shared__ u32 s_T1[LC2_CAP], s_T2[LC2_CAP], s_TM[LC2_CAP], s_CN[LC2_CAP / 2];     /* 5 workgroups per CU */
+	__shared__ u32 s_BL[LC_BLOOM_WORDS];
+	__shared__ unsigned short s_listb[LC2_FULL_BF];                /* slots of the distinct k-mers, in claim order */
+	__shared__ u32 s_misc[8];
+	const u32 tid = threadIdx.x;
+	const bool bloom = fp.bloom_mode != 0, virgin = fp.bf_virgin != 0;
+	const int lb = bloom ? fp.nb - 9 - fp.s2_bits : 0;             /* log2 bloom blocks owned by a sub-bucket */
+	const int rsh = 10 - lb;                                       /* log2 table slots per block */
+	const u32 R = 1u << rsh, nbw = bloom ? 16u << lb : 0;
+	const u64 lmask = (1ull << lb) - 1;
+	const u32 sb0 = (u32)fp.plo << fp.s2_bits;
+	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_run = s_misc + 3;
+	unsigned short *s_list = bloom ? s_listb : (unsigned short*)s_BL;
+	const u32 full = bloom ? LC2_FULL_BF : LC2_FULL;
+
+	auto cn_get = [&](u32 s) -> u32 { return s_CN[s >> 1] >> (16 * (s & 1)) & 0xffffu; };
+	for (u32 i = tid; i < LC2_CAP; i += 256) { s_K[i] = YK_EMPTY; s_T1[i] = T32_INF; s_T2[i] = T32_INF; s_TM[i] = 0; }
+	for (u32 i = tid; i < LC2_CAP / 2; i += 256) s_CN[i] = 0;
+	if (virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = 0;
+	if (tid < 8) s_misc[tid] = 0;
+	u32 it = blockIdx.x;
+	u64 lo = 0, hi = 0;
+	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
+	if (it < n_sb) {
+		lo = sbstart[sb0 + it]; hi = sbstart[sb0 + it + 1];
+		if (lo + tid < hi) r0 = rec[lo + tid];
+		if (lo + 256 + tid < hi) r1 = rec[lo + 256 + tid];
+		if (lo + 512 + tid < hi) r2 = rec[lo + 512 + tid];
+	}
+	__syncthreads();
+
+	auto home = [&](u64 key) -> u32 {
+		const u64 x = key >> fp.pre;
+		return ((u32)(x & lmask) << rsh) | (u32)((x * 0x9E3779B97F4A7C15ull) >> (64 - rsh));
+	};
+	u32 tmax = 0;
+	auto put = [&](const Rec rc) {
+		const u64 key = rc.x;
+		const u32 t = (u32)rc.y;
+		u32 s = home(key), n = 0;
+		for (; n < LC2_CAP; ++n, s = (s + 1) & (LC2_CAP - 1)) {
+			u64 cur = s_K[s];
+			if (cur == key) break;
+			if (cur == YK_EMPTY) {
+				cur = atomicCAS(&s_K[s], YK_EMPTY, key);
+				if (cur == YK_EMPTY) { const u32 at = atomicAdd(s_ndist, 1u); if (at < full) s_list[at] = (unsigned short)s; break; }
+				if (cur == key) break;
+			}
+		}
+		if (n == LC2_CAP) { *s_ovf = 1; return; }
+		if ((cn_get(s) & LC2_CMASK) < 0x800u) atomicAdd(&s_CN[s >> 1], 1u << (16 * (s & 1)));   /* only min(count, 1024) is ever used; 256 racing lanes cannot carry out of the field */
+		const u32 old = atomicMin(&s_T1[s], t);
+		if (bloom) {
+			if (old != T32_INF) atomicMin(&s_T2[s], old > t ? old : t);
+			atomicMax(&s_TM[s], t);
+		}
+		tmax = t + 1 > tmax ? t + 1 : tmax;
+	};
+
+	while (it < n_sb) {
+		const u32 sb = sb0 + it, itn = it + gridDim.x;
+		u32 *gw = bloom ? bloom32 + ((((u64)(sb >> fp.s2_bits) << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5) : 0;
+		u64 lon = 0, hin = 0;
+		if (itn < n_sb) { lon = sbstart[sb0 + itn]; hin = sbstart[sb0 + itn + 1]; }
+		if (bloom && !virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = gw[i];
+		/* A: count; first / second / last occurrence (same loser rule as k_acc_insert) */
+		tmax = 0;
+		if (lo + tid < hi) put(r0);
+		if (lo + 256 + tid < hi) put(r1);
+		if (lo + 512 + tid < hi) put(r2);
+		for (u64 i = lo + 768 + tid; i < hi; i += 256) put(rec[i]);
+		if (!bloom && tmax) atomicMax(s_lp, tmax);                /* without a filter every instance is a put-call */
+		/* the next sub-bucket's records travel while this one is gated and selected */
+		if (lon + tid < hin) r0 = rec[lon + tid];
+		if (lon + 256 + tid < hin) r1 = rec[lon + 256 + tid];
+		if (lon + 512 + tid < hin) r2 = rec[lon + 512 + tid];
+		__syncthreads();
+		const u32 ndist = *s_ndist;
+		const bool give_up = *s_ovf || ndist > full;
+		if (!give_up && !(fp.dbg & 16)) {
+			/* B: keys already in the table image only gain counts (htab.c:66-69 on an existing key) */
+			if (fp.img_nonempty) {
+				for (u32 li = tid; li < ndist; li += 256) {
+					const u32 s = s_list[li];
+					const int64_t idx = img_find(img, s_K[s]);
+					if (idx >= 0) {
+						const u64 kc = img.keys[idx], c = (kc & 1023) + (cn_get(s) & LC2_CMASK);
+						img.keys[idx] = fp.or_mode ? kc | (s_T1[s] & 15u) : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+						atomicOr(&s_CN[s >> 1], LC2_EXIST << (16 * (s & 1)));
+					}
+				}
+				__syncthreads();
+			}
+			/* C: the gate, one lane per key.  First the earlier keys of the same block are collected (a short
+			 * scan of the block's probe cluster), then their probe bits are matched against the key's own:
+			 * for n_hash <= 4 the key's probes are packed into four 16-bit fields and one peer probe is
+			 * compared with all of them at once */
+			if (bloom && !(fp.dbg & 32)) {
+				for (u32 li = tid; li < ndist; li += 256) {
+					const u32 s = s_list[li];
+					const u64 kx = s_K[s];
+					if (cn_get(s) & LC2_EXIST) continue;
+					const BfSeq q = lc_seq(kx, fp);
+					const u32 blk = (u32)((kx >> fp.pre) & lmask), t1x = s_T1[s];
+					u32 miss = q.nd >= 32 ? 0xffffffffu : (1u << q.nd) - 1;
+					if (!virgin) {
+						const u32 *w = s_BL + (blk << 4);
+						for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) if (w[z >> 5] >> (z & 31) & 1) miss &= ~(1u << i);
+					}
+					u64 peers = 0; u32 np = 0;                                    /* up to 6 slot numbers of 10 bits */
+					const u32 r0s = blk << rsh;
+					for (u32 d = 0; miss && d < LC2_CAP; ++d) {
+						const u32 j = (r0s + d) & (LC2_CAP - 1);
+						const u64 ky = s_K[j];
+						if (ky == YK_EMPTY) { if (d + 1 >= R) break; continue; }     /* no key of this block can sit beyond */
+						if (j == s || (u32)((ky >> fp.pre) & lmask) != blk || s_T1[j] >= t1x || (cn_get(j) & LC2_EXIST)) continue;
+						if (np < 6) peers |= (u64)j << (10 * np);
+						else {                                                      /* a crowded block: the plain way */
+							const BfSeq y = lc_seq(ky, fp);
+							for (u32 a2 = 0, w = y.h1; a2 < y.nd; ++a2, w = (w + y.h2) & 511)
+								for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) if (z == w) miss &= ~(1u << i);
+						}
+						++np;
+					}
+					if (np > 6) np = 6;
+					if (miss && np) {
+						if (q.nd <= 4) {
+							u64 zp = 0;
+							for (u32 i = 0, z = q.h1; i < 4; ++i, z = (z + q.h2) & 511) zp |= (u64)(i < q.nd ? z : 0x3ffu) << (16 * i);
+							u64 nz = 0x8000800080008000ull;                        /* field i keeps its top bit while probe i is matched by nobody */
+							for (u32 e = 0; e < np; ++e) {
+								const BfSeq y = lc_seq(s_K[(u32)(peers >> (10 * e)) & 1023u], fp);
+								for (u32 a2 = 0, w = y.h1; a2 < y.nd; ++a2, w = (w + y.h2) & 511)
+									nz &= (zp ^ (w * 0x0001000100010001ull)) + 0x7fff7fff7fff7fffull;   /* fields are < 2^10: no carry between them */
+							}
+							const u32 cov = (u32)(~nz >> 15 & 1) | (u32)(~nz >> 30 & 2) | (u32)(~nz >> 45 & 4) | (u32)(~nz >> 60 & 8);
+							miss &= ~cov;
+						} else {
+							for (u32 e = 0; e < np; ++e) {
+								const BfSeq y = lc_seq(s_K[(u32)(peers >> (10 * e)) & 1023u], fp);
+								for (u32 a2 = 0, w = y.h1; a2 < y.nd; ++a2, w = (w + y.h2) & 511)
+									for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) if (z == w) miss &= ~(1u << i);
+							}
+						}
+					}
+					if (miss == 0) atomicOr(&s_CN[s >> 1], LC2_FP << (16 * (s & 1)));   /* yak_bf_insert() == n_hash */
+				}
+				if (!virgin) __syncthreads();                                  /* every gate has read the filter as it was */
+			}
+			/* C' + D + E: set the bits, last put-call, keys entering the table */
+			u32 best = 0;
+			for (u32 li = tid; li < ndist; li += 256) {
+				const u32 s = s_list[li];
+				const u64 kx = s_K[s];
+				const u32 cn = cn_get(s);
+				if (bloom && !(fp.dbg & 32)) {
+					if (!(cn & LC2_EXIST)) {
+						const BfSeq q = lc_seq(kx, fp);
+						u32 *w = s_BL + ((u32)((kx >> fp.pre) & lmask) << 4);
+						for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) atomicOr(&w[z >> 5], 1u << (z & 31));
+					}
+					/* last put-call = last instance that is not a rejected first occurrence (htab.c:63-65) */
+					if ((cn & (LC2_EXIST | LC2_FP)) || (cn & LC2_CMASK) >= 2) best = s_TM[s] + 1 > best ? s_TM[s] + 1 : best;
+				}
+				if (cn & LC2_EXIST) continue;
+				u32 c = cn & LC2_CMASK, Tt;
+				if (!bloom || (cn & LC2_FP)) Tt = s_T1[s];
+				else if (s_T2[s] != T32_INF) { Tt = s_T2[s]; c -= 1; }
+				else continue;
+				if (c > 1023) c = 1023;
+				if (fp.or_mode) c = s_T1[s] & 15u;                            /* a key seen once per load: its flag travels in the time's low bits */
+				const u32 r = atomicAdd(s_run, 1u);
+				O.kc[lo + r] = (kx >> fp.pre) << 10 | c; O.T[lo + r] = fp.t_pass0 + Tt;
+			}
+			if (best) atomicMax(s_lp, best);
+		}
+		__syncthreads();
+		/* write-back, per-sub-bucket results, clean tables for the next sub-bucket */
+		if (give_up) {
+			if (virgin) for (u32 i = tid; i < nbw; i += 256) gw[i] = 0;       /* the next tier expects real zeros */
+			if (tid == 0) { ovf_list[atomicAdd(&counters[YKC_NOVF2], 1ull)] = sb; O.nsel[sb] = 0; O.lp[sb] = 0; O.nd[sb] = 0; }
+		} else {
+			if (bloom && !(fp.dbg & 64)) for (u32 i = tid; i < nbw; i += 256) gw[i] = s_BL[i];
+			if (tid == 0) { O.nsel[sb] = *s_run; O.lp[sb] = *s_lp; O.nd[sb] = ndist; }
+		}
+		if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; s_misc[2] = 0; s_misc[3] = 0; }
+		if (give_up) {
+			for (u32 i = tid; i < LC2_CAP; i += 256) { s_K[i] = YK_EMPTY; s_T1[i] = T32_INF; s_T2[i] = T32_INF; s_TM[i] = 0; }
+			for (u32 i = tid; i < LC2_CAP / 2; i += 256) s_CN[i] = 0;
+		} else for (u32 li = tid; li < ndist; li += 256) {
+			const u32 s = s_list[li];
+			s_K[s] = YK_EMPTY; s_T1[s] = T32_INF; s_T2[s] = T32_INF; s_TM[s] = 0; s_CN[s >> 1] = 0;
+		}
+		if (virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = 0;
+		it = itn; lo = lon; hi = hin;
+		__syncthreads();
+	}
+}
+
+/* keys selected per sub-table = sum over its sub-buckets */
+__global__ __launch_bounds__(256)
+void k_lc_sum(const u32 *__restrict__ nsel, int s2_bits, int plo, u32 *seg_cnt)
+{
+	__shared__ u32 s_tot;
+	const u32 p = (u32)plo + blockIdx.x, S2 = 1u << s2_bits;
+	if (threadIdx.x == 0) s_tot = 0;
+	__syncthreads();
+	u32 c = 0;
+	for (u32 j = threadIdx.x; j < S2; j += 256) c += nsel[(size_t)p * S2 + j];
+	for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_tot, c);
+	__syncthreads();
+	if (threadIdx.x == 0) seg_cnt[p] = s_tot;
+}
+
+/* gather the fragments of one sub-table into its contiguous list (any order: the sort by insertion time
+ * follows); last put-call and distinct k-mers of the sub-table */
+__global__ __launch_bounds__(256)
+void k_lc_compact(LcOut O, const u64 *__restrict__ sbstart, int s2_bits, int plo, u64 t_pass0, const u64 *__restrict__ seg_base,
+                  u64 *__restrict__ out_kc, u64 *__restrict__ out_T, u64 *lastput, u32 *ndist_p)
+{
+	__shared__ u32 s_off[256], s_red[2];
+	const u32 p = (u32)plo + blockIdx.x, S2 = 1u << s2_bits, tid = threadIdx.x, lane = tid & 63;
+	const size_t b0 = (size_t)p * S2;
+	if (tid < 2) s_red[tid] = 0;
+	u64 run = seg_base[p];
+	u32 lpm = 0, nds = 0;
+	for (u32 j0 = 0; j0 < S2; j0 += 256) {
+		__syncthreads();
+		const u32 j = j0 + tid, n = j < S2 ? O.nsel[b0 + j] : 0;
+		if (j < S2) { const u32 l = O.lp[b0 + j]; lpm = l > lpm ? l : lpm; nds += O.nd[b0 + j]; }
+		s_off[tid] = n;
+		__syncthreads();
+		if (tid < 64) {                                            /* exclusive scan of 256 counts by one wave */
+			u32 v[4], t = 0;
+			for (int q = 0; q < 4; ++q) { v[q] = s_off[4 * tid + q]; t += v[q]; }
+			u32 incl = t;
+			for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= (u32)o) incl += x; }
+			u32 e = incl - t;
+			for (int q = 0; q < 4; ++q) { s_off[4 * tid + q] = e; e += v[q]; }
+			if (tid == 63) s_red[1] = incl;
+		}
+		__syncthreads();
+		/* one wave per sub-bucket */
+		for (u32 q = tid >> 6; q < 256 && j0 + q < S2; q += 4) {
+			const u32 cnt = O.nsel[b0 + j0 + q];
+			const u64 src = sbstart[b0 + j0 + q], dst = run + s_off[q];
+			for (u32 i = lane; i < cnt; i += 64) { out_kc[dst + i] = O.kc[src + i]; out_T[dst + i] = O.T[src + i]; }
+		}
+		run += s_red[1];
+	}
+	for (int o = 32; o; o >>= 1) { const u32 x = __shfl_down(lpm, o); lpm = x > lpm ? x : lpm; nds += __shfl_down(nds, o); }
+	__syncthreads();
+	if (lane == 0) { atomicMax(&s_red[0], lpm); atomicAdd(&ndist_p[p], nds); }
+	__syncthreads();
+	if (tid == 0 && s_red[0]) { const u64 v = t_pass0 + (u64)s_red[0]; if (v > lastput[p]) lastput[p] = v; }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2521,6 +2800,147 @@ void k_img_count_rng(const u64 *__restrict__ rec, const u64 *__restrict__ sbstar
 	for (u32 li = tid; li < len; li += 1024) {
 		const u32 c = s_ct[li >> 1] >> (16 * (li & 1)) & 0xffffu;
 		if (c) img.delta[off + start + li] += c;                          /* exclusive owner: plain read-modify-write */
+	}
+}
+
+/* ==========================================================================================
+ * Count-existing passes with the KEYS in LDS (the default for records grouped by sub-table).
+ * k_img_count_lds keeps bitmap + counters of a whole sub-table in one workgroup's LDS but compares
+ * every probe against a key in HBM/L2: 64 bytes fetched per 8-byte compare, the measured traffic was
+ * 4x the algorithmic bytes.  Here a sub-table is cut into 2^rbp slot ranges and ONE workgroup owns a
+ * range outright: its `used` bits, a per-word rank table, the keys of its used slots packed in rank
+ * order and a 16-bit counter per key all sit in LDS, so a probe is LDS work only.  The records are
+ * not partitioned again: the 2^rbp workgroups of a sub-table all stream the sub-table's records and
+ * keep those whose home slot (top bits of khashl's 32-bit product, khashl.h:98) falls in their range.
+ * blockIdx is mapped so that these workgroups run on ONE XCD next to each other in time: the stream
+ * comes from HBM once and from that XCD's L2 for the others.  A probe that runs past the end of its
+ * range goes to `list` (counted by k_img_count_h afterwards; CROSS = 1 is the second sweep if the list
+ * overflowed).  A range with more keys than the LDS budget counts its records with device atomics.
+ * ========================================================================================== */
+#define OWN_U 8
+template <int W, int CROSS>
+__global__ __launch_bounds__(1024)
+void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart, ImgView img, int plo, int n_p, int rb, int rng_log, u32 kmax,
+                     u64 *__restrict__ list, u32 *list_n, u32 list_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ u32 s_wsum[16];
+	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u32 xcd = blockIdx.x & 7, y = blockIdx.x >> 3, pi = ((y >> rb) << 3) + xcd, r = y & ((1u << rb) - 1);
+	if (pi >= (u32)n_p) return;
+	const u32 p = (u32)plo + pi, bits = img.bits[p];
+	const u64 lo = bstart[p], hi = bstart[p + 1];
+	if (bits == YK_NOCAP || lo == hi) return;
+	const int rbp = (int)bits > rng_log ? (int)bits - rng_log : 0;     /* log2 ranges of this sub-table */
+	if (r >> rbp) return;
+	const u32 cap = 1u << bits, nmask = cap - 1, L = cap >> rbp, start = r * L, nw = (L + 31) / 32;
+	const u64 off = img.off[p];
+	u32 *s_bm = s_dyn, *s_rk = s_dyn + nw;
+	u64 *s_k = (u64*)(s_dyn + 2 * ((nw + 1) & ~1u));
+	u32 *s_ct = (u32*)(s_k + kmax);
+	/* bitmap + exclusive popcount scan (every thread owns a contiguous run of words) */
+	const u32 per = (nw + 1023) / 1024;
+	u32 mine = 0;
+	for (u32 j = 0; j < per; ++j) {
+		const u32 w = tid * per + j;
+		if (w < nw) { const u32 x = img.used[((off + start) >> 5) + w]; s_bm[w] = x; mine += __popc(x); }
+	}
+	u32 incl = mine;
+	for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
+	if (lane == 63) s_wsum[wave] = incl;
+	__syncthreads();
+	u32 base = incl - mine, total = 0;
+	for (u32 w2 = 0; w2 < 16; ++w2) { if (w2 < wave) base += s_wsum[w2]; total += s_wsum[w2]; }
+	const bool fits = total <= kmax;
+	const u32 rsel = rbp ? 32 - rbp : 0;
+	if (!fits) {                                                   /* cannot happen with the host's sizing rule short of a pathological table */
+		if (CROSS) return;
+		for (u64 i = lo + tid; i < hi; i += 1024) {
+			const u64 h = rec[W * i];
+			if (rbp && ((u32)(h >> img.pre) * 2654435769u) >> rsel != r) continue;
+			const int64_t hit = img_find(img, h);
+			if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
+		}
+		return;
+	}
+	{
+		u32 rr = base;
+		for (u32 j = 0; j < per; ++j) {
+			const u32 w = tid * per + j;
+			if (w >= nw) break;
+			s_rk[w] = rr;
+			u32 x = s_bm[w];
+			while (x) { const u32 b = __ffs((int)x) - 1; x &= x - 1; s_k[rr++] = img.keys[off + start + w * 32 + b]; }
+		}
+	}
+	for (u32 i = tid; i < (total + 1) / 2; i += 1024) s_ct[i] = 0;
+	__syncthreads();
+	auto probe = [&](const u64 h) {
+		const u64 kid = h >> img.pre;
+		const u32 first = (((u32)kid * 2654435769u) >> (32 - bits)) - start;
+		u32 s = first;
+		for (;;) {
+			const u32 word = s_bm[s >> 5];
+			if (!(word >> (s & 31) & 1)) break;                          /* khashl get: stop at the first unused slot */
+			const u32 rr = s_rk[s >> 5] + __popc(word & ((1u << (s & 31)) - 1));
+			if (s_k[rr] >> 10 == kid) {
+				if (!CROSS) {
+					const u32 sh = 16 * (rr & 1);
+					if ((s_ct[rr >> 1] >> sh & 0xffffu) < 4096u) atomicAdd(&s_ct[rr >> 1], 1u << sh);   /* only min(count, 1023) matters */
+				}
+				break;
+			}
+			++s;
+			if (rbp == 0) { s &= nmask; if (s == first) break; continue; }   /* the range is the whole table: plain wrap-around */
+			if (s < L) continue;
+			if (!CROSS) {                                                /* the probe leaves the range */
+				const u32 at = atomicAdd(&list_n[0], 1u);
+				if (at < list_cap) list[at] = h; else atomicAdd(&list_n[1], 1u);
+			} else {
+				const u32 home = (start + first) & nmask;
+				for (u32 s2 = (start + L) & nmask; s2 != home; s2 = (s2 + 1) & nmask) {
+					const u64 g = off + s2;
+					if (!(img.used[g >> 5] >> (g & 31) & 1)) break;
+					if (img.keys[g] >> 10 == kid) { atomicAdd(&img.delta[g], 1u); break; }
+				}
+			}
+			break;
+		}
+	};
+	/* OWN_U records per lane are requested together (the stream comes from L2 / HBM: one exposed latency per
+	 * OWN_U records instead of one per record); the records of this range -- one in 2^rbp -- are packed into
+	 * a per-wave LDS queue and probed 64 at a time, so the probe code runs with full waves */
+	u64 *s_q = (u64*)(s_ct + ((kmax + 1) / 2 + 1 & ~1u)) + wave * 128;
+	u32 qn = 0;
+	for (u64 i0 = lo; i0 < hi; i0 += (u64)1024 * OWN_U) {
+		u64 hv[OWN_U];
+#pragma unroll
+		for (int u = 0; u < OWN_U; ++u) { const u64 i = i0 + (u64)u * 1024 + tid; hv[u] = i < hi ? rec[W * i] : 0; }
+#pragma unroll
+		for (int u = 0; u < OWN_U; ++u) {
+			const bool valid = i0 + (u64)u * 1024 + tid < hi;
+			if (rbp == 0) { if (valid) probe(hv[u]); continue; }
+			const bool match = valid && ((u32)(hv[u] >> img.pre) * 2654435769u) >> rsel == r;
+			const u64 mk = __ballot(match);
+			if (match) s_q[qn + __popcll(mk & lanemask_lt())] = hv[u];
+			qn += (u32)__popcll(mk);
+			if (qn >= 64) { qn -= 64; probe(s_q[qn + lane]); }
+		}
+	}
+	if (lane < qn) probe(s_q[lane]);
+	if (CROSS) return;
+	__syncthreads();
+	for (u32 j = 0; j < per; ++j) {
+		const u32 w = tid * per + j;
+		if (w >= nw) break;
+		u32 x = s_bm[w], rr = s_rk[w];
+		while (x) {
+			const u32 b = __ffs((int)x) - 1;
+			x &= x - 1;
+			const u32 c = s_ct[rr >> 1] >> (16 * (rr & 1)) & 0xffffu;
+			if (c) img.delta[off + start + w * 32 + b] += c;             /* exclusive owner: plain read-modify-write */
+			++rr;
+		}
 	}
 }
 
@@ -2805,26 +3225,71 @@ int yk_launch_img_count_rng(const u64 *rec, int cross, const u64 *sbstart, ImgVi
 
 /* tier = LC_G over every sub-bucket of the shard (in_list == NULL), or LC_S over a list */
 void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
-                         u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                         u64 *lastput, u32 *ndist_p, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st)
+                         u32 *bloom32, ImgView img, LcOut O, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st)
 {
 	if (tier == 0) {
 		const unsigned n_sb = (unsigned)(fp.phi - fp.plo) << fp.s2_bits;
 		hipLaunchKernelGGL(k_lds_count<LC_G>, dim3(n_sb), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
-		                   seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, counters, (const u32*)0, ovf_list, (int)YKC_NOVF);
+		                   O, counters, (const u32*)0, ovf_list, (int)YKC_NOVF);
 	} else if (n_list) {
 		hipLaunchKernelGGL(k_lds_count<LC_S>, dim3(n_list), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
-		                   seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, counters, in_list, ovf_list, (int)YKC_NOVF2);
+		                   O, counters, in_list, ovf_list, (int)YKC_NOVF2);
 	}
 }
 
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
-                             u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                             u64 *lastput, u32 *ndist_p, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u32 *bloom32, ImgView img, LcOut O, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st)
 {
 	if (n_ovf) hipLaunchKernelGGL(k_lds_count_ovf, dim3(n_ovf), dim3(256), 0, st, fp, sbstart, rec, bloom32, img,
-	                              seg_base, seg_cur, out_kc, out_T, lastput, ndist_p, ovf_list, scr_off, scr);
+	                              O, ovf_list, scr_off, scr);
+}
+
+size_t yk_count_own_lds(u32 range_len, u32 kmax) { const u32 nw = (range_len + 31) / 32; return (size_t)2 * ((nw + 1) & ~1u) * 4 + (size_t)kmax * 8 + (size_t)((kmax + 1) / 2 + 1 & ~1u) * 4 + 16 * 128 * 8 + 16; }   /* bitmap, ranks, keys, counters, 16 wave queues */
+
+int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
+                            size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st)
+{
+	static bool attr = false;
+	if (!attr) {
+		const void *fn[4] = { (const void*)k_img_count_own<1, 0>, (const void*)k_img_count_own<1, 1>, (const void*)k_img_count_own<2, 0>, (const void*)k_img_count_own<2, 1> };
+		for (int i = 0; i < 4; ++i) if (hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		attr = true;
+	}
+	const int n_p = phi - plo;
+	const dim3 grid((unsigned)((n_p + 7) / 8 * 8) << rb), blk(1024);
+#define YK_OWN(Wv, Cv) hipLaunchKernelGGL((k_img_count_own<Wv, Cv>), grid, blk, lds, st, (const u64*)rec, bstart, img, plo, n_p, rb, rng_log, kmax, list, list_n, list_cap)
+	if (hash_only) { if (cross) YK_OWN(1, 1); else YK_OWN(1, 0); }
+	else { if (cross) YK_OWN(2, 1); else YK_OWN(2, 0); }
+#undef YK_OWN
+	return 0;
+}
+
+int yk_lc2_ok(FastParams fp)
+{
+	const int on = getenv("YAKAMD_LC2") ? atoi(getenv("YAKAMD_LC2")) : 1;          /* 0: the older three-tier kernels (tests) */
+	if (!on || fp.n_hash > 32) return 0;
+	if (fp.bloom_mode) { const int lb = fp.nb - 9 - fp.s2_bits; if (lb < 0 || lb > 7) return 0; }
+	return 1;
+}
+
+void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters, u32 *ovf_list, hipStream_t st)
+{
+	const unsigned n_sb = (unsigned)(fp.phi - fp.plo) << fp.s2_bits;
+	const int wgs = getenv("YAKAMD_LC2_WGS") ? atoi(getenv("YAKAMD_LC2_WGS")) : 256 * 5;   /* 5 workgroups of 32 KB LDS per CU */
+	const unsigned grid = n_sb < (unsigned)wgs ? n_sb : (unsigned)wgs;
+	if (grid) hipLaunchKernelGGL(k_lc2, dim3(grid), dim3(256), 0, st, fp, sbstart, rec, bloom32, img, O, counters, ovf_list, n_sb);
+}
+
+void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_lc_sum, dim3(phi - plo), dim3(256), 0, st, nsel, s2_bits, plo, seg_cnt);
+}
+
+void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
+                          u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_lc_compact, dim3(phi - plo), dim3(256), 0, st, O, sbstart, s2_bits, plo, t_pass0, seg_base, out_kc, out_T, lastput, ndist_p);
 }
 
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,

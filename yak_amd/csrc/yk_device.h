@@ -156,6 +156,11 @@ struct FastParams {
 	u64 t_pass0;
 };
 
+/* outputs of the exclusive-ownership counting kernels: the keys a sub-bucket adds to its sub-table go to the
+ * front of the sub-bucket's own record range in kc / T (fragments, gathered by k_lc_compact); per sub-bucket
+ * their number, the time (relative to the slice, + 1; 0 = none) of its last put-call, its distinct k-mers */
+struct LcOut { u64 *kc, *T; u32 *nsel, *lp, *nd; };
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -168,12 +173,18 @@ int yk_launch_img_count_rng(const u64 *rec, int cross, const u64 *sbstart, ImgVi
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
                      u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
 void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
-                         u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                         u64 *lastput, u32 *ndist_p, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st);
+                         u32 *bloom32, ImgView img, LcOut O, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st);
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
-                             u32 *bloom32, ImgView img, const u64 *seg_base, u32 *seg_cur, u64 *out_kc, u64 *out_T,
-                             u64 *lastput, u32 *ndist_p, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
+                             u32 *bloom32, ImgView img, LcOut O, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st);
+size_t yk_count_own_lds(u32 range_len, u32 kmax);
+int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
+                            size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
+int yk_lc2_ok(FastParams fp);
+void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters, u32 *ovf_list, hipStream_t st);
+void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st);
+void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
+                          u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
 #ifdef __cplusplus
