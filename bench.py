@@ -193,8 +193,10 @@ def main():
     # The logical input of the whole job is cut into chunks of `batch_reads` reads, dealt round-robin to the
     # ranks: chunk c = b * world + r is batch b of rank r.  A single rank therefore sees the same stream as N
     # ranks do (N-GPU bytes == 1-GPU bytes), and every rank is busy in every round however long the input.
-    batch_reads = a.reads if world == 1 else min(a.reads, a.batch_reads)
-    n_batches = -(-a.reads // batch_reads)
+    n_batches = 1 if world == 1 else -(-a.reads // max(1, min(a.reads, a.batch_reads)))
+    while a.reads % n_batches:                      # equal chunks, so that the chunks of all ranks tile the job's reads without gaps
+        n_batches += 1
+    batch_reads = a.reads // n_batches
     rec_len = READ_LEN + 1
     B = batch_reads * rec_len                       # bytes (= stream positions) of a full chunk
     d_reads = torch.empty(a.reads * rec_len, dtype=torch.uint8, device=dev)
@@ -391,12 +393,58 @@ def main():
         ms_q = (time.perf_counter() - tq) / 3 * 1e3
         n_q = int((d_t16 != -1).sum().item())
         present = int((d_t16 > 0).sum().item())
-        # algorithmic bytes per looked-up k-mer: 1 (base) + 2 (result) + 8 (table slot)
+        # lookup = 8 algorithmic bytes per k-mer instance (+ the input, reported separately)
         qv_probe = {"kernel": "k_lookup", "kmers_looked_up": n_q, "present": present, "ms": ms_q, "lookups_per_s": n_q / (ms_q * 1e-3),
-                    "achieved_GBs": 11.0 * n_q / (ms_q * 1e-3) / 1e9, "frac_of_hbm_peak": 11.0 * n_q / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "achieved_GBs": 8.0 * n_q / (ms_q * 1e-3) / 1e9, "frac_of_hbm_peak": 8.0 * n_q / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_instance": 8.0,
                     "note": "bound by random 64-byte-granule HBM reads: the 1 GB table image exceeds the 256 MB Infinity Cache, ~50 G such reads/s measured"}
         t_q.close()
         del d_t16
+
+    # the rate with the base image handed over from HOST memory in both passes (yakamd_feed_bases_host, what
+    # yak_count() does after parsing) and the whole `yak-amd count` command on the same reads as a FASTQ file
+    # (process start, parsing, PCIe, counting, writing the .yak) -- side figures, never `value`
+    pcie_ms = e2e = None
+    if not a.no_pcie and not sharded:
+        def host_protocol():
+            t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
+            for create_new in ((1, 0) if a.bf_shift > 0 else (1,)):
+                if L.yakamd_pass_begin(t.h, create_new) != 0 or L.yakamd_feed_bases_host(t.h, h_reads.data_ptr(), n_bytes, 0) != 0:
+                    raise RuntimeError(yak_amd._err())
+                n_ins = L.yakamd_pass_end(t.h)
+                t.h.contents.tot += n_ins
+                if create_new and a.bf_shift > 0:
+                    t.destroy_bf(); t.clear()
+            if a.bf_shift > 0:
+                t.shrink(2, 1023)
+            torch.cuda.synchronize()
+            tot_ = t.tot
+            t.close()
+            return tot_
+        host_protocol()
+        tq = time.perf_counter()
+        for _ in range(2):
+            tot_h = host_protocol()
+        pcie_ms = (time.perf_counter() - tq) / 2 * 1e3
+        if tot_h != tot:
+            raise SystemExit("FAILED: host-fed run counted a different table")
+        cli = os.path.join(ROOT, "yak_amd", "yak-amd")
+        if os.path.exists(cli) and a.reads <= 12_000_000:
+            tmp = tempfile.mkdtemp(prefix="yke", dir=os.environ.get("YAKAMD_TMP", None))
+            try:
+                fq = os.path.join(tmp, "r.fq")
+                subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(a.reads), "-l", str(READ_LEN), "-g", str(genome), "-s", "42",
+                                       "-t", str(min(threads, 32)), "-o", fq])
+                cmd = [cli, "count", f"-k{K}", f"-t{min(threads, 32)}", "-o", os.path.join(tmp, "o.yak")] + ([f"-b{a.bf_shift}"] if a.bf_shift else []) + [fq]
+                subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)        # file into the page cache, HIP start-up files touched
+                tq = time.perf_counter()
+                subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+                e2e = {"ms": (time.perf_counter() - tq) * 1e3, "command": " ".join(os.path.basename(x) if os.sep in x else x for x in cmd),
+                       "fastq_bytes": os.path.getsize(fq), "yak_md5": hashlib.md5(open(os.path.join(tmp, "o.yak"), "rb").read()).hexdigest()}
+                if verify and e2e["yak_md5"] != verify["yak_md5"]:
+                    raise SystemExit("FAILED: the CLI's .yak differs from the device-resident run's")
+            finally:
+                subprocess.call(["rm", "-rf", tmp])
 
     if rank != 0:
         dist.destroy_process_group()
@@ -447,6 +495,15 @@ def main():
         key = k_["kernel"].split(" ")[0]
         cand = [v for n_, v in pmc.items() if n_.startswith(key) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 else []
         k_["traffic_bytes"] = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
+    # the pass and the step as a whole against the same roof: SURVEY 8(d)'s algorithmic bytes of every instance
+    # the pass consumed / its wall-clock time (pass 1 with and without the exact-layout tail: sort + replay)
+    bloom_on = a.bf_shift > PRE and s2 is not None
+    b_pass1 = (16.0 + 128.0 + 16.0 * f_ins) * n1 if bloom_on else 32.0 * n1
+    b_pass2 = (16.0 + 8.0 + 8.0 * f_hit) * n2
+    w = wall_timed
+    ms_p1 = w.get("pass1", 0.0)
+    ms_p1_core = s1["ms_extract"] + s1["ms_insert"]
+    frac = lambda by, ms: by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
     dom = max(kern, key=lambda x: x["ms"])
     name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
     bpi, st = dom["bytes"] / max(1, n1), s1
@@ -479,10 +536,17 @@ def main():
                               "no-bloom share of 24 B/instance",
                      "achieved_no_bloom_model": (dom["bytes_no_bloom_model"] / (dom["ms"] * 1e-3) / 1e9) if dom.get("bytes_no_bloom_model") else None,
                      "f_ins": f_ins, "f_hit": f_hit,
+                     "pass1_frac": frac(b_pass1, ms_p1), "pass1_extract_insert_frac": frac(b_pass1, ms_p1_core),
+                     "pass2_frac": frac(b_pass2, w.get("pass2", 0.0)) if s2 else None,
+                     "step_frac": frac(b_pass1 + b_pass2, ms_step if world == 1 else 0.0),
+                     "pass_bytes": {"pass1": b_pass1, "pass2": b_pass2, "per_instance_pass1": b_pass1 / max(1, n1), "per_instance_pass2": (b_pass2 / n2) if n2 else None},
+                     "pass_ms": {"pass1": ms_p1, "pass1_extract_insert": ms_p1_core, "pass2": w.get("pass2"), "step": ms_step},
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
         "verify": verify,
         "job_yak_md5": job_md5,
         "qv_lookup_probe": qv_probe,
+        "pcie_inclusive_ms": pcie_ms, "pcie_inclusive_value": (tot_all / (pcie_ms * 1e-3)) if pcie_ms else None,
+        "e2e_cli": e2e,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }
     if not a.no_cpu_baseline and world == 1:                      # rank 0 at N = 1 only

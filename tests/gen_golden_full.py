@@ -15,7 +15,55 @@ SYN = os.path.join(ROOT, "tools", "yaksynth")
 N, L, G, SEED, K, BF = 10_000_000, 150, 50_000_000, 42, 31, 37
 
 
+def md5_file(fn):
+    h = hashlib.md5()
+    with open(fn, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def cfg45(tmp):
+    """goldens for bench.py --config cfg4 / cfg5 -> tests/golden/cfg45_full.json (reference binary, build container)"""
+    dst = os.path.join(ROOT, "tests", "golden", "cfg45_full.json")
+    res = json.load(open(dst)) if os.path.exists(dst) else {}
+    for nc, cl in ((4, 50_000_000), (10, 100_000_000)):        # 0.2 Gb (quick) and 1 Gb (the largest the 62 GB container takes comfortably)
+        name = f"cfg4_{nc}x{cl}"
+        if name in res:
+            continue
+        fa, out = os.path.join(tmp, f"asm{nc}.fa"), os.path.join(tmp, "asm.yak")
+        subprocess.check_call([SYN, "-T", "-n", str(nc), "-l", str(cl), "-s", "42", "-w", "60", "-t", "8", "-o", fa])
+        subprocess.run([REF, "count", "-k21", "-t8", "-o", out, fa], check=True, stderr=subprocess.DEVNULL)
+        res[name] = {"workload": f"yak count -k21 on yaksynth -T -n {nc} -l {cl} -s 42 -w 60 (FASTA, 60 columns)", "contigs": nc, "contig_len": cl, "k": 21,
+                     "md5": md5_file(out), "size": os.path.getsize(out), "produced_by": "oracle/_ref/yak (the reference, compiled from /root/reference), -t8"}
+        print(name, res[name]); os.remove(fa); os.remove(out)
+        json.dump(res, open(dst, "w"), indent=1)
+    # cfg5: yak qv -p of the reference: table = its own cfg2 .yak, queries = 20 kb reads (e = 0.2 %) of the same genome
+    for reads, nq in ((10_000_000, 75_000),):
+        name = f"cfg5_{reads}_{nq}"
+        if name in res:
+            continue
+        fq, tab, qa = os.path.join(tmp, "r.fq"), os.path.join(tmp, "cfg2.yak"), os.path.join(tmp, "q.fa")
+        if not os.path.exists(fq):
+            subprocess.check_call([SYN, "-n", str(reads), "-l", str(L), "-g", str(5 * reads), "-s", str(SEED), "-t", "8", "-o", fq])
+        subprocess.run([REF, "count", f"-k{K}", f"-b{BF}", "-t8", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+        subprocess.check_call([SYN, "-a", "-n", str(nq), "-l", "20000", "-g", str(5 * reads), "-s", str(SEED), "-e", "0.002", "-N", "0", "-t", "8", "-o", qa])
+        o = subprocess.run([REF, "qv", "-p", "-K3.2g", "-t8", tab, qa], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        ct = {int(f[1]): int(f[3]) for f in (l.split("\t") for l in o.splitlines()) if f[0] == "CT"}
+        lines = "\n".join(f"{c}\t{v}" for c, v in sorted(ct.items()) if v)
+        tail = [l for l in o.splitlines() if l[:2] in ("FR", "ER", "CV", "QV")]
+        res[name] = {"workload": f"yak qv -p -K3.2g: table = yak count -k{K} -b{BF} of yaksynth -n {reads} -g {5 * reads} -s {SEED}; queries = yaksynth -a -n {nq} -l 20000 -e 0.002 -N 0",
+                     "table_md5": md5_file(tab), "ct_md5": hashlib.md5(lines.encode()).hexdigest(), "kmers": sum(ct.values()), "summary_lines": tail,
+                     "n_sq": sum(1 for l in o.splitlines() if l.startswith("SQ")), "produced_by": "oracle/_ref/yak qv (the reference)"}
+        print(name, res[name])
+        json.dump(res, open(dst, "w"), indent=1)
+
+
 def main():
+    if "--cfg45" in sys.argv:
+        tmp = next((a for a in sys.argv[1:] if not a.startswith("--")), "/tmp/cfg45")
+        os.makedirs(tmp, exist_ok=True)
+        return cfg45(tmp)
     tmp = next((a for a in sys.argv[1:] if not a.startswith("--")), "/tmp/cfg2")
     os.makedirs(tmp, exist_ok=True)
     fq, out = os.path.join(tmp, "r.fq"), os.path.join(tmp, "ref.yak")

@@ -168,7 +168,7 @@ struct yakamd_ctx {
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
-	bool in_pass; int create_new; bool bloom_mode; bool gate_off; bool or_mode;   /* gate_off: puts of a merge never consult the filter */
+	bool in_pass; int create_new; bool bloom_mode; bool gate_off; int or_mode;   /* gate_off: puts of a merge never consult the filter */
 	AccTab acc; u64 acc_count;
 	u64 *d_counters, *d_lastput, *d_lpbatch;
 	u32 *d_missing, *d_nmissing;
@@ -184,6 +184,9 @@ struct yakamd_ctx {
 	u64 t_end;
 	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
 	yakamd_stats_t st_cur, st_last;
+
+	std::mutex api_mu;                 /* serialises whole-table entry points that callers may reach from several threads (yak_ch_insert_list) */
+	void *d_scratch; size_t scratch_bytes;
 
 	/* host mirror */
 	bool host_valid;
@@ -247,10 +250,10 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
 	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
 	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false;
-	c->in_pass = false; c->gate_off = false; c->or_mode = false; c->acc.s = 0; c->acc_count = 0;
+	c->in_pass = false; c->gate_off = false; c->or_mode = 0; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
-	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0;
+	c->d_stage = 0; c->stage_cap = 0; c->t_end = 0; c->list_t = 0; c->d_scratch = 0; c->scratch_bytes = 0;
 	c->d_rows = 0; c->d_partial = 0; c->d_bstart = 0; c->rows_blk = 0;
 	c->nb_bits = (int)std::min<int64_t>(pre, env_i64("YAKAMD_PART_BITS", 13));
 	if (c->nb_bits < 3) c->nb_bits = 3;
@@ -300,6 +303,7 @@ void yk_ctx_destroy(yakamd_ctx *c)
 	hipSetDevice(c->dev);
 	pass_free(c);
 	dfree(c->d_stage); dfree(c->d_rows); dfree(c->d_partial); dfree(c->d_bstart);
+	{ uint8_t *q = (uint8_t*)c->d_scratch; dfree(q); c->d_scratch = 0; }
 	dfree(c->d_bits); dfree(c->d_used); dfree(c->d_delta); dfree(c->d_off); dfree(c->d_keys);
 	dfree(c->d_bf); dfree(c->d_multi);
 	dfree(c->d_counters); dfree(c->d_lastput); dfree(c->d_lpbatch); dfree(c->d_missing); dfree(c->d_nmissing);
@@ -739,13 +743,14 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
 	const int hash_only = !c->create_new;                  /* counting existing keys needs no stream positions */
 	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
-	if (rec_reserve(c, bmax) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;
+	if ((!c->fast && rec_reserve(c, bmax)) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;   /* the fast path keeps every batch in a buffer of its own */
 	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
 		const int64_t end = std::min(n_bytes, pos + batch);
 		u64 n_rec = 0;
 		Rec *out = c->d_rec;
 		if (c->fast) {                                   /* the batch stays resident until pass_end */
 			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &out)) return -1;
+			if (!c->fast) { if (rec_reserve(c, bmax)) return -1; out = c->d_rec; }   /* the pass has just left the fast path */
 		}
 		{
 			EvTimer tm(c->st);
@@ -1438,7 +1443,7 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 }
 void yk_pool_release(void *p) { if (p) pool_free(p); }
 void yk_ctx_gate(yakamd_ctx *c, bool on) { c->gate_off = !on; }
-void yk_ctx_or_mode(yakamd_ctx *c, bool on) { c->or_mode = on; }
+void yk_ctx_or_mode(yakamd_ctx *c, int mode) { c->or_mode = mode; }
 
 /* khashl resize(want[p]) on every sub-table (htab.c:441 on an existing table): same size re-places in place */
 int yk_ctx_resize_to(yakamd_ctx *c, const uint32_t *want)
@@ -1522,6 +1527,38 @@ extern "C" int yakamd_subtable(yak_ch_t *h, int i, uint32_t *capacity, uint32_t 
 }
 
 u64 yk_ctx_list_time(yakamd_ctx *c, u64 n) { const u64 t = c->list_t; c->list_t += n; return t; }
+void yk_ctx_lock(yakamd_ctx *c) { c->api_mu.lock(); }
+void yk_ctx_unlock(yakamd_ctx *c) { c->api_mu.unlock(); }
+
+/* a device buffer of at least `bytes` that lives as long as the context (small repeated calls: yak_ch_insert_list) */
+void *yk_ctx_scratch(yakamd_ctx *c, size_t bytes)
+{
+	if (bytes <= c->scratch_bytes) return c->d_scratch;
+	if (hipSetDevice(c->dev) != hipSuccess) return 0;
+	uint8_t *q = (uint8_t*)c->d_scratch;
+	dfree(q);
+	c->d_scratch = 0; c->scratch_bytes = 0;
+	const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+	if (dmalloc(&q, want)) return 0;
+	c->d_scratch = q; c->scratch_bytes = want;
+	return q;
+}
+
+/* reference htab.c:80-91: saturating ++ of one stored k-mer; -1 if absent.  One single-lane kernel; a valid host
+ * mirror is patched in place instead of being refreshed */
+int yk_ctx_inc(yakamd_ctx *c, u64 hash, int *count)
+{
+	if (c->in_pass) return fail("yak_ch_inc during an open pass");
+	HIPCK(hipSetDevice(c->dev));
+	u64 out[2];
+	yk_launch_img_inc(img_view(c), hash, c->d_counters, c->st);
+	HIPCK(hipMemcpyAsync(out, c->d_counters, 16, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (out[0] == ~0ull) { *count = -1; return 0; }
+	*count = (int)out[1];
+	if (c->host_valid && c->hm_keys) c->hm_keys[out[0]] = (c->hm_keys[out[0]] & ~1023ull) | out[1];
+	return 0;
+}
 int yk_ctx_device(yakamd_ctx *c) { return c->dev; }
 hipStream_t yk_ctx_stream(yakamd_ctx *c) { return c->st; }
 const yak_ht_t *yk_ctx_ht(yakamd_ctx *c, int p) { return c->hts ? &c->hts[p] : 0; }

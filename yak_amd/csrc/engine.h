@@ -19,7 +19,11 @@ int  yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other);
 int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n);
 void yk_pool_release(void *p);
 void yk_ctx_gate(yakamd_ctx *c, bool on);
-void yk_ctx_or_mode(yakamd_ctx *c, bool on);
+void yk_ctx_or_mode(yakamd_ctx *c, int mode);   /* 0 counting; 1 flag loads; 2 saved-count loads (yk_device.h FastParams.or_mode) */
+void yk_ctx_lock(yakamd_ctx *c);
+void yk_ctx_unlock(yakamd_ctx *c);
+void *yk_ctx_scratch(yakamd_ctx *c, size_t bytes);
+int  yk_ctx_inc(yakamd_ctx *c, u64 hash, int *count);
 int  yk_ctx_resize_to(yakamd_ctx *c, const uint32_t *want);
 u64  yk_ctx_keys_total(yakamd_ctx *c);
 int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys);

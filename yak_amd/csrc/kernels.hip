@@ -843,6 +843,16 @@ void k_img_count_h(const u64 *__restrict__ hash, int64_t n, ImgView img)
 	}
 }
 
+/* reference htab.c:80-91 (yak_ch_inc): one key, saturating ++; out[0] = arena slot or ~0, out[1] = new count */
+__global__ void k_img_inc(ImgView img, u64 hash, u64 *out)
+{
+	const int64_t a = img_find(img, hash);
+	if (a < 0) { out[0] = ~0ull; out[1] = 0; return; }
+	u64 kc = img.keys[a];
+	if ((kc & 1023) < 1023) img.keys[a] = ++kc;
+	out[0] = (u64)a; out[1] = kc & 1023;
+}
+
 __global__ __launch_bounds__(256)
 void k_img_fold(ImgView img, u64 n_slots)                    /* htab.c:68-69,73-74: saturate at 1023 */
 {
@@ -2183,7 +2193,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 			const int64_t idx = img_find(img, T.K[s]);
 			if (idx >= 0) {
 				const u64 kc = img.keys[idx], c = (kc & 1023) + (T.CN[s] & LC_CMASK);
-				img.keys[idx] = fp.or_mode ? kc | (T.T1[s] & 15u) : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+				img.keys[idx] = fp.or_mode == 1 ? kc | (T.T1[s] & 15u) : fp.or_mode == 2 ? kc : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
 				T.CN[s] |= LC_EXIST;
 			}
 		}
@@ -2302,7 +2312,7 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 		else if (T.T2[s] != T32_INF) { *Tt = T.T2[s]; c -= 1; }
 		else return false;
 		if (c > 1023) c = 1023;
-		if (fp.or_mode) c = T.T1[s] & 15u;                        /* a key seen once per load: its flag travels in the time's low bits */
+		if (fp.or_mode) c = T.T1[s] & (fp.or_mode == 1 ? 15u : 1023u);   /* a key seen once per load: its flag / saved count travels in the time's low bits */
 		*kc = (T.K[s] >> fp.pre) << 10 | c;
 		return true;
 	};
@@ -2415,7 +2425,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 
 	auto home = [&](u64 key) -> u32 {
 		const u64 x = key >> fp.pre;
-		return ((u32)(x & lmask) << rsh) | (u32)((x * 0x9E3779B97F4A7C15ull) >> (64 - rsh));
+		return ((u32)(x & lmask) << rsh) | ((u32)((x * 0x9E3779B97F4A7C15ull) >> 24) & (R - 1));   /* middle bits: the top ones name the sub-bucket when there is no filter (sub_of) */
 	};
 	u32 tmax = 0;
 	auto put = [&](const Rec rc) {
@@ -2469,7 +2479,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 					const int64_t idx = img_find(img, s_K[s]);
 					if (idx >= 0) {
 						const u64 kc = img.keys[idx], c = (kc & 1023) + (cn_get(s) & LC2_CMASK);
-						img.keys[idx] = fp.or_mode ? kc | (s_T1[s] & 15u) : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
+						img.keys[idx] = fp.or_mode == 1 ? kc | (s_T1[s] & 15u) : fp.or_mode == 2 ? kc : (kc & ~1023ull) | (c > 1023 ? 1023 : c);
 						atomicOr(&s_CN[s >> 1], LC2_EXIST << (16 * (s & 1)));
 					}
 				}
@@ -2552,7 +2562,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 				else if (s_T2[s] != T32_INF) { Tt = s_T2[s]; c -= 1; }
 				else continue;
 				if (c > 1023) c = 1023;
-				if (fp.or_mode) c = s_T1[s] & 15u;                            /* a key seen once per load: its flag travels in the time's low bits */
+				if (fp.or_mode) c = s_T1[s] & (fp.or_mode == 1 ? 15u : 1023u);       /* a key seen once per load: its flag / saved count travels in the time's low bits */
 				const u32 r = atomicAdd(s_run, 1u);
 				O.kc[lo + r] = (kx >> fp.pre) << 10 | c; O.T[lo + r] = fp.t_pass0 + Tt;
 			}
@@ -3057,6 +3067,8 @@ void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t 
 	if (n <= 0) return;
 	hipLaunchKernelGGL(k_img_count_h, dim3(grid_for((u64)n)), dim3(256), 0, st, hash, n, img);
 }
+
+void yk_launch_img_inc(ImgView img, u64 hash, u64 *out2, hipStream_t st) { hipLaunchKernelGGL(k_img_inc, dim3(1), dim3(1), 0, st, img, hash, out2); }
 
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st)
 {

@@ -151,19 +151,26 @@ int yak_ch_insert_list(yak_ch_t *h, int create_new, int n, const uint64_t *a)
 	hv.reserve(n); tv.reserve(n);
 	for (int j = 0; j < n; ++j)
 		if ((a[j] & pm) == (a[0] & pm)) { hv.push_back(a[j]); tv.push_back((uint32_t)j); }   /* htab.c:61 */
-	uint64_t *d_h = 0; uint32_t *d_t = 0;
-	hipSetDevice(yk_ctx_device(e->ctx));
-	if (hipMalloc((void**)&d_h, hv.size() * 8) != hipSuccess || hipMalloc((void**)&d_t, hv.size() * 4) != hipSuccess) return 0;
-	hipMemcpy(d_h, hv.data(), hv.size() * 8, hipMemcpyHostToDevice);
-	hipMemcpy(d_t, tv.data(), tv.size() * 4, hipMemcpyHostToDevice);
-	int64_t n_ins = 0;
-	const uint64_t t0 = yk_ctx_list_time(e->ctx, (uint64_t)n);
-	if (yakamd_pass_begin(h, create_new) == 0) {
-		yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)hv.size(), t0, (uint64_t)n);
-		n_ins = yakamd_pass_end(h);
+	/* the reference's callers run this from kt_for workers, one sub-table each (count.c:129-143); here a call
+	 * is a whole-table device pass, so concurrent callers take turns.  Failures are reported, never silent. */
+	struct Lock { yakamd_ctx *c; Lock(yakamd_ctx *c_) : c(c_) { yk_ctx_lock(c); } ~Lock() { yk_ctx_unlock(c); } } lock(e->ctx);
+	const size_t nb = hv.size() * 8, need = ((nb + 15) & ~(size_t)15) + hv.size() * 4;
+	uint8_t *d = (uint8_t*)yk_ctx_scratch(e->ctx, need);
+	int64_t n_ins = -1;
+	bool ok = d != 0 && hipSetDevice(yk_ctx_device(e->ctx)) == hipSuccess;
+	uint64_t *d_h = (uint64_t*)d; uint32_t *d_t = (uint32_t*)(d + ((nb + 15) & ~(size_t)15));
+	ok = ok && hipMemcpy(d_h, hv.data(), nb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_t, tv.data(), tv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) {
+		const uint64_t t0 = yk_ctx_list_time(e->ctx, (uint64_t)n);
+		ok = yakamd_pass_begin(h, create_new) == 0;
+		if (ok) {
+			ok = yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)hv.size(), t0, (uint64_t)n) == 0;
+			n_ins = yakamd_pass_end(h);                          /* closes the pass whatever the feed did */
+			ok = ok && n_ins >= 0;
+		}
 	}
-	hipFree(d_h); hipFree(d_t);
-	return n_ins < 0 ? 0 : (int)n_ins;
+	if (!ok) { fprintf(stderr, "[E::%s] %s\n", __func__, *yakamd_last_error() ? yakamd_last_error() : "device buffer allocation or copy failed"); return -1; }
+	return (int)n_ins;
 }
 
 static inline uint32_t ht_cap(const yak_ht_t *g) { return g->keys ? 1U << g->bits : 0U; }
@@ -191,10 +198,9 @@ int yak_ch_get(const yak_ch_t *h, uint64_t x)                /* reference htab.c
 
 int yak_ch_inc(yak_ch_t *h, uint64_t x)                      /* reference htab.c:80-91 */
 {
-	const int c = yak_ch_get(h, x);
-	if (c < 0) return -1;
-	yak_ch_insert_list(h, 0, 1, &x);                         /* one-element device pass keeps HBM authoritative */
-	return c < YAK_MAX_COUNT ? c + 1 : c;
+	int c = -1;                                              /* one single-lane kernel on the table image; a valid host mirror is patched in place */
+	if (yk_ctx_inc(((yak_ch_ext*)h)->ctx, x, &c) != 0) { fprintf(stderr, "[E::%s] %s\n", __func__, yakamd_last_error()); return -1; }
+	return c;
 }
 
 void yak_ch_clear(yak_ch_t *h, int n_thread)                 /* reference htab.c:127-130 */
@@ -368,6 +374,9 @@ static bool read_yak(const char *fn, uint32_t hdr[3], std::vector<uint32_t> &cap
 	for (int p = 0; p < P; ++p) {
 		uint32_t u[2];
 		if (fread(u, 4, 2, fp) != 2) break;
+		/* a capacity is 0 or a power of two <= 2^31 (khashl.h:155-158), and it holds its keys at <= 75 % load after the
+		 * resize-before-put rule: anything else is a corrupt file */
+		if (u[0] > (1u << 31) || (u[0] & (u[0] - 1)) != 0 || u[1] > u[0]) { fprintf(stderr, "ERROR: corrupt sub-table header in '%s' (capacity %u, size %u)\n", fn, u[0], u[1]); fclose(fp); return false; }
 		caps[p] = u[0]; sizes[p] = u[1];
 		const size_t at = keys.size();
 		keys.resize(at + u[1]);
@@ -394,51 +403,71 @@ yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...)
 	std::vector<uint32_t> caps, sizes;
 	std::vector<uint64_t> keys;
 	if (!read_yak(fn, hdr, caps, sizes, keys)) return 0;
-	if (mode == YAK_LOAD_ALL) {
-		if (ch0) { fprintf(stderr, "[E::%s] YAK_LOAD_ALL into an existing table is not supported\n", __func__); return 0; }
+	if (mode == YAK_LOAD_ALL && ch0 == 0) {
 		yak_ch_t *h = yak_ch_init((int)hdr[0], (int)hdr[1], 0, 0);
 		if (h == 0) return 0;
 		if (yk_ctx_load(((yak_ch_ext*)h)->ctx, caps.data(), sizes.data(), keys.data()) != 0) { yak_ch_destroy(h); return 0; }
 		fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", __func__, (long)keys.size(), (long)keys.size());
 		return h;
 	}
+	/* every other case puts the selected keys, in file order, into a table that may already hold some of them
+	 * (htab.c:441-470): a flag mode ORs a flag into keys already present, YAK_LOAD_ALL leaves them alone, and a
+	 * new key keeps the flag / its saved count.  That is a counting pass whose records carry the payload in the low
+	 * bits of their list position (4 bits for a flag, 10 for a count), run in as many passes as the 32-bit
+	 * position field needs: a pass meets the keys of the earlier ones as existing state, exactly as the
+	 * reference's sequential puts do. */
 	yak_ch_t *h = ch0 ? ch0 : yak_ch_init((int)hdr[0], (int)hdr[1], 0, 0);
 	if (h == 0) return 0;
 	assert((int)hdr[0] == h->k && (int)hdr[1] == h->pre);       /* htab.c:437 */
 	yakamd_ctx *c = ((yak_ch_ext*)h)->ctx;
 	const int P = 1 << h->pre;
 	const uint64_t mask = (1ULL << YAK_COUNTER_BITS) - 1;
+	const int pbits = mode == YAK_LOAD_ALL ? YAK_COUNTER_BITS : 4;
+	size_t per_pass = ((size_t)1 << (32 - pbits)) - 16;
+	if (getenv("YAKAMD_LOAD_SLICE")) per_pass = std::min<size_t>(per_pass, std::max<long long>(1, atoll(getenv("YAKAMD_LOAD_SLICE"))));   /* tests */
 	std::vector<uint64_t> hashes;
 	std::vector<uint32_t> times;
+	long n_tot = 0, n_new = 0;
+	bool ok = yk_ctx_resize_to(c, caps.data()) == 0;             /* htab.c:441 */
+	void *d_h = 0, *d_t = 0;
+	auto flush = [&]() {
+		const size_t n = hashes.size();
+		if (n == 0 || !ok) return;
+		if (!d_h) { d_h = yakamd_dev_alloc(std::min(per_pass, keys.size()) * 8); d_t = yakamd_dev_alloc(std::min(per_pass, keys.size()) * 4); }
+		ok = d_h && d_t && yakamd_memcpy_h2d(d_h, hashes.data(), n * 8) == 0 && yakamd_memcpy_h2d(d_t, times.data(), n * 4) == 0;
+		if (ok) {
+			yk_ctx_gate(c, false); yk_ctx_or_mode(c, mode == YAK_LOAD_ALL ? 2 : 1);
+			ok = yakamd_pass_begin(h, 1) == 0;
+			if (ok) {
+				ok = yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)n, 0, (uint64_t)n << pbits) == 0;
+				const int64_t r = yakamd_pass_end(h);
+				ok = ok && r >= 0;
+				if (ok) n_new += (long)r;
+			}
+			yk_ctx_gate(c, true); yk_ctx_or_mode(c, 0);
+		}
+		n_tot += (long)n;
+		hashes.clear(); times.clear();
+	};
 	size_t at = 0;
-	for (int p = 0; p < P; ++p)
-		for (uint32_t j = 0; j < sizes[p]; ++j, ++at) {
+	for (int p = 0; p < P && ok; ++p)
+		for (uint32_t j = 0; j < sizes[p] && ok; ++j, ++at) {
 			const uint64_t key = keys[at];
 			int x;
-			if (mode == YAK_LOAD_TRIOBIN1 || mode == YAK_LOAD_TRIOBIN2) {
+			if (mode == YAK_LOAD_ALL) x = (int)(key & mask);
+			else if (mode == YAK_LOAD_TRIOBIN1 || mode == YAK_LOAD_TRIOBIN2) {
 				const int cnt = (int)(key & mask), shift = mode == YAK_LOAD_TRIOBIN1 ? 0 : 2;
 				x = cnt >= mid_cnt ? 2 << shift : cnt >= min_cnt ? 1 << shift : -1;
 			} else x = 1 << (mode - YAK_LOAD_SEXCHR1);
 			if (x < 0) continue;
 			hashes.push_back((key >> YAK_COUNTER_BITS) << h->pre | (uint64_t)p);
-			times.push_back((uint32_t)(hashes.size() - 1) << 4 | (uint32_t)x);
+			times.push_back((uint32_t)(hashes.size() - 1) << pbits | (uint32_t)x);
+			if (hashes.size() >= per_pass) flush();
 		}
-	const size_t n = hashes.size();
-	bool ok = n < ((size_t)1 << 28) && yk_ctx_resize_to(c, caps.data()) == 0;     /* htab.c:441 */
-	long n_new = 0;
-	if (ok && n) {
-		void *d_h = yakamd_dev_alloc(n * 8), *d_t = yakamd_dev_alloc(n * 4);
-		ok = d_h && d_t && yakamd_memcpy_h2d(d_h, hashes.data(), n * 8) == 0 && yakamd_memcpy_h2d(d_t, times.data(), n * 4) == 0;
-		if (ok) {
-			yk_ctx_gate(c, false); yk_ctx_or_mode(c, true);
-			ok = yakamd_pass_begin(h, 1) == 0 && yakamd_feed_hashed_dev(h, d_h, d_t, (int64_t)n, 0, (uint64_t)n << 4) == 0;
-			if (ok) { const int64_t r = yakamd_pass_end(h); ok = r >= 0; n_new = (long)r; }
-			yk_ctx_gate(c, true); yk_ctx_or_mode(c, false);
-		}
-		yakamd_dev_free(d_h); yakamd_dev_free(d_t);
-	}
-	if (!ok) { fprintf(stderr, "[E::%s] %s\n", __func__, n < ((size_t)1 << 28) ? yakamd_last_error() : "more than 2^28 k-mers in one file"); if (!ch0) yak_ch_destroy(h); return 0; }
-	fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", __func__, (long)n, n_new);
+	flush();
+	yakamd_dev_free(d_h); yakamd_dev_free(d_t);
+	if (!ok) { fprintf(stderr, "[E::%s] %s\n", __func__, yakamd_last_error()); if (!ch0) yak_ch_destroy(h); return 0; }
+	fprintf(stderr, "[M::%s] inserted %ld k-mers, of which %ld are new\n", __func__, n_tot, n_new);
 	return h;
 }
 

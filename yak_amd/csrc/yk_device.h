@@ -92,6 +92,7 @@ void yk_launch_qv_reduce(const unsigned short *t, const u64 *roff, const u32 *rl
                          u32 *tot_out, u32 *non0_out, u64 *hist, hipStream_t st);
 int yk_launch_img_count_lds(const void *rec, int hash_only, const u64 *bstart, ImgView img, int plo, int phi, size_t lds, u64 *compact, u32 stride, hipStream_t st);
 void yk_launch_img_count_h(const u64 *hash, int64_t n, ImgView img, hipStream_t st);
+void yk_launch_img_inc(ImgView img, u64 hash, u64 *out2, hipStream_t st);
 void yk_launch_img_fold(ImgView img, u64 n_slots, hipStream_t st);
 void yk_launch_img_hist(ImgView img, u64 n_slots, u64 *hist, hipStream_t st);
 void yk_launch_img_setcnt(ImgView img, u64 n_slots, u32 cnt, hipStream_t st);
@@ -152,7 +153,7 @@ struct FastParams {
 	int img_nonempty;
 	int plo, phi;
 	int dbg, bf_virgin;             /* dbg: timing ablations only (YAKAMD_DBG); bf_virgin: filter never written (all zero) */
-	int or_mode;                    /* flag-set loads (htab.c:449-470): the low 4 bits of a record's time are a flag, ORed into the key's low bits instead of counting */
+	int or_mode;                    /* loads from a .yak file (htab.c:436-470) instead of counting: 1 = the low 4 bits of a record's time are a flag, ORed into the key's low bits; 2 = the low 10 bits are the saved count, kept by new keys only */
 	u64 t_pass0;
 };
 
