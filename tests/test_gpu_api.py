@@ -58,6 +58,43 @@ def test_insert_list_sequences(bf, ya, oracle):
     t.close(); O.yko_ch_destroy(o)
 
 
+def test_inc_and_concurrent_insert_lists(ya, oracle):
+    """yak_ch_inc (htab.c:80-91) as a single-slot device update that keeps a valid host mirror coherent, and
+    yak_ch_insert_list called from several threads at once (the reference's kt_for workers call it
+    concurrently, one sub-table each, count.c:129-143): calls take turns, nothing is dropped"""
+    import threading
+    L, O = ya.lib(), oracle.lib()
+    t = ya.Table(31, 10, 0, 0)
+    o = O.yko_ch_init(31, 10, 0, 0)
+    lists = _lists(oracle, 5, 24, 200)
+    res = [None] * len(lists)
+
+    def work(j0):
+        for i in range(j0, len(lists), 4):
+            arr = (C.c_uint64 * len(lists[i]))(*lists[i])
+            res[i] = L.yak_ch_insert_list(t.h, 1, len(lists[i]), arr)
+    th = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert all(r is not None and r >= 0 for r in res)
+    # the final multiset of (key, count) does not depend on the order in which the lists were taken
+    for a in lists:
+        O.yko_ch_insert_list(o, 1, len(a), (C.c_uint64 * len(a))(*a))
+    keys = sorted({x for a in lists for x in a})
+    assert [L.yak_ch_get(t.h, x) for x in keys] == [O.yko_ch_get(o, x) for x in keys]
+    assert sum(res) == len(keys)
+    O.yko_ch_inc.restype = C.c_int; O.yko_ch_inc.argtypes = [C.POINTER(oracle.Ch), C.c_uint64]
+    for x in keys[:50] + [keys[0]] * 5 + [(12345 << 10) | 3]:
+        assert L.yak_ch_inc(t.h, x) == O.yko_ch_inc(o, x)
+        assert L.yak_ch_get(t.h, x) == O.yko_ch_get(o, x)      # the mirror was patched, not refreshed
+    h1 = (C.c_int64 * 1024)(); h2 = (C.c_int64 * 1024)()
+    L.yak_ch_hist(t.h, h1, 1); O.yko_ch_hist.argtypes = [C.POINTER(oracle.Ch), C.POINTER(C.c_int64)]; O.yko_ch_hist(o, h2)
+    assert list(h1) == list(h2)                                # ... and the device image holds the increments
+    t.close(); O.yko_ch_destroy(o)
+
+
 def test_clear_shrink_restore_hist(ya, oracle, synth, tmp_path):
     L, O = ya.lib(), oracle.lib()
     img = synth(3000, g=15000, s=4)
@@ -321,8 +358,8 @@ def test_subtract_and_isec_protocols_equal_reference_cli(cmd, ya, oracle, synth,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family", ["triobin", "sexchr"])
-def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_path):
+@pytest.mark.parametrize("family", ["triobin", "sexchr", "triobin_sliced", "sexchr_sliced", "load_all_into_existing", "load_all_into_existing_sliced"])
+def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_path, monkeypatch):
     """yak_ch_restore_core modes 2-6 (htab.c:396-476): flag sets of several .yak files ORed into one
     table -- the loads of `yak triobin` (main.c) and `yak sexchr`; bytes against the oracle (itself pinned
     on the reference's library, tests/test_oracle_vs_ref.py)"""
@@ -336,7 +373,10 @@ def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_pa
     fc = str(tmp_path / "t2.yak")
     assert O.yko_ch_dump(hc, fc.encode()) == 0
     O.yko_ch_destroy(hc)
-    steps = [(2, fa), (3, fb)] if family == "triobin" else [(4, fa), (5, fb), (6, fc)]
+    if family.endswith("_sliced"):                           # several passes per file, as files with >= 2^28 (2^22) selected k-mers need
+        monkeypatch.setenv("YAKAMD_LOAD_SLICE", "777")
+    # YAK_LOAD_ALL into a table that already holds keys (htab.c:436-448): present keys stay as they are, new ones keep their saved count
+    steps = [(2, fa), (3, fb)] if family.startswith("triobin") else [(4, fa), (5, fb), (6, fc)] if family.startswith("sexchr") else [(1, fa), (1, fb), (1, fc), (1, fa)]
     h, ho = None, None
     for mode, fn in steps:
         h = L.yak_ch_restore_core(h, fn.encode(), C.c_int(mode), C.c_int(2), C.c_int(5))

@@ -125,12 +125,25 @@ static void *pool_alloc(size_t bytes)
 static void pool_free(void *p)
 {
 	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
-	DevPool &P = pool_here();
+	static const size_t cap = (size_t)env_i64("YAKAMD_POOL_MAX_GB", 96) << 30;   /* idle bytes kept per device; beyond that the largest blocks go back to the driver */
+	/* the block's owner is the pool that handed it out, whatever device is current now */
+	DevPool *Pp = &pool_here();
+	{
+		bool mine;
+		{ std::lock_guard<std::mutex> lk(Pp->mu); mine = Pp->size_of.count(p) != 0; }
+		for (int d = 0; d < 16 && !mine; ++d) { std::lock_guard<std::mutex> lk(g_pool[d].mu); if (g_pool[d].size_of.count(p)) { Pp = &g_pool[d]; mine = true; } }
+	}
+	DevPool &P = *Pp;
 	std::lock_guard<std::mutex> lk(P.mu);
 	auto it = P.size_of.find(p);
 	if (!on || it == P.size_of.end()) { if (it != P.size_of.end()) P.size_of.erase(it); (void)hipFree(p); return; }
 	P.idle.insert({ it->second, p });
 	P.cached += it->second;
+	while (P.cached > cap && !P.idle.empty()) {
+		auto big = std::prev(P.idle.end());
+		P.cached -= big->first; P.size_of.erase(big->second); (void)hipFree(big->second);
+		P.idle.erase(big);
+	}
 }
 
 size_t yk_pool_cached_bytes(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); return P.cached; }
@@ -524,6 +537,7 @@ static int count_by_ranges(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart)
 	}
 	chunk_first[P] = (u32)chunks.size();
 	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_ln = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_h2 = 0, *d_list = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_chunks); dfree(d_cf); dfree(d_bbase); dfree(d_rows2); dfree(d_sbstart); dfree(d_h2); dfree(d_list); dfree(d_ln); } };
 	const u32 list_cap = (u32)std::min<int64_t>(env_i64("YAKAMD_XLIST_CAP", 1 << 22), 1 << 22);   /* the knob is for tests */
 	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, (chunks.size() + 1) * S2) ||
 	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_h2, (size_t)n_rec) || dmalloc(&d_list, (size_t)1 << 22) || dmalloc(&d_ln, 2)) return -1;
@@ -545,7 +559,6 @@ static int count_by_ranges(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart)
 		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] range count: 2^%d ranges per sub-table, %u boundary-crossing instances%s\n", rb, xn[0], xn[1] ? " (list overflow: second sweep)" : "");
 		HIPCK(hipStreamSynchronize(c->st));
 	}
-	dfree(d_chunks); dfree(d_cf); dfree(d_bbase); dfree(d_rows2); dfree(d_sbstart); dfree(d_h2); dfree(d_list); dfree(d_ln);
 	return r;
 }
 
@@ -977,6 +990,9 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	(void)d_seg_off;
 	u64 *nk = 0, *sp = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0;
 	ReplayTask *d_tasks = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {   /* nk / nu / nd are handed to the context on success (set to 0 there) */
+		dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc); dfree(nk); dfree(nu); dfree(nd);
+	} };
 	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
 	if ((par && dmalloc(&sp, 2 * tot)) || dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) || dmalloc(&nd, tot) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
@@ -1004,9 +1020,9 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc);
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
 	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
+	nk = 0; nu = 0; nd = 0;
 	c->h_off = new_off;
 	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
@@ -1184,10 +1200,19 @@ static int fast_finish(yakamd_ctx *c)
 	return 0;
 }
 
+static int64_t pass_end_body(yakamd_ctx *c);
+
 extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("no pass open");
+	const int64_t r = pass_end_body(c);
+	if (r < 0) pass_free(c);                                 /* a failed pass is closed too: the table stays usable (the pass's k-mers are lost, the error is reported) */
+	return r;
+}
+
+static int64_t pass_end_body(yakamd_ctx *c)
+{
 	HIPCK(hipSetDevice(c->dev));
 	const int P = c->P;
 	int64_t n_ins = 0;
@@ -1210,6 +1235,7 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 		std::vector<u32> m(P, 0);
 		std::vector<u64> seg_off(P + 1, 0);
 		u32 *d_segcnt = 0, *d_segcur = 0; u64 *d_segoff = 0, *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
+		struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segcnt); dfree(d_segcur); dfree(d_segoff); dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); } };
 		if (dmalloc(&d_segcnt, P) || dmalloc(&d_segcur, P) || dmalloc(&d_segoff, P + 1)) return -1;
 		HIPCK(hipMemsetAsync(d_segcnt, 0, P * 4, c->st));
 		HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
@@ -1246,8 +1272,6 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 			if (run_replay(c, m, d_segoff, kc[cur], tt[cur], c->d_lastput, 0, false)) return -1;
 			c->st_cur.ms_replay += tm.stop();
 		}
-		dfree(d_segcnt); dfree(d_segcur); dfree(d_segoff);
-		dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]);
 		n_ins = (int64_t)(c->img_keys_total - before);
 		c->st_cur.n_distinct_seen = (int64_t)c->acc_count;
 		c->st_cur.n_new_keys = n_ins;
@@ -1321,6 +1345,7 @@ static int rebuild(yakamd_ctx *c, int cmin, int cmax, int which, yakamd_ctx *oth
 	std::vector<u32> m(P), init(P);
 	std::vector<u64> seg_off(P + 1, 0);
 	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segcnt); dfree(d_segoff); dfree(d_kc); } };
 	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
 	yk_launch_shrink_count(img_view(c), P, cmin, cmax, which, ov, d_segcnt, c->st);
 	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
@@ -1332,7 +1357,6 @@ static int rebuild(yakamd_ctx *c, int cmin, int cmax, int which, yakamd_ctx *oth
 	EvTimer tm(c->st);
 	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
 	c->st_last.ms_shrink = tm.stop();
-	dfree(d_segcnt); dfree(d_segoff); dfree(d_kc);
 	if (r) return r;
 	*tot = c->img_keys_total;
 	return 0;
@@ -1426,19 +1450,21 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 	std::vector<u32> m(P);
 	std::vector<u64> seg_off(P + 1, 0);
 	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
+	*d_hash = 0; *d_t = 0;
+	bool done = false;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segcnt); dfree(d_segoff); dfree(d_kc); if (!done) { dfree(*d_hash); dfree(*d_t); } } };
 	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
 	yk_launch_shrink_count(img_view(c), P, cmin, cmax, 0, img_view(c), d_segcnt, c->st);
 	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	for (int p = 0; p < P; ++p) seg_off[p + 1] = seg_off[p] + m[p];
 	*n = seg_off[P];
-	*d_hash = 0; *d_t = 0;
 	if (dmalloc(&d_kc, seg_off[P]) || dmalloc(d_hash, seg_off[P]) || dmalloc(d_t, seg_off[P])) return -1;
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, 0, img_view(c), d_segoff, d_kc, c->st);
 	yk_launch_keys_to_hashes(d_kc, d_segoff, P, c->pre, *d_hash, *d_t, c->st);
 	HIPCK(hipStreamSynchronize(c->st));
-	dfree(d_segcnt); dfree(d_segoff); dfree(d_kc);
+	done = true;
 	return 0;
 }
 void yk_pool_release(void *p) { if (p) pool_free(p); }
