@@ -88,8 +88,8 @@ def run_cfg4(a, torch, yak_amd):
                   "yak_size_bytes": 16 + 8 * (1 << PRE) + 8 * t.tot, "distinct": t.tot}
         g = _gold(f"cfg4_{a.contigs}x{a.contig_len}")
         if g:                                                  # the reference's own .yak for this very input (tests/gen_golden_full.py --cfg4)
-            md5 = hashlib.md5(t.dump_bytes()).hexdigest()
-            verify.update(yak_md5=md5, reference_md5=g["md5"], equals_reference=md5 == g["md5"])
+            md5, nbytes = t.dump_md5()
+            verify.update(yak_md5=md5, reference_md5=g["md5"], equals_reference=md5 == g["md5"] and nbytes == g["size"])
             if md5 != g["md5"]:
                 raise SystemExit("FAILED: .yak differs from the reference's")
         t.close()

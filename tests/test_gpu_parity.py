@@ -246,6 +246,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_OWN_LDS="19500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_LC2="0"), dict(YAKAMD_LC2="0", YAKAMD_S2_BITS="4"),
                                  dict(YAKAMD_LC2_WGS="3"),
+                                 dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
@@ -253,7 +254,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
                               "count_with_device_atomics", "count_lds_rank_kernel",
                               "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
-                              "lc2_three_persistent_workgroups", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
+                              "lc2_three_persistent_workgroups",
+                              "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""
@@ -288,9 +290,11 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
+                                 dict(YAKAMD_R2_SMALL_BITS="10", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_R2_SMALL_BITS="9", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_OWN_LDS="30000", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64"), dict(YAKAMD_REPLAY_LDS="32768"),
                                  dict(YAKAMD_REPLAY_LDS="2048"), dict(YAKAMD_REPLAY_LDS="1024", YAKAMD_REPLAY_THREADS="256"), dict(YAKAMD_REPLAY_LDS="2048", YAKAMD_DBG="256")],
                          ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow",
+                              "streaming_replay_2k_slot_segments", "streaming_replay_from_512_slots_1k_slot_segments", "k_replay_for_16k_slots",
                               "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "lds_keys_for_small_stages",
                               "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
 def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
@@ -300,10 +304,17 @@ def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch)
     img = synth(50000, g=8_000_000, s=77, e=0.0, N=0.0)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    dbg0 = (C.c_uint32 * 4)(); dbg1 = (C.c_uint32 * 4)()
+    ya.lib().yakamd_debug_counters(dbg0)
     for opt in (dict(k=31), dict(k=27, bf_shift=30)):
         got, tot = ya.count_protocol_host(img, **opt)
         want, wtot = oracle.count_protocol_mem(img, **opt)
         assert (got == want, tot) == (True, wtot), opt
+    ya.lib().yakamd_debug_counters(dbg1)
+    if env.get("YAKAMD_REPLAY2") == "0":
+        assert dbg1[2] == dbg0[2]
+    elif "YAKAMD_R2_SMALL_BITS" in env:                       # 8 Ki-slot sub-tables: the streaming replay did them, and never handed one back
+        assert dbg1[2] > dbg0[2] and dbg1[3] == dbg0[3], list(dbg1)
 
 
 @pytest.mark.parametrize("seed", range(32))
@@ -323,6 +334,7 @@ def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
     for key, vals in (("YAKAMD_BATCH", [None, None, "4096", "65536", "1048576"]), ("YAKAMD_S2_BITS", [None, None, None, "0", "2", "5", "9"]),
                       ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096", "32768"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
                       ("YAKAMD_COUNT_OWN", [None, None, "0"]), ("YAKAMD_OWN_LDS", [None, None, "18500", "24000"]), ("YAKAMD_OWN_MAXRB", [None, "12"]), ("YAKAMD_LC2", [None, None, None, "0"]),
+                      ("YAKAMD_R2_SMALL_BITS", [None, "5", "6", "8"]), ("YAKAMD_R2_SEG_LOG", [None, "10", "11", "12"]), ("YAKAMD_REPLAY2", [None, None, None, "0"]),
                       ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_XP_WC", [None, None, "0", "1", "2"]), ("YAKAMD_FAST", [None, None, None, "0"])):
         v = rnd.choice(vals)
         if v is not None:

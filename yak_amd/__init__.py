@@ -212,9 +212,25 @@ class Table:
         n = self.L.yakamd_dump_mem(self.h, C.byref(out))
         if n < 0:
             raise RuntimeError(_err())
-        data = C.string_at(out, n)
+        addr = C.cast(out, C.c_void_p).value
+        data = bytes((C.c_char * n).from_address(addr))          # C.string_at takes a C int: .yak files pass 2 GB
         C.CDLL(None).free(out)
         return data
+
+    def dump_md5(self):
+        """md5 of the .yak bytes without a second copy of them (multi-GB tables)"""
+        import hashlib
+        out = C.POINTER(C.c_uint8)()
+        n = self.L.yakamd_dump_mem(self.h, C.byref(out))
+        if n < 0:
+            raise RuntimeError(_err())
+        addr = C.cast(out, C.c_void_p).value
+        h = hashlib.md5()
+        step = 1 << 28
+        for o in range(0, n, step):
+            h.update((C.c_char * min(step, n - o)).from_address(addr + o))
+        C.CDLL(None).free(out)
+        return h.hexdigest(), n
 
     def subtable(self, i):
         cap, size = C.c_uint32(), C.c_uint32()

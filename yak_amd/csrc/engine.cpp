@@ -965,9 +965,271 @@ static u32 plan_cap(u32 cap, u32 cnt, u32 m, bool may_trail)
 }
 
 /* rebuild the image from per-sub-table ordered record lists.  rec_t/lastput may be NULL (shrink) */
+/* launch parameters of k_replay for a set of tasks (shared by the two replay drivers) */
+static void legacy_replay_launch(yakamd_ctx *c, const std::vector<ReplayTask> &tasks, const ReplayTask *d_tasks, u64 *nk, u32 *nu, u32 *su, u32 *so, u64 *sp,
+                                 const u64 *d_rec_kc, const u64 *d_rec_t, const u64 *d_lastput, u32 *d_ob, u32 *d_oc)
+{
+	const int P = c->P, n_active = c->phi - c->plo;
+	u32 cap_top = 0;
+	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
+	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 16384));   /* 64 KB: two workgroups per CU (measured 18.5 ms against 20.5 with 128 KB); 0: owner ranks in global scratch */
+	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
+	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
+	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
+	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, lds_words, c->st);
+}
+
+/* Layout replay with the large sub-tables on the streaming kernels (kernels.hip "replay2").  A sub-table whose
+ * final capacity stays within 2^SB slots is replayed by k_replay as before.  A larger one is brought to 2^SB slots
+ * by k_replay (everything in LDS there), then all of them advance together, step by step: a placement of the next
+ * keys up to the growth threshold, or a doubling.  The schedule is khashl's (khashl.h:202: grow BEFORE the put once
+ * count >= 0.75 capacity; a trailing put-call on an existing key can still double) and is simulated here on the
+ * host; the kernels only move keys.  Returns 0 done, -1 error, 1 not applicable / refused (caller: k_replay). */
+static u32 g_r2_used = 0, g_r2_refused = 0;        /* debug counters: replays done by the streaming kernels / handed back to k_replay */
+
+static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_rec_kc, const u64 *d_rec_t,
+                         const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty, const std::vector<u64> *rec_off_in)
+{
+	const int P = c->P;
+	if (env_i64("YAKAMD_REPLAY2", 1) == 0 || P > 65536) return 1;
+	const u32 SB = (u32)std::min<int64_t>(20, std::max<int64_t>(5, env_i64("YAKAMD_R2_SMALL_BITS", 13))), SMALLCAP = 1u << SB;
+	std::vector<ReplayTask> tasks(P);
+	std::vector<u64> rec_off(P), new_off(P);
+	std::vector<u32> cap0(P), cnt0(P), capm(P);
+	std::vector<char> large(P, 0);
+	u64 rec = 0, tot = 0;
+	bool any = false;
+	for (int p = 0; p < P; ++p) {
+		const u32 ob = from_empty ? YK_NOCAP : c->h_bits[p], ib = init_bits ? (*init_bits)[p] : YK_NOCAP;
+		cnt0[p] = from_empty ? 0 : c->h_count[p];
+		cap0[p] = ob == YK_NOCAP ? 0 : 1u << ob;
+		if (cap0[p] == 0 && ib != YK_NOCAP) cap0[p] = 1u << ib;
+		rec_off[p] = rec_off_in ? (*rec_off_in)[p] : rec; rec += m[p];
+		capm[p] = plan_cap(cap0[p], cnt0[p], m[p], d_lastput != 0);
+		large[p] = capm[p] > SMALLCAP;
+		any = any || large[p];
+		new_off[p] = tot; tot += std::max<u64>(32, capm[p]);
+	}
+	if (!any) return 1;
+	/* trailing put-calls (device data: last put-call and the time of the last new key per sub-table) */
+	std::vector<u32> trail(P, 0);
+	std::vector<u64> lp_host(P, 0);
+	u32 *d_m = 0, *d_trail = 0; u64 *d_ro = 0, *d_lp2 = 0;
+	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
+	ReplayTask *d_tasks = 0; R2Tab *d_tabs = 0; R2Act *d_acts = 0; R2Load *d_ld = 0; R2Pub *d_pub = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
+		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so); dfree(nd);
+		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
+	} };
+	if (d_lastput) {
+		if (dmalloc(&d_m, P) || dmalloc(&d_trail, P) || dmalloc(&d_ro, P) || dmalloc(&d_lp2, P)) return -1;
+		HIPCK(hipMemcpyAsync(d_m, m.data(), P * 4, hipMemcpyHostToDevice, c->st));
+		HIPCK(hipMemcpyAsync(d_ro, rec_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
+		yk_r2_trail(d_lastput, d_rec_t, d_ro, d_m, P, d_trail, c->st);
+		HIPCK(hipMemcpyAsync(trail.data(), d_trail, P * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipMemcpyAsync(lp_host.data(), d_lastput, P * 8, hipMemcpyDeviceToHost, c->st));
+		HIPCK(hipStreamSynchronize(c->st));
+	}
+	/* the schedule of every large sub-table: keys placed by k_replay first (m1), then its actions */
+	struct Act { u32 kind, bits, i0, batch; };
+	std::vector<std::vector<Act> > sched(P);
+	std::vector<u32> m1(P, 0), bitsS(P, YK_NOCAP), cntS(P, 0), bitsF(P, YK_NOCAP), cntF(P, 0);
+	size_t n_steps = 0;
+	u32 n_large = 0;
+	for (int p = 0; p < P; ++p) {
+		if (!large[p]) continue;
+		++n_large;
+		u64 cap = cap0[p], cnt = cnt0[p], rem = m[p];
+		while (rem > 0 && cap0[p] <= SMALLCAP) {                   /* the part k_replay does: up to a full table of SMALLCAP slots */
+			const u64 thr = (cap >> 1) + (cap >> 2);
+			if (cnt >= thr) { if (cap >= SMALLCAP) break; cap = cap ? cap << 1 : 4; continue; }
+			const u64 b = std::min(rem, thr - cnt);
+			cnt += b; rem -= b;
+		}
+		m1[p] = (u32)(m[p] - rem);
+		bitsS[p] = cap ? (u32)ceil_log2_u64(cap) : YK_NOCAP; cntS[p] = (u32)cnt;
+		if (cap == 0) { large[p] = 0; --n_large; continue; }       /* cannot happen: a large sub-table has keys or a table */
+		for (;;) {
+			const u64 thr = (cap >> 1) + (cap >> 2);
+			if (rem > 0) {
+				if (cnt >= thr) { sched[p].push_back({ 2u, (u32)ceil_log2_u64(cap), 0u, 0u }); cap <<= 1; continue; }
+				const u64 b = std::min(rem, thr - cnt);
+				sched[p].push_back({ 1u, (u32)ceil_log2_u64(cap), (u32)(m[p] - rem), (u32)b });
+				cnt += b; rem -= b;
+			} else {
+				if (trail[p] && cnt >= thr) { sched[p].push_back({ 2u, (u32)ceil_log2_u64(cap), 0u, 0u }); cap <<= 1; }
+				break;
+			}
+		}
+		bitsF[p] = (u32)ceil_log2_u64(cap); cntF[p] = (u32)cnt;
+		if ((1ull << bitsF[p]) > capm[p]) return fail("replay schedule exceeds the planned capacity");
+		n_steps = std::max(n_steps, sched[p].size());
+	}
+	if (n_large == 0) return 1;
+	for (int p = 0; p < P; ++p) if (large[p] && (int)bitsF[p] - yk_r2_seg_log() > 10) return 1;   /* more than 1024 segments per sub-table: not handled */
+	/* k_replay: the small sub-tables into the final arena, the first part of the large ones into a side arena behind it */
+	const u64 tot_ext = tot + (u64)n_large * std::max<u64>(32, SMALLCAP);
+	{
+		u64 side = tot;
+		for (int p = 0; p < P; ++p) {
+			ReplayTask &t = tasks[p];
+			t.old_bits = from_empty ? YK_NOCAP : c->h_bits[p];
+			t.old_count = cnt0[p]; t.old_off = c->h_off[p];
+			t.rec_off = rec_off[p]; t.m = m[p];
+			t.init_bits = init_bits ? (*init_bits)[p] : YK_NOCAP;
+			t.cap_max_bits = capm[p] ? (u32)ceil_log2_u64(capm[p]) : 0;
+			t.dbg = (u32)env_i64("YAKAMD_DBG", 0);
+			t.new_off = new_off[p];
+			if (large[p]) {
+				t.new_off = side; side += std::max<u64>(32, SMALLCAP);
+				lp_host[p] = 0;                                       /* the trailing put-call is the schedule's business */
+				if (cap0[p] > SMALLCAP) { t.old_bits = YK_NOCAP; t.old_count = 0; t.m = 0; t.init_bits = YK_NOCAP; t.cap_max_bits = 0; }   /* already beyond: loaded straight from the old image */
+				else { t.m = m1[p]; t.cap_max_bits = SB; }
+			}
+		}
+	}
+	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
+	if ((par && dmalloc(&sp, 2 * tot_ext)) || dmalloc(&nk, tot_ext) || dmalloc(&nu, tot_ext / 32 + 1) || dmalloc(&su, tot_ext / 32 + 1) || dmalloc(&so, tot_ext) || dmalloc(&nd, tot) ||
+	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
+	HIPCK(hipMemsetAsync(nk, 0xff, tot_ext * 8, c->st));
+	HIPCK(hipMemsetAsync(nu, 0, (tot_ext / 32 + 1) * 4, c->st));
+	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
+	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
+	if (d_lastput) HIPCK(hipMemcpyAsync(d_lp2, lp_host.data(), P * 8, hipMemcpyHostToDevice, c->st));
+	legacy_replay_launch(c, tasks, d_tasks, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput ? d_lp2 : 0, d_ob, d_oc);
+	std::vector<u32> ob(P), oc(P);
+	HIPCK(hipMemcpyAsync(ob.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipMemcpyAsync(oc.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	dfree(sp); dfree(su); dfree(so);
+	/* buffers of the large sub-tables */
+	std::vector<R2Tab> tabs(P);
+	std::vector<u32> seg0(P, 0);
+	const int SEGLOG = yk_r2_seg_log();
+	u64 tot2 = 0, nseg_tot = 0; u32 bmaxF = 0, bmaxS = 0;
+	for (int p = 0; p < P; ++p) {
+		tabs[p].off = tot2; tabs[p].rec_off = rec_off[p];
+		if (!large[p]) continue;
+		if (cap0[p] <= SMALLCAP && (ob[p] != bitsS[p] || oc[p] != cntS[p])) return fail("replay: sub-table %d left k_replay with 2^%u slots / %u keys, the schedule says 2^%u / %u", p, ob[p], oc[p], bitsS[p], cntS[p]);
+		tot2 += 1ull << bitsF[p];
+		seg0[p] = (u32)nseg_tot;
+		nseg_tot += (bitsF[p] > (u32)SEGLOG ? 1ull << (bitsF[p] - SEGLOG) : 1) + 1;
+		bmaxF = std::max(bmaxF, bitsF[p]); bmaxS = std::max(bmaxS, bitsS[p]);
+	}
+	std::vector<R2Act> acts(std::max<size_t>(1, n_steps) * P);
+	memset(acts.data(), 0, acts.size() * sizeof(R2Act));
+	std::vector<R2Load> ld(P); std::vector<R2Pub> pub(P);
+	u64 side = tot;
+	for (int p = 0; p < P; ++p) {
+		ld[p].bits = YK_NOCAP; ld[p].src_off = 0; ld[p].from_src = 0; ld[p].dst = 0; ld[p].pad = 0;
+		pub[p].bits = YK_NOCAP; pub[p].new_off = new_off[p]; pub[p].src = 0;
+		if (!large[p]) continue;
+		ld[p].bits = bitsS[p];
+		if (cap0[p] > SMALLCAP) { const bool old = !from_empty && c->h_bits[p] != YK_NOCAP; ld[p].from_src = old ? 2 : 0; ld[p].src_off = old ? c->h_off[p] : 0; }
+		else { ld[p].from_src = 1; ld[p].src_off = side; }
+		side += std::max<u64>(32, SMALLCAP);
+		u32 src = 0;
+		for (size_t k = 0; k < sched[p].size(); ++k) {
+			R2Act &a = acts[k * P + p];
+			a.kind = sched[p][k].kind; a.bits = sched[p][k].bits; a.i0 = sched[p][k].i0; a.batch = sched[p][k].batch; a.src = src; a.seg0 = seg0[p];
+			if (a.kind == 2) src ^= 1;
+		}
+		pub[p].bits = bitsF[p]; pub[p].src = src;
+	}
+	const u32 spill_cap = (u32)std::min<u64>(1u << 28, std::max<u64>(1u << 20, tot2 / 16));   /* also the list of long runs of a doubling round */
+	u64 n_keys = 0;
+	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
+	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
+	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 2 * (size_t)P) || dmalloc(&misc, 4)) return -1;
+	HIPCK(hipMemcpyAsync(d_tabs, tabs.data(), P * sizeof(R2Tab), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_acts, acts.data(), acts.size() * sizeof(R2Act), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_ld, ld.data(), P * sizeof(R2Load), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemsetAsync(misc, 0, 16, c->st));
+	u32 *d_fail = misc, *d_nspill = misc + 1;
+	yk_r2_load(d_tabs, d_ld, P, bmaxS, nk, c->d_keys, K0, K1, c->st);
+	const bool prof = env_i64("YAKAMD_VERBOSE", 0) > 1;
+	auto lap = [&](const char *what, size_t k, u32 bits, double *t0) {
+		if (!prof) return;
+		hipStreamSynchronize(c->st);
+		const double t1 = now_ms();
+		fprintf(stderr, "[yak_amd] replay2 step %zu (2^%u): %s %.3f ms\n", k, bits, what, t1 - *t0);
+		*t0 = t1;
+	};
+	double tl = now_ms();
+	lap("k_replay part + load", 0, bmaxS, &tl);
+	for (size_t k = 0; k < n_steps; ++k) {
+		u32 bd = 0, bp = 0; bool any_d = false, any_p = false;
+		for (int p = 0; p < P; ++p) {
+			const R2Act &a = acts[k * P + p];
+			if (a.kind == 2) { any_d = true; bd = std::max(bd, a.bits); }
+			else if (a.kind == 1) { any_p = true; bp = std::max(bp, a.bits); }
+		}
+		const R2Act *da = d_acts + k * P;
+		if (any_d) {
+			yk_r2_dinit(d_tabs, da, P, bd, K0, K1, TAG, OCC, c->st);
+			lap("dinit", k, bd, &tl);
+			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, d_fail, c->st);
+			lap("dsmall", k, bd, &tl);
+			const u64 n = 1ull << bd, SF = (u64)yk_r2_small_f();
+			int cur = 0;
+			for (u64 reach = SF; reach < 2 * n; reach <<= 1) {       /* F at least doubles... it cannot: G <= 2F; so one round per factor of two, plus slack for short rounds */
+				const u64 span = std::min<u64>(n, 2 * reach);
+				yk_r2_dround(d_tabs, da, P, (u32)span, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, d_fail, spill, misc + 2, spill_cap, c->st);
+				cur ^= 1;
+			}
+			/* rounds can be shorter than a factor of two (the boundary is the last unused slot before 2F): finish whatever is left */
+			for (int extra = 0; extra < 2; ++extra) {
+				yk_r2_dround(d_tabs, da, P, (u32)n, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, d_fail, spill, misc + 2, spill_cap, c->st);
+				cur ^= 1;
+			}
+			lap("drounds", k, bd, &tl);
+			/* every doubling sub-table must have reached its end */
+			std::vector<u32> Fh(P);
+			HIPCK(hipMemcpyAsync(Fh.data(), Fc + cur * P, P * 4, hipMemcpyDeviceToHost, c->st));
+			HIPCK(hipStreamSynchronize(c->st));
+			for (int p = 0; p < P; ++p) if (acts[k * P + p].kind == 2 && Fh[p] < (1u << acts[k * P + p].bits)) {   /* did not converge: the caller replays with k_replay */
+				if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] streaming replay: doubling of sub-table %d (2^%u slots) stopped at slot %u (step %zu, %s): falling back to k_replay\n", p, acts[k * P + p].bits, Fh[p], k, hipGetErrorString(hipGetLastError()));
+				++g_r2_refused; return 1;
+			}
+		}
+		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, c->st); lap("place", k, bp, &tl); }
+	}
+	yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, nk, nu, c->st);
+	lap("publish", n_steps, bmaxF, &tl);
+	u32 h_fail = 0;
+	HIPCK(hipMemcpyAsync(&h_fail, d_fail, 4, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	if (h_fail) {
+		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] streaming replay refused (code %u): falling back to k_replay\n", h_fail);
+		++g_r2_refused;
+		return 1;
+	}
+	++g_r2_used;
+	for (int p = 0; p < P; ++p) {
+		if (large[p]) { c->h_bits[p] = bitsF[p]; c->h_count[p] = cntF[p]; }
+		else { c->h_bits[p] = ob[p]; c->h_count[p] = oc[p]; }
+	}
+	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
+	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
+	nk = 0; nu = 0; nd = 0;
+	c->h_off = new_off;
+	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	c->img_keys_total = 0;
+	for (int p = 0; p < P; ++p) c->img_keys_total += c->h_count[p];
+	c->host_valid = false;
+	return 0;
+}
+
 static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg_off, const u64 *d_rec_kc, const u64 *d_rec_t,
                       const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty, const std::vector<u64> *rec_off = 0)
 {
+	{
+		const int r2 = run_replay_v2(c, m, d_rec_kc, d_rec_t, d_lastput, init_bits, from_empty, rec_off);
+		if (r2 <= 0) return r2;
+	}
 	const int P = c->P;
 	std::vector<ReplayTask> tasks(P);
 	std::vector<u64> new_off(P);
@@ -1284,8 +1546,9 @@ static int64_t pass_end_body(yakamd_ctx *c)
 
 extern "C" void yakamd_debug_counters(uint32_t *out4)
 {
-	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	out4[0] = out4[1] = 0;
 	yk_par_counters(&out4[0], &out4[1]);
+	out4[2] = g_r2_used; out4[3] = g_r2_refused;
 }
 
 extern "C" void *yakamd_dev_alloc(size_t bytes) { void *p = 0; return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : 0; }

@@ -12,6 +12,7 @@
  * All work is 64-bit integer arithmetic; the bound is HBM / L2-atomic traffic, never MFMA.
  */
 #include "yk_device.h"
+#include <algorithm>
 
 #define WAVE 64
 
@@ -1891,6 +1892,576 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 	if (tid == 0) { out_bits[blockIdx.x] = n ? bits : YK_NOCAP; out_count[blockIdx.x] = cnt; }
 }
 
+/* ==========================================================================================
+ * K5 for LARGE sub-tables ("replay2").  k_replay gives one sub-table to one workgroup and walks global
+ * arrays with random accesses and device atomics; that is fine up to a few thousand slots (everything in
+ * LDS) and hopeless at a million (measured 2.7 s for 1024 x 2 Mi slots).  Two facts about khashl make
+ * both steps of the replay LOCAL, streaming and free of global atomics:
+ *
+ * DOUBLING (khashl.h:171-189, n -> 2n slots).  A maximal run of used old slots (e, e') -- slots e and e'
+ * unused -- holds keys whose old home lies inside the run, so their new homes lie in [2e + 2, 2e' - 1], and
+ * for every h the run has at most e' - h keys with new home >= 2h: the run's keys end up inside the new
+ * region [2e + 2, 2e' + 1] whatever the order, and no key of another run ever enters it.  Runs interact
+ * only through the ORDER of re-insertion: the key at old slot s is kicked out early iff a key lands on
+ * physical slot s before the scan reaches s.  Its processing time is therefore
+ *     sigma(s) = (c, d + 1) if the final occupant x of new slot s has sigma(x) = (c, d) with c < s
+ *                (s, 0)     otherwise,
+ * and the final content of a region is first-come-first-served linear probing of its run's keys in sigma
+ * order.  New slot s < 2F belongs to the region of a run below F (when slot F - 1 is unused), so once all
+ * runs below F are placed, every run inside [F, 2F) can be placed at once, one lane per run, with plain
+ * loads and stores on its own region; `tag` keeps sigma of the occupant of every new slot < n.  The first
+ * few slots are done by the literal rule by one lane (chains followed while they stay in that prefix).
+ *
+ * PLACEMENT of the new keys of a stage (first come first served in rank order, khashl.h:197-221) is
+ * ordered probing with the smallest rank winning a slot (order-free), done per segment of R2_SEG slots
+ * with the ranks in LDS; the keys of the stage are first grouped by the segment of their home slot.  A walk
+ * that leaves its segment is finished afterwards on the first R2_HEAD slots of the next segment, whose
+ * ranks are kept in a global array for that purpose (device atomics, but only for these few walks).
+ *
+ * All sub-tables advance together, one kernel per step; the table of a sub-table alternates between two
+ * buffers.  Anything unexpected (a run longer than the round, a walk longer than a head) raises `fail`
+ * and the host falls back to k_replay.
+ * ========================================================================================== */
+#define R2_SEG_LOG 14
+#define R2_SEG  (1u << R2_SEG_LOG)
+#define R2_HEAD 2048u
+#define R2_NONE 0xffffffffu
+#define R2_SMALL_F 1024u                      /* the single-workgroup kernel runs the doubling rounds up to here */
+#define R2_BASE_MAX 4096u
+#define R2_LONG 8u                             /* runs longer than this are placed by a whole wave */
+#define R2_LMAX 512u
+#define R2_RMAX (2 * R2_LMAX + 2 + 256)
+#define R2_MOVED (YK_EMPTY - 1)                 /* old slot whose key a chain of the prefix has re-inserted: still part of its run, no longer a key */
+
+__device__ __forceinline__ u32 r2_home(u64 key, u32 bits) { return yk_h2b((u32)(key >> 10), bits); }
+
+/* largest g in (F, x] such that old slot g - 1 is unused (g == n is always a boundary); 0 if there is none */
+__device__ __forceinline__ u32 r2_boundary(const u64 *S, u32 F, u32 x, u32 n)
+{
+	if (x >= n) return n;
+	u32 g = x;
+	while (g > F && S[g - 1] != YK_EMPTY) --g;
+	return g > F ? g : 0;
+}
+
+/* put `key`, whose processing time is (c, d), into the new table; while it lands on an unmoved key of the run [a, b)
+ * that key is kicked out and follows at once with (c, d + 1) (khashl.h:183-187).  A key landing on an unmoved key of
+ * ANOTHER run only leaves its tag: that run reads it when its round comes. */
+__device__ __forceinline__ void r2_chain(u64 *S, u64 *D, u32 *TG, u64 key, u32 c, u32 d, u32 a, u32 b, u32 n, u32 nb)
+{
+	const u32 Nmask = 2 * n - 1;
+	for (;;) {
+		u32 p = r2_home(key, nb);
+		while (D[p] != YK_EMPTY) p = (p + 1) & Nmask;
+		D[p] = key;
+		if (p >= n) return;
+		TG[p] = c << 6 | (d < 63 ? d : 63);
+		if (p < a || p >= b) return;
+		const u64 v = S[p];
+		if (v == YK_EMPTY || v == R2_MOVED) return;
+		key = v; S[p] = R2_MOVED; ++d;
+	}
+}
+
+/* place the run of used old slots starting at a (slot a - 1 is unused).  First the keys kicked out by keys that are
+ * already in place (tag with c < slot), in (c, d) order -- c lies below the run, so they all come before the run's own
+ * scan positions; then the scan.  COH: the tags were written by other waves of this kernel (in-kernel rounds). */
+template <bool COH>
+__device__ __forceinline__ bool r2_run(u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u32 nb)      /* false: a long run, left to a wave */
+{
+	u32 b = a, nk = 0;
+	for (; b < n && S[b] != YK_EMPTY; ++b) {
+		if (b - a >= R2_LONG) return false;
+		const u32 t = COH ? __hip_atomic_load(&TG[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : TG[b];
+		nk += t != R2_NONE && (t >> 6) < b && S[b] != R2_MOVED;
+	}
+	u32 last = 0;                                                          /* tag + 1 of the last key taken */
+	for (u32 it = 0; it < nk; ++it) {
+		u32 best = R2_NONE, bs = a;
+		for (u32 s = a; s < b; ++s) {
+			if (S[s] == R2_MOVED) continue;
+			const u32 t = COH ? __hip_atomic_load(&TG[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : TG[s];
+			if (t == R2_NONE || (t >> 6) >= s) continue;
+			if (t + 1 > last && t < best) { best = t; bs = s; }               /* tags order like (c, d) */
+		}
+		if (best == R2_NONE) break;                                           /* the others left with a chain */
+		last = best + 1;
+		const u64 key = S[bs];
+		S[bs] = R2_MOVED;
+		r2_chain(S, D, TG, key, best >> 6, (best & 63u) + 1, a, b, n, nb);
+	}
+	for (u32 s = a; s < b; ++s) {
+		const u64 key = S[s];
+		if (key == R2_MOVED) continue;
+		S[s] = R2_MOVED;
+		r2_chain(S, D, TG, key, s, 0, a, b, n, nb);
+	}
+	return true;
+}
+
+/* A long run is placed by a whole wave on LDS copies.  In a round all tags a run reads are final, its kicked keys
+ * all precede its scan positions, and no chain continues inside it (its region starts at 2a >= b): first come first
+ * served in sigma order is then ordered probing with priority = rank in sigma order, all keys at once.  DYN: the run
+ * covers [F, 2F] and feeds its own slots (only below R2_SMALL_F): one lane walks it with the literal rule, on LDS. */
+struct R2Wave { u64 keys[R2_LMAX]; u32 sig[R2_LMAX]; u32 own[R2_RMAX]; unsigned short byrank[R2_LMAX], rk[R2_LMAX]; u32 mv[R2_LMAX / 32]; };
+
+__device__ __forceinline__ void r2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+template <bool COH, bool DYN>
+__device__ void r2_wave_run(R2Wave &W, u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u32 nb, u32 *fail)
+{
+	const u32 lane = threadIdx.x & 63, Nmask = 2 * n - 1;
+	u32 L = 0;
+	for (;;) {                                                              /* length of the run */
+		const u32 idx = a + L + lane;
+		const u64 m = __ballot(idx < n && S[idx] != YK_EMPTY);
+		if (m == ~0ull) { L += 64; if (L > R2_LMAX) break; continue; }
+		L += (u32)__ffsll((long long)~m) - 1;
+		break;
+	}
+	u32 wrap = 0;
+	if (a + L >= n) {                                                       /* the run that reaches the end of the table shares its region with the table's first run */
+		u32 j0 = 0;
+		while (j0 < 128 && S[j0] != YK_EMPTY) ++j0;
+		wrap = 2 * j0 + 2;
+	}
+	const u32 R = 2 * L + 2 + wrap;
+	if (L > R2_LMAX || R > R2_RMAX) { if (lane == 0) *fail = 6; return; }
+	for (u32 i = lane; i < L; i += 64) {
+		const u32 sl = a + i;
+		const u64 k = S[sl];
+		const u32 t = COH ? __hip_atomic_load(&TG[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : TG[sl];
+		W.keys[i] = k;
+		W.sig[i] = k == R2_MOVED ? R2_NONE : (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
+	}
+	for (u32 i = lane; i < R; i += 64) W.own[i] = D[(2 * a + i) & Nmask] != YK_EMPTY ? 0u : 0xffffffffu;
+	if (lane < R2_LMAX / 32) W.mv[lane] = 0;
+	r2_wave_sync();
+	for (u32 i = lane; i < L; i += 64) {                                    /* rank in sigma order */
+		const u32 g = W.sig[i];
+		if (g == R2_NONE) continue;
+		u32 r = 0;
+		for (u32 j = 0; j < L; ++j) r += W.sig[j] < g;
+		W.rk[i] = (unsigned short)r; W.byrank[r] = (unsigned short)i;
+	}
+	r2_wave_sync();
+	if (!DYN) {
+		for (u32 i = lane; i < L; i += 64) {
+			if (W.sig[i] == R2_NONE) continue;
+			u32 r = (u32)W.rk[i] + 1, li = (r2_home(W.keys[i], nb) - 2 * a) & Nmask;
+			for (;;) {
+				if (li >= R) { *fail = 7; break; }
+				const u32 old = atomicMin(&W.own[li], r);
+				if (old == 0xffffffffu) break;
+				if (old > r) r = old;
+				++li;
+			}
+		}
+		r2_wave_sync();
+		for (u32 i = lane; i < R; i += 64) { const u32 o = W.own[i]; if (o != 0 && o != 0xffffffffu) W.own[i] = (u32)W.byrank[o - 1] + 1; }
+	} else if (lane == 0) {
+		u32 nv = 0;
+		for (u32 i = 0; i < L; ++i) nv += W.sig[i] != R2_NONE;
+		auto chain = [&](u32 i, u32 c, u32 d) {
+			for (;;) {
+				W.mv[i >> 5] |= 1u << (i & 31);
+				W.sig[i] = c << 6 | (d < 63 ? d : 63);
+				u32 li = (r2_home(W.keys[i], nb) - 2 * a) & Nmask;
+				while (li < R && W.own[li] != 0xffffffffu) ++li;
+				if (li >= R) { *fail = 7; return; }
+				W.own[li] = i + 1;
+				const u32 slot = (2 * a + li) & Nmask;
+				if (slot < a || slot >= a + L) return;
+				const u32 v = slot - a;
+				if (W.sig[v] == R2_NONE || (W.mv[v >> 5] >> (v & 31) & 1)) return;
+				i = v; ++d;                                                  /* an unmoved key of the run sits there: it follows at once */
+			}
+		};
+		for (u32 r = 0; r < nv; ++r) {                                       /* the keys kicked out from below come first, in sigma order */
+			const u32 i = W.byrank[r];
+			if (W.mv[i >> 5] >> (i & 31) & 1) continue;                     /* left with a chain already (its time has been overwritten) */
+			const u32 g = W.sig[i];
+			if ((g & 63u) == 0) break;
+			chain(i, g >> 6, g & 63u);
+		}
+		for (u32 i = 0; i < L; ++i)
+			if (W.sig[i] != R2_NONE && !(W.mv[i >> 5] >> (i & 31) & 1)) chain(i, a + i, 0);
+	}
+	r2_wave_sync();
+	for (u32 i = lane; i < R; i += 64) {
+		const u32 o = W.own[i];
+		if (o == 0 || o == 0xffffffffu) continue;
+		const u32 slot = (2 * a + i) & Nmask;
+		D[slot] = W.keys[o - 1];
+		if (slot < n) TG[slot] = W.sig[o - 1];
+	}
+	if (DYN) for (u32 i = lane; i < L; i += 64) if (W.sig[i] != R2_NONE) S[a + i] = R2_MOVED;
+}
+
+/* R2Tab: first slot in the two buffers, first sorted new key.  R2Act: kind 0 nothing, 1 place, 2 double; bits = log2 capacity before
+ * the action; src = buffer (0/1) holding the table; seg0 = first entry of this sub-table in the per-segment arrays (yk_device.h) */
+
+/* empty destination + no tags, for the sub-tables that double in this step */
+__global__ __launch_bounds__(256)
+void k_r2_dinit(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC)
+{
+	const R2Act A = acts[blockIdx.y];
+	if (A.kind != 2) return;
+	const u64 off = tabs[blockIdx.y].off;
+	const u64 n = 1ull << A.bits, N = 2 * n;
+	u64 *D = (A.src ? K0 : K1) + off;
+	u32 *TG = TAG + (off >> 1);
+	u32 *OC = OCC + (off >> 4);                                       /* one bit per new slot: taken by a chain of the prefix (k_r2_dsmall) */
+	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < N; i += (u64)gridDim.x * 256) { D[i] = YK_EMPTY; if (i < n) TG[i] = R2_NONE; if (i < (N + 31) / 32) OC[i] = 0; }
+}
+
+/* the prefix by the literal rule, then the rounds below R2_SMALL_F; one workgroup per sub-table */
+__global__ __launch_bounds__(256)
+void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail)
+{
+	__shared__ R2Wave s_wave[4];
+	__shared__ u32 s_long[256];
+	__shared__ u32 s_F, s_dyn, s_nlong;
+	const u32 p = blockIdx.x, tid = threadIdx.x;
+	const R2Act A = acts[p];
+	if (A.kind != 2) return;
+	const u64 off = tabs[p].off;
+	const u32 n = 1u << A.bits, nb = A.bits + 1, Nmask = 2 * n - 1;
+	u64 *S = (A.src ? K1 : K0) + off;
+	u64 *D = (A.src ? K0 : K1) + off;
+	u32 *TG = TAG + (off >> 1);
+	u32 *OC = OCC + (off >> 4);
+	if (tid == 0) {
+		/* the literal rule (khashl.h:171-189) for the scan positions below F0, every chain followed to its end
+		 * wherever it goes: all keys with a processing time (c, d), c < F0, are then in place, in the reference's
+		 * order -- including the keys the run that wraps around the end of the table shares with its beginning.
+		 * A kicked-out key leaves a tombstone: its slot still belongs to its run */
+		u32 F0 = n < 8 ? n : 8;
+		while (F0 < n && S[F0 - 1] != YK_EMPTY) ++F0;               /* slot F0 - 1 unused (or F0 == n) */
+		if (F0 > R2_BASE_MAX && F0 < n) *fail = 1;
+		for (u32 j = 0; j < F0; ++j) {
+			u64 key = S[j];
+			if (key == YK_EMPTY || key == R2_MOVED) continue;
+			u32 d = 0;
+			S[j] = R2_MOVED;
+			for (;;) {
+				u32 q = r2_home(key, nb);
+				while (D[q] != YK_EMPTY) q = (q + 1) & Nmask;
+				D[q] = key;
+				OC[q >> 5] |= 1u << (q & 31);
+				if (q >= n) break;
+				TG[q] = j << 6 | (d < 63 ? d : 63);
+				const u64 v = S[q];
+				if (v == YK_EMPTY || v == R2_MOVED) break;
+				key = v; S[q] = R2_MOVED; ++d;                          /* an unmoved key sits there: kick it out */
+			}
+		}
+		s_F = F0;
+	}
+	__threadfence();
+	__syncthreads();
+	u32 F = s_F;
+	while (F < n && F < R2_SMALL_F) {
+		if (tid == 0) {
+			u32 g = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
+			s_dyn = 0; s_nlong = 0;
+			if (g == 0) {
+				/* one run covers [F, 2F]: the keys landing on its slots come from the run itself; it is placed alone, by the
+				 * literal rule in sigma order (r2_wave_run<.., true>), up to its own end */
+				s_dyn = 1;
+				g = 2 * F;
+				while (g < n && S[g] != YK_EMPTY) ++g;
+				g = g < n ? g + 1 : n;
+			}
+			s_F = g;
+		}
+		__syncthreads();
+		const u32 G = s_F;
+		if (s_dyn) { if (tid < 64) r2_wave_run<true, true>(s_wave[0], S, D, TG, F, n, nb, fail); }
+		else {
+			for (u32 s = F + tid; s < G; s += 256)
+				if (S[s] != YK_EMPTY && (s == F || S[s - 1] == YK_EMPTY) && !r2_run<true>(S, D, TG, s, n, nb)) {
+					const u32 at = atomicAdd(&s_nlong, 1u);
+					if (at < 256) s_long[at] = s; else *fail = 8;
+				}
+			__syncthreads();
+			const u32 nl = s_nlong < 256 ? s_nlong : 256;
+			for (u32 j = tid >> 6; j < nl; j += 4) r2_wave_run<true, false>(s_wave[tid >> 6], S, D, TG, s_long[j], n, nb, fail);
+		}
+		__threadfence();
+		__syncthreads();
+		F = G;
+	}
+	if (tid == 0) Fcur[p] = F;
+}
+
+/* One round [F, G) of every sub-table still doubling.  A wave takes R2_CH consecutive old slots: keys and tags come
+ * into LDS with coalesced loads; every key of a run that STARTS in the chunk gets its processing time from its tag and
+ * goes into an LDS window of the new table by ordered probing (smallest time wins a slot, the displaced key walks
+ * on): in a round no chain continues inside a run, so first come first served in sigma order IS ordered probing, and
+ * the runs keep to their own regions by themselves.  A lane per key, uniform work, no dependent global access; the
+ * window goes back with coalesced stores.  Slots a chain of the prefix took are marked from the OCC bits.  Runs longer
+ * than R2_CHL, or touching the end of the table, are listed for k_r2_long. */
+#define R2_CH  256u
+#define R2_CHL 32u
+#define R2_CHX (R2_CHL + 8)
+#define R2_NA  (R2_CH + R2_CHX + 1)
+#define R2_WN  (2 * (R2_CH + R2_CHX) + 2)
+__global__ __launch_bounds__(64)
+void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap)
+{
+	__shared__ u64 s_key[R2_NA];                                             /* s_key[x] = old slot c0 - 1 + x */
+	__shared__ u32 s_tag[R2_NA];
+	__shared__ short s_le[R2_NA], s_ne[R2_NA];                               /* last unused slot at or before x (-1: none), next unused slot at or after x (R2_NA: none) */
+	__shared__ u64 s_win[R2_WN];                                             /* (time + 1) << 32 | x; 0 = taken before this round; ~0 = free */
+	const u32 p = blockIdx.y, lane = threadIdx.x;
+	const R2Act A = acts[p];
+	if (A.kind != 2) return;
+	const u32 n = 1u << A.bits, nb = A.bits + 1, F = Fcur[p];
+	if (F >= n) { if (blockIdx.x == 0 && lane == 0) Fnext[p] = F; return; }
+	const u64 off = tabs[p].off;
+	u64 *S = (A.src ? K1 : K0) + off, *D = (A.src ? K0 : K1) + off;
+	u32 *TG = TAG + (off >> 1);
+	const u32 *OC = OCC + (off >> 4);
+	const u32 G = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
+	if (G == 0) { if (blockIdx.x == 0 && lane == 0) { *fail = 3; Fnext[p] = n; } return; }
+	if (blockIdx.x == 0 && lane == 0) Fnext[p] = G;
+	const u32 PER = (R2_NA + 63) / 64;
+	for (u32 c0 = F + blockIdx.x * R2_CH; c0 < G; c0 += gridDim.x * R2_CH) {
+		const u32 w0 = 2 * c0;
+		for (u32 x = lane; x < R2_NA; x += 64) {
+			const u32 sl = c0 - 1 + x;                                          /* c0 >= F >= 8 */
+			s_key[x] = sl < n ? S[sl] : YK_EMPTY;
+			s_tag[x] = sl < n ? TG[sl] : R2_NONE;
+		}
+		for (u32 i = lane; i < R2_WN; i += 64) {
+			const u32 q = w0 + i;
+			s_win[i] = (q < 2 * n && (OC[q >> 5] >> (q & 31) & 1)) ? 0ull : ~0ull;
+		}
+		__syncthreads();
+		{	/* last / next unused slot: every lane owns PER consecutive entries, the lanes are linked by a shuffle scan */
+			const u32 x0 = lane * PER;
+			int le = -1, ne = (int)R2_NA;
+			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x < R2_NA && s_key[x] == YK_EMPTY) le = (int)x; }
+			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x < R2_NA && s_key[x] == YK_EMPTY) ne = (int)x; }
+			int lei = le, nei = ne;
+			for (int o = 1; o < 64; o <<= 1) {
+				const int t = __shfl_up(lei, o), u = __shfl_down(nei, o);
+				if ((int)lane >= o && t > lei) lei = t;
+				if ((int)lane + o < 64 && u < nei) nei = u;
+			}
+			int run_le = __shfl_up(lei, 1), run_ne = __shfl_down(nei, 1);
+			if (lane == 0) run_le = -1;
+			if (lane == 63) run_ne = (int)R2_NA;
+			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x >= R2_NA) break; if (s_key[x] == YK_EMPTY) run_le = (int)x; s_le[x] = (short)run_le; }
+			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x >= R2_NA) continue; if (s_key[x] == YK_EMPTY) run_ne = (int)x; s_ne[x] = (short)run_ne; }
+		}
+		__syncthreads();
+		const u32 lim = (G < c0 + R2_CH ? G : c0 + R2_CH) - c0;              /* runs start in [c0, c0 + lim) */
+		for (u32 x = lane + 1; x < R2_NA; x += 64) {
+			const u64 key = s_key[x];
+			if (key == YK_EMPTY) continue;
+			const int le = s_le[x], ne = s_ne[x];
+			if (le < 0 || (u32)le >= lim) continue;                             /* its run starts before / behind this chunk */
+			const u32 L = (u32)(ne - le - 1), a = c0 + (u32)le;
+			if (ne >= (int)R2_NA || L > R2_CHL || a + L >= n) {                 /* too long for the window, or it reaches the end of the table: a wave does it */
+				if ((int)x == le + 1) {
+					const u32 at = atomicAdd(long_n, 1u);
+					if (at < long_cap) long_list[at] = (u64)p << 32 | a; else *fail = 8;
+				}
+				continue;
+			}
+			if (key == R2_MOVED) continue;
+			const u32 sl = c0 - 1 + x, t = s_tag[x];
+			const u32 sig = (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
+			u64 e = (u64)(sig + 1) << 32 | x;
+			u32 q = r2_home(key, nb) - w0;
+			for (;;) {
+				if (q >= R2_WN) { *fail = 9; break; }
+				const u64 old = atomicMin((unsigned long long*)&s_win[q], (unsigned long long)e);
+				if (old == ~0ull) break;
+				if (old > e) e = old;                                           /* we took the slot; carry the displaced later key on */
+				++q;
+			}
+		}
+		__syncthreads();
+		for (u32 i = lane; i < R2_WN; i += 64) {
+			const u64 e = s_win[i];
+			if (e == ~0ull || (e >> 32) == 0) continue;
+			const u32 q = w0 + i;
+			D[q] = s_key[(u32)e];
+			if (q < n) TG[q] = (u32)(e >> 32) - 1;
+		}
+		__syncthreads();
+	}
+}
+
+/* the long runs of the round just launched, a wave each */
+__global__ __launch_bounds__(64)
+void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u64 *long_list, const u32 *long_n, u32 long_cap, u32 *fail)
+{
+	__shared__ R2Wave W;
+	const u32 nl = *long_n < long_cap ? *long_n : long_cap;
+	for (u32 j = blockIdx.x; j < nl; j += gridDim.x) {
+		const u32 p = (u32)(long_list[j] >> 32), a = (u32)long_list[j];
+		const R2Act A = acts[p];
+		const u64 off = tabs[p].off;
+		r2_wave_run<false, false>(W, (A.src ? K1 : K0) + off, (A.src ? K0 : K1) + off, TAG + (off >> 1), a, 1u << A.bits, A.bits + 1, fail);
+		__syncthreads();
+	}
+}
+
+/* keys of a stage grouped by the segment of their home slot: pk/pr[rec_off + i0 + ...], seg_start[seg0 + s] relative to the stage's first key */
+__global__ __launch_bounds__(1024)
+void k_r2_ppart(const R2Tab *tabs, const R2Act *acts, const u64 *__restrict__ kc, u64 *__restrict__ pk, u32 *__restrict__ pr, u32 *seg_start, u32 SEGLOG)
+{
+	__shared__ u32 s_cnt[1024];
+	__shared__ u32 s_w[16];
+	const u32 p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const R2Act A = acts[p];
+	if (A.kind != 1 || A.bits <= SEGLOG) return;
+	const u32 nseg = 1u << (A.bits - SEGLOG);                    /* <= 1024 */
+	const u64 base = tabs[p].rec_off + A.i0;
+	s_cnt[tid] = 0;
+	__syncthreads();
+	for (u32 q = tid; q < A.batch; q += 1024) atomicAdd(&s_cnt[r2_home(kc[base + q], A.bits) >> SEGLOG], 1u);
+	__syncthreads();
+	const u32 c = s_cnt[tid];
+	u32 incl = c;
+	for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	u32 ex = incl - c;
+	for (u32 w = 0; w < wave; ++w) ex += s_w[w];
+	if (tid < nseg) seg_start[A.seg0 + tid] = ex;
+	if (tid == nseg - 1) seg_start[A.seg0 + nseg] = ex + c;
+	__syncthreads();
+	s_cnt[tid] = ex;
+	__syncthreads();
+	for (u32 q = tid; q < A.batch; q += 1024) {
+		const u64 key = kc[base + q];
+		const u32 d = atomicAdd(&s_cnt[r2_home(key, A.bits) >> SEGLOG], 1u);
+		pk[base + d] = key; pr[base + d] = q + 1;
+	}
+}
+
+/* ordered probing of one segment's keys with the ranks in LDS */
+__global__ __launch_bounds__(1024)
+void k_r2_place(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, const u64 *__restrict__ kc, const u64 *__restrict__ pk, const u32 *__restrict__ pr,
+                const u32 *__restrict__ seg_start, u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, u32 SEGLOG, u32 HEAD)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_own[];
+	const u32 p = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+	const R2Act A = acts[p];
+	if (A.kind != 1) return;
+	const u32 n = 1u << A.bits, nseg = A.bits > SEGLOG ? 1u << (A.bits - SEGLOG) : 1;
+	if (seg >= nseg) return;
+	const u32 L = nseg > 1 ? 1u << SEGLOG : n, start = seg * L;
+	u64 *keys = (A.src ? K1 : K0) + tabs[p].off;
+	const u64 base = tabs[p].rec_off + A.i0;
+	for (u32 i = tid; i < L; i += 1024) s_own[i] = keys[start + i] != YK_EMPTY ? 0u : 0xffffffffu;
+	__syncthreads();
+	const u32 q0 = nseg > 1 ? seg_start[A.seg0 + seg] : 0, q1 = nseg > 1 ? seg_start[A.seg0 + seg + 1] : A.batch;
+	for (u32 q = q0 + tid; q < q1; q += 1024) {
+		u32 r, li;
+		if (nseg > 1) { r = pr[base + q]; li = r2_home(pk[base + q], A.bits) - start; }
+		else { r = q + 1; li = r2_home(kc[base + q], A.bits); }
+		for (;;) {
+			const u32 old = atomicMin(&s_own[li], r);
+			if (old == 0xffffffffu) break;
+			if (old > r) r = old;                                      /* we took the slot; carry the displaced later key on */
+			++li;
+			if (nseg == 1) { li &= n - 1; continue; }
+			if (li == L) {                                             /* the walk goes on in the next segment's head */
+				const u32 at = atomicAdd(spill_n, 1u);
+				if (at < spill_cap) spill[at] = (u64)p << 48 | (u64)((seg + 1) & (nseg - 1)) << 32 | r; else *fail = 4;
+				break;
+			}
+		}
+	}
+	__syncthreads();
+	const u64 *src = kc + base;
+	const u32 h0 = nseg > 1 ? HEAD : 0;
+	u32 *hd = head + (size_t)(A.seg0 + seg) * HEAD;
+	for (u32 i = tid; i < L; i += 1024) {
+		const u32 o = s_own[i];
+		if (i < h0) hd[i] = o;                                          /* finished by k_r2_spill / k_r2_headfill */
+		else if (o != 0 && o != 0xffffffffu) keys[start + i] = src[o - 1];
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_r2_spill(const R2Act *acts, const u64 *spill, const u32 *spill_n, u32 spill_cap, u32 *head, u32 *fail, u32 HEAD)
+{
+	const u32 ns = *spill_n < spill_cap ? *spill_n : spill_cap;
+	for (u32 j = blockIdx.x * 256 + threadIdx.x; j < ns; j += gridDim.x * 256) {
+		const u64 e = spill[j];
+		const u32 p = (u32)(e >> 48), seg = (u32)(e >> 32) & 0xffffu;
+		u32 r = (u32)e;
+		u32 *hd = head + (size_t)(acts[p].seg0 + seg) * HEAD;
+		u32 li = 0;
+		for (;;) {
+			const u32 old = atomicMin(&hd[li], r);
+			if (old == 0xffffffffu) break;
+			if (old > r) r = old;
+			if (++li == HEAD) { *fail = 5; break; }
+		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_r2_headfill(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, const u64 *__restrict__ kc, const u32 *head, u32 SEGLOG, u32 HEAD)
+{
+	const u32 p = blockIdx.y, seg = blockIdx.x;
+	const R2Act A = acts[p];
+	if (A.kind != 1 || A.bits <= SEGLOG || seg >= 1u << (A.bits - SEGLOG)) return;
+	u64 *keys = (A.src ? K1 : K0) + tabs[p].off + ((u64)seg << SEGLOG);
+	const u64 *src = kc + tabs[p].rec_off + A.i0;
+	const u32 *hd = head + (size_t)(A.seg0 + seg) * HEAD;
+	for (u32 i = threadIdx.x; i < HEAD; i += 256) {
+		const u32 o = __hip_atomic_load(&hd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (o != 0 && o != 0xffffffffu) keys[i] = src[o - 1];
+	}
+}
+
+/* table of a sub-table into one of the two buffers: a copy of `n` slots of src (unused slots hold YK_EMPTY) or an empty table */
+__global__ __launch_bounds__(256)
+void k_r2_load(const R2Tab *tabs, const R2Load *ld, const u64 *__restrict__ src1, const u64 *__restrict__ src2, u64 *K0, u64 *K1)
+{
+	const R2Load Ld = ld[blockIdx.y];
+	if (Ld.bits == YK_NOCAP) return;
+	u64 *D = (Ld.dst ? K1 : K0) + tabs[blockIdx.y].off;
+	const u64 *src = Ld.from_src == 2 ? src2 : src1;
+	const u64 n = 1ull << Ld.bits;
+	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) D[i] = Ld.from_src ? src[Ld.src_off + i] : YK_EMPTY;
+}
+
+/* does a put-call follow the last new key of the sub-table (khashl.h:202 on an existing key: the trailing doubling)? */
+__global__ void k_r2_trail(const u64 *lastput, const u64 *rec_t, const u64 *rec_off, const u32 *m, int P, u32 *out)
+{
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= P) return;
+	const u64 lp = lastput[p];
+	out[p] = lp != 0 && (m[p] == 0 || lp - 1 > rec_t[rec_off[p] + m[p] - 1]);
+}
+
+/* final table -> arena + bitmap (one lane per slot; a wave's ballot is two bitmap words) */
+__global__ __launch_bounds__(256)
+void k_r2_publish(const R2Tab *tabs, const R2Pub *pub, const u64 *K0, const u64 *K1, u64 *__restrict__ nk, u32 *__restrict__ nu)
+{
+	const R2Pub Pb = pub[blockIdx.y];
+	if (Pb.bits == YK_NOCAP) return;
+	const u64 *S = (Pb.src ? K1 : K0) + tabs[blockIdx.y].off;
+	const u64 n = 1ull << Pb.bits;
+	for (u64 i0 = (u64)blockIdx.x * 256; i0 < n; i0 += (u64)gridDim.x * 256) {
+		const u64 i = i0 + threadIdx.x;
+		const u64 k = i < n ? S[i] : YK_EMPTY;
+		if (i < n) nk[Pb.new_off + i] = k;
+		const u64 b = __ballot(k != YK_EMPTY);
+		if ((threadIdx.x & 63) == 0 && i < n) { nu[(Pb.new_off + i) >> 5] = (u32)b; if (i + 32 < n) nu[((Pb.new_off + i) >> 5) + 1] = (u32)(b >> 32); }
+	}
+}
+
 /* ------------------------------------------------------------------------------------------
  * shrink (reference htab.c:180-197): keys with min <= count <= max, in ascending OLD slot order
  * ------------------------------------------------------------------------------------------ */
@@ -3275,6 +3846,57 @@ int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64
 	else { if (cross) YK_OWN(2, 1); else YK_OWN(2, 0); }
 #undef YK_OWN
 	return 0;
+}
+
+/* ---- replay2 launchers (grids: x = blocks per sub-table, y = sub-table) ---- */
+void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, hipStream_t st)
+{
+	const u64 N = 2ull << bmax;
+	hipLaunchKernelGGL(k_r2_dinit, dim3((unsigned)std::min<u64>((N + 1023) / 1024, 4096), P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC);
+}
+void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, fail);
+}
+int yk_r2_small_f(void) { return (int)R2_SMALL_F; }
+void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail,
+                  u64 *long_list, u32 *long_n, u32 long_cap, hipStream_t st)
+{
+	hipMemsetAsync(long_n, 0, 4, st);
+	const u32 blocks = (span + R2_CH - 1) / R2_CH;                      /* `span` old slots per sub-table at most in this round */
+	hipLaunchKernelGGL(k_r2_dround, dim3(blocks < (1u << 20) ? blocks : 1u << 20, P), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, fail, long_list, long_n, long_cap);
+	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_cap, fail);
+}
+int yk_r2_seg_log(void) { const int v = getenv("YAKAMD_R2_SEG_LOG") ? atoi(getenv("YAKAMD_R2_SEG_LOG")) : R2_SEG_LOG; return v < 10 ? 10 : v > R2_SEG_LOG ? R2_SEG_LOG : v; }   /* the knob lets tests split small tables */
+int yk_r2_head(void) { const u32 seg = 1u << yk_r2_seg_log(); return (int)(seg / 2 < R2_HEAD ? seg / 2 : R2_HEAD); }
+void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
+                 u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, hipStream_t st)
+{
+	static bool attr = false;
+	if (!attr) { hipFuncSetAttribute((const void*)k_r2_place, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 256); attr = true; }
+	const u32 SL = (u32)yk_r2_seg_log(), HD = (u32)yk_r2_head();
+	const u32 nseg = bmax > SL ? 1u << (bmax - SL) : 1, L = bmax > SL ? 1u << SL : 1u << bmax;
+	hipMemsetAsync(spill_n, 0, 4, st);
+	if (nseg > 1) hipLaunchKernelGGL(k_r2_ppart, dim3(P), dim3(1024), 0, st, tabs, acts, kc, pk, pr, seg_start, SL);
+	hipLaunchKernelGGL(k_r2_place, dim3(nseg, P), dim3(1024), (size_t)L * 4, st, tabs, acts, K0, K1, kc, (const u64*)pk, (const u32*)pr, (const u32*)seg_start, head, spill, spill_n, spill_cap, fail, SL, HD);
+	if (nseg > 1) {
+		hipLaunchKernelGGL(k_r2_spill, dim3(64), dim3(256), 0, st, acts, (const u64*)spill, (const u32*)spill_n, spill_cap, head, fail, HD);
+		hipLaunchKernelGGL(k_r2_headfill, dim3(nseg, P), dim3(256), 0, st, tabs, acts, K0, K1, kc, (const u32*)head, SL, HD);
+	}
+}
+void yk_r2_load(const R2Tab *tabs, const R2Load *ld, int P, u32 bmax, const u64 *src1, const u64 *src2, u64 *K0, u64 *K1, hipStream_t st)
+{
+	const u64 n = 1ull << bmax;
+	hipLaunchKernelGGL(k_r2_load, dim3((unsigned)std::min<u64>((n + 1023) / 1024, 4096), P), dim3(256), 0, st, tabs, ld, src1, src2, K0, K1);
+}
+void yk_r2_trail(const u64 *lastput, const u64 *rec_t, const u64 *rec_off, const u32 *m, int P, u32 *out, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_r2_trail, dim3((P + 255) / 256), dim3(256), 0, st, lastput, rec_t, rec_off, m, P, out);
+}
+void yk_r2_publish(const R2Tab *tabs, const R2Pub *pub, int P, u32 bmax, const u64 *K0, const u64 *K1, u64 *nk, u32 *nu, hipStream_t st)
+{
+	const u64 n = 1ull << bmax;
+	hipLaunchKernelGGL(k_r2_publish, dim3((unsigned)std::min<u64>((n + 1023) / 1024, 4096), P), dim3(256), 0, st, tabs, pub, K0, K1, nk, nu);
 }
 
 int yk_lc2_ok(FastParams fp)

@@ -479,6 +479,7 @@ yak_ch_t *yak_ch_restore(const char *fn) { return yak_ch_restore_core(0, fn, YAK
  * sequence is every following line up to one starting with '>', '@' or '+', a '+' line introduces
  * quality lines covering at least the sequence length; a truncated quality ends the input.
  * ------------------------------------------------------------------------------------------ */
+extern "C++" {
 struct FxReader {
 	gzFile fp; int fd; unsigned char *buf; int beg, end, eof, last;
 	std::vector<char> seq, name; size_t qlen; int qlast;
@@ -552,7 +553,7 @@ struct FxReader {
 	 * bases.  The reader state it leaves is exactly what next() would leave; anything else (blank or
 	 * wrapped lines, CR, a record cut by the buffer end, EOF) returns NOT_FAST without touching the
 	 * state, and the caller takes next(). */
-	int64_t fast(std::vector<char> &out, int64_t min_len) {
+	template <class V> int64_t fast(V &out, int64_t min_len) {
 		const unsigned char *b = buf;
 		int p = beg;
 		if (p >= end) return NOT_FAST;
@@ -606,6 +607,7 @@ struct FxReader {
 		return qlen == seq.size() ? (int64_t)seq.size() : -2;
 	}
 };
+} /* extern "C++" */
 
 /* ------------------------------------------------------------------------------------------
  * Parallel parsing of a plain (uncompressed, mapped) file.  A window of the file is cut into one
@@ -627,7 +629,30 @@ static int parse_threads(int n_thread)
 	return n < 1 ? 1 : n > 32 ? 32 : n;
 }
 
-struct ParSeg { int64_t start, end, stop; std::vector<char> img; int64_t n_seq, sum_len; bool hard_end; };
+/* Parsed base images live in page-locked host memory (the copy to the device is then a DMA transfer that
+ * runs beside the parser threads) unless YAKAMD_PIN=0; the buffers are reused from window to window. */
+extern "C++" {
+template <class T> struct PinAlloc {
+	typedef T value_type;
+	PinAlloc() {}
+	template <class U> PinAlloc(const PinAlloc<U>&) {}
+	T *allocate(size_t n) {
+		static const bool pin = !(getenv("YAKAMD_PIN") && atoi(getenv("YAKAMD_PIN")) == 0);
+		void *p = 0;
+		if (pin && hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess) return (T*)((uintptr_t)p);
+		(void)hipGetLastError();
+		p = malloc(n * sizeof(T) + 16);
+		if (!p) throw std::bad_alloc();
+		return (T*)p;
+	}
+	void deallocate(T *p, size_t) { if (hipHostFree((void*)p) != hipSuccess) { (void)hipGetLastError(); free((void*)p); } }
+	template <class U> bool operator==(const PinAlloc<U>&) const { return true; }
+	template <class U> bool operator!=(const PinAlloc<U>&) const { return false; }
+};
+typedef std::vector<char, PinAlloc<char> > PinVec;
+} /* extern "C++" */
+
+struct ParSeg { int64_t start, end, stop; PinVec img; int64_t n_seq, sum_len; bool hard_end; };
 
 static int64_t guess_record_start(int fd, int64_t from, int64_t limit)
 {
@@ -656,6 +681,7 @@ static void parse_segment(int fd, int64_t file_end, ParSeg *sg, int min_len)
 	r.open_at(fd, sg->start);
 	sg->n_seq = sg->sum_len = 0; sg->hard_end = false;
 	sg->img.clear();
+	if (sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
 	int64_t l;
 	for (;;) {
 		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = true; break; }
@@ -669,37 +695,61 @@ static void parse_segment(int fd, int64_t file_end, ParSeg *sg, int min_len)
 	r.close_at();
 }
 
-/* calls sink(image, n_seq) for consecutive pieces of the input, in order; false if sink failed */
-static bool parse_parallel(int fd, int64_t size, int min_len, int n_thr, const std::function<bool(const std::vector<char>&, int64_t)> &sink)
+/* one window: cut [pos, wend) into segments, parse them on n_thr threads, accept the verified prefix.  Returns the
+ * number of accepted segments; *next = where the following window starts; *done = the stream has ended */
+static int parse_window(int fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done)
+{
+	const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
+	int n_seg = 0;
+	for (int i = 0; i < n_thr; ++i) {
+		const int64_t cut = pos + i * step;
+		if (cut >= wend) break;
+		const int64_t st = i == 0 ? pos : guess_record_start(fd, cut, std::min(size, cut + ((int64_t)1 << 18)));
+		if (i && (st < 0 || st >= wend)) continue;
+		if (n_seg && st <= seg[n_seg - 1].start) continue;
+		seg[n_seg].start = st; ++n_seg;
+	}
+	for (int i = 0; i < n_seg; ++i) seg[i].end = i + 1 < n_seg ? seg[i + 1].start : wend;
+	std::vector<std::thread> th;
+	for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len);
+	parse_segment(fd, size, &seg[0], min_len);
+	for (auto &t : th) t.join();
+	int64_t at = pos;
+	int n_ok = 0;
+	for (int i = 0; i < n_seg; ++i) {
+		if (seg[i].start != at) break;                           /* wrong guess: the rest of the window is parsed again */
+		++n_ok;
+		at = seg[i].stop;
+		if (seg[i].hard_end) { *done = true; break; }
+	}
+	*next = at;
+	return n_ok;
+}
+
+/* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
+ * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
+ * threads already work on the next one. */
+static bool parse_parallel(int fd, int64_t size, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
 {
 	const int64_t WIN = (int64_t)env_threads_window();
-	std::vector<ParSeg> seg(n_thr);
-	int64_t pos = 0;
-	bool done = false;
-	while (!done && pos < size) {
-		const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
-		int n_seg = 0;
-		for (int i = 0; i < n_thr; ++i) {
-			const int64_t cut = pos + i * step;
-			if (cut >= wend) break;
-			const int64_t st = i == 0 ? pos : guess_record_start(fd, cut, std::min(size, cut + ((int64_t)1 << 18)));
-			if (i && (st < 0 || st >= wend)) continue;
-			if (n_seg && st <= seg[n_seg - 1].start) continue;
-			seg[n_seg].start = st; ++n_seg;
-		}
-		for (int i = 0; i < n_seg; ++i) seg[i].end = i + 1 < n_seg ? seg[i + 1].start : wend;
-		std::vector<std::thread> th;
-		for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len);
-		parse_segment(fd, size, &seg[0], min_len);
-		for (auto &t : th) t.join();
-		int64_t at = pos;
-		for (int i = 0; i < n_seg; ++i) {
-			if (seg[i].start != at) break;                       /* wrong guess: the rest of the window is parsed again */
-			if (!sink(seg[i].img, seg[i].n_seq)) return false;
-			at = seg[i].stop;
-			if (seg[i].hard_end) { done = true; break; }
-		}
-		pos = at;
+	std::vector<ParSeg> seg[2] = { std::vector<ParSeg>(n_thr), std::vector<ParSeg>(n_thr) };
+	int64_t pos = 0, next[2] = { 0, 0 };
+	bool done[2] = { false, false };
+	int n_ok[2] = { 0, 0 }, cur = 0;
+	if (size <= 0) return true;
+	n_ok[0] = parse_window(fd, size, 0, WIN, min_len, n_thr, seg[0], &next[0], &done[0]);
+	for (;;) {
+		pos = next[cur];
+		const bool more = !done[cur] && pos < size;
+		std::thread ahead;
+		if (more) ahead = std::thread([&, pos]() { n_ok[cur ^ 1] = parse_window(fd, size, pos, WIN, min_len, n_thr, seg[cur ^ 1], &next[cur ^ 1], &done[cur ^ 1]); });
+		bool ok = true;
+		for (int i = 0; i < n_ok[cur] && ok; ++i) ok = sink(seg[cur][i].img.data(), seg[cur][i].img.size(), seg[cur][i].n_seq);
+		if (ahead.joinable()) ahead.join();
+		if (!ok) return false;
+		if (!more) break;
+		done[cur] = false;
+		cur ^= 1;
 	}
 	return true;
 }
@@ -733,9 +783,9 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) par_size = sb.st_size;
 	}
 	if (ok && par_size >= 0) {
-		ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, [&](const std::vector<char> &img, int64_t ns) {
-			bool good = img.empty() || yakamd_feed_bases_host(h, img.data(), (int64_t)img.size(), t0) == 0;
-			t0 += img.size(); n_seq_tot += ns;
+		ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
+			bool good = img_n == 0 || yakamd_feed_bases_host(h, img, (int64_t)img_n, t0) == 0;
+			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
 			return good;
 		});
@@ -797,7 +847,7 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 		struct stat sb;
 		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
 			size_t total = 0;
-			parse_parallel(fx.fd, (int64_t)sb.st_size, min_len, n_thr, [&](const std::vector<char> &part, int64_t) { total += part.size(); if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part.begin(), part.end()); return true; });
+			parse_parallel(fx.fd, (int64_t)sb.st_size, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part, part + part_n); return true; });
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes\n", yk_realtime() - t_, n_thr, total);
 			fx.close_file();
 			*out = (char*)malloc(img.size() + 1);

@@ -178,6 +178,23 @@ void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec 
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, LcOut O, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st);
+/* replay2 (layout replay of large sub-tables, kernels.hip) */
+struct R2Tab { u64 off, rec_off; };
+struct R2Act { u32 kind, bits, i0, batch, src, seg0, pad0, pad1; };
+struct R2Load { u64 src_off; u32 bits, from_src, dst, pad; };
+struct R2Pub { u64 new_off; u32 bits, src; };
+void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, hipStream_t st);
+void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, hipStream_t st);
+void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail,
+                  u64 *long_list, u32 *long_n, u32 long_cap, hipStream_t st);
+void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
+                 u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, hipStream_t st);
+void yk_r2_load(const R2Tab *tabs, const R2Load *ld, int P, u32 bmax, const u64 *src1, const u64 *src2, u64 *K0, u64 *K1, hipStream_t st);
+void yk_r2_trail(const u64 *lastput, const u64 *rec_t, const u64 *rec_off, const u32 *m, int P, u32 *out, hipStream_t st);
+void yk_r2_publish(const R2Tab *tabs, const R2Pub *pub, int P, u32 bmax, const u64 *K0, const u64 *K1, u64 *nk, u32 *nu, hipStream_t st);
+int yk_r2_small_f(void);
+int yk_r2_seg_log(void);
+int yk_r2_head(void);
 size_t yk_count_own_lds(u32 range_len, u32 kmax);
 int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
                             size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
