@@ -1,0 +1,40 @@
+"""Several GPUs behind yak_count() (YAKAMD_GPUS; SURVEY 8e, reference count.c:129-143): the library deals the
+input to N ranks in chunks, every rank groups its k-mers by prefix, one exchange per round moves them to the
+owner.  A one-GPU box runs the N ranks on the same device (YAKAMD_GPU_LIST=0,0,...: device copies instead of
+RCCL); the bytes must equal the single-GPU run's, which the other tests pin on the oracle and the reference."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+YAM = os.path.join(ROOT, "yak_amd", "yak-amd")
+YKO = os.path.join(ROOT, "oracle", "yko")
+SYN = os.path.join(ROOT, "tools", "yaksynth")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reads(tmp_path_factory):
+    import yak_amd
+    if yak_amd.lib().yakamd_device_count() < 1:
+        pytest.skip("no MI355X visible")
+    d = tmp_path_factory.mktemp("mgpu")
+    fq, fa = str(d / "r.fq"), str(d / "c.fa")
+    subprocess.check_call([SYN, "-n", "20000", "-l", "150", "-g", "100000", "-s", "31", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "12", "-l", "40000", "-g", "100000", "-s", "31", "-e", "0.001", "-N", "0.0003", "-o", fa])
+    return dict(fq=fq, fa=fa, dir=str(d))
+
+
+@pytest.mark.parametrize("n_gpu,chunk", [(2, "300000"), (4, "150000"), (8, "100000"), (2, None)])
+@pytest.mark.parametrize("args,inp", [(["-k31", "-b24"], "fq"), (["-k31"], "fq"), (["-k21", "-b22", "-t1"], "fa")], ids=["reads_b24", "reads_nofilter", "contigs_b22_stream_reader"])
+def test_multi_gpu_count_equals_single(n_gpu, chunk, args, inp, reads):
+    want, got = os.path.join(reads["dir"], "one.yak"), os.path.join(reads["dir"], "multi.yak")
+    subprocess.run([YKO, "count"] + args + ["-o", want, reads[inp]], check=True, stderr=subprocess.DEVNULL)      # the oracle's file
+    env = dict(os.environ, YAKAMD_GPUS=str(n_gpu), YAKAMD_GPU_LIST=",".join(["0"] * n_gpu))
+    if chunk:
+        env["YAKAMD_MGPU_CHUNK"] = chunk
+    r = subprocess.run([YAM, "count"] + args + ["-o", got, reads[inp]], check=True, env=env, stderr=subprocess.PIPE)
+    assert f"{n_gpu} GPUs".encode() in r.stderr
+    assert open(got, "rb").read() == open(want, "rb").read()

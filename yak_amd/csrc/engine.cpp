@@ -207,7 +207,7 @@ struct yakamd_ctx {
 	struct yak_ht_t *hts;
 };
 
-struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; u32 magic; };
+struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; u32 magic; int n_sub; yak_ch_t **sub; };   /* n_sub > 1: a table sharded over several GPUs (yak_api.cpp) */
 #define EXT_MAGIC 0x59414b41u
 
 static yakamd_ctx *ctx_of(const yak_ch_t *h)
@@ -254,6 +254,9 @@ static int img_reset_empty(yakamd_ctx *c)
 	return 0;
 }
 
+static thread_local int g_next_device = -1;          /* device of the next context created on this thread (multi-GPU tables) */
+void yk_ctx_next_device(int dev) { g_next_device = dev; }
+
 yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 {
 	if (yakamd_device_count() < 1) { fail("no gfx950 GPU visible: the counting engine has no CPU fallback"); return 0; }
@@ -279,6 +282,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 		int nd = 0;
 		if (!getenv("YAKAMD_DEVICE") && lr && hipGetDeviceCount(&nd) == hipSuccess && nd > 0) c->dev = atoi(lr) % nd;
 	}
+	if (g_next_device >= 0) { c->dev = g_next_device; g_next_device = -1; }
 	if (hipSetDevice(c->dev) != hipSuccess || hipStreamCreate(&c->st) != hipSuccess) { fail("cannot open device %d", c->dev); delete c; return 0; }
 	if (n_hash > 0 && n_shift > pre) {                       /* reference htab.c:23-27 */
 		c->n_hash = n_hash; c->bf_shift = n_shift; c->nb = n_shift - pre;
@@ -1731,6 +1735,25 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 	return 0;
 }
 void yk_pool_release(void *p) { if (p) pool_free(p); }
+
+/* the stored keys of every sub-table in ascending slot order, packed (what a .yak file holds, htab.c:385-389), copied
+ * to `out` (room for the sum of the sub-table sizes): the dump moves 8 bytes per key instead of the whole slot arrays */
+int yk_ctx_dump_keys(yakamd_ctx *c, u64 *out)
+{
+	HIPCK(hipSetDevice(c->dev));
+	const int P = c->P;
+	std::vector<u64> seg_off(P + 1, 0);
+	for (int p = 0; p < P; ++p) seg_off[p + 1] = seg_off[p] + c->h_count[p];
+	if (seg_off[P] == 0) return 0;
+	u64 *d_segoff = 0, *d_kc = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segoff); dfree(d_kc); } };
+	if (dmalloc(&d_segoff, P + 1) || dmalloc(&d_kc, seg_off[P])) return -1;
+	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
+	yk_launch_shrink_scatter(img_view(c), P, 0, 1023, 0, img_view(c), d_segoff, d_kc, c->st);
+	HIPCK(hipMemcpyAsync(out, d_kc, seg_off[P] * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCK(hipStreamSynchronize(c->st));
+	return 0;
+}
 void yk_ctx_gate(yakamd_ctx *c, bool on) { c->gate_off = !on; }
 void yk_ctx_or_mode(yakamd_ctx *c, int mode) { c->or_mode = mode; }
 

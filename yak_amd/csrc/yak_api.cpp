@@ -25,9 +25,11 @@
 #include <string>
 #include <cmath>
 #include "engine.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>                                   /* types and prototypes only: the library is opened when a job asks for several GPUs */
 
 struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };
-struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; uint32_t magic; };
+struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; uint32_t magic; int n_sub; yak_ch_t **sub; };   /* n_sub > 1: sharded over several GPUs, sub[r] owns prefixes [r P / n_sub, (r + 1) P / n_sub) */
 #define EXT_MAGIC 0x59414b41u
 
 extern "C" {
@@ -123,9 +125,19 @@ yak_ch_t *yak_ch_init(int k, int pre, int n_hash, int n_shift)
 	return h;
 }
 
+#define YK_MULTI(e) ((e)->n_sub > 1)
+static void multi_tot(yak_ch_t *h) { yak_ch_ext *e = (yak_ch_ext*)h; uint64_t t = 0; for (int r = 0; r < e->n_sub; ++r) t += e->sub[r]->tot; h->tot = t; }
+static int multi_refuse(const yak_ch_t *h, const char *what)
+{
+	if (!YK_MULTI((const yak_ch_ext*)h)) return 0;
+	fprintf(stderr, "[E::%s] not available on a table sharded over several GPUs (YAKAMD_GPUS): count, clear, shrink, hist, get and dump are\n", what);
+	return 1;
+}
+
 void yak_ch_destroy_bf(yak_ch_t *h)
 {
 	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (YK_MULTI(e)) { for (int r = 0; r < e->n_sub; ++r) yak_ch_destroy_bf(e->sub[r]); for (int i = 0; i < 1 << h->pre; ++i) h->h[i].b = 0; return; }
 	if (h->h[0].b) free(h->h[0].b);                          /* one block of descriptors */
 	for (int i = 0; i < 1 << h->pre; ++i) h->h[i].b = 0;
 	yk_ctx_destroy_bf(e->ctx);
@@ -135,6 +147,7 @@ void yak_ch_destroy(yak_ch_t *h)
 {
 	if (h == 0) return;
 	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (YK_MULTI(e)) { for (int r = 0; r < e->n_sub; ++r) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); return; }
 	yak_ch_destroy_bf(h);
 	yk_ctx_destroy(e->ctx);
 	free(h->h); free(e);
@@ -146,6 +159,7 @@ int yak_ch_insert_list(yak_ch_t *h, int create_new, int n, const uint64_t *a)
 {
 	yak_ch_ext *e = (yak_ch_ext*)h;
 	if (n <= 0) return 0;
+	if (YK_MULTI(e)) return yak_ch_insert_list(e->sub[(a[0] & ((1ULL << h->pre) - 1)) * e->n_sub >> h->pre], create_new, n, a);   /* the owner of the list's prefix */
 	const uint64_t pm = (1ULL << h->pre) - 1;
 	std::vector<uint64_t> hv; std::vector<uint32_t> tv;
 	hv.reserve(n); tv.reserve(n);
@@ -190,6 +204,7 @@ static uint32_t ht_get(const yak_ht_t *g, uint64_t key)      /* khashl.h:137-150
 int yak_ch_get(const yak_ch_t *h, uint64_t x)                /* reference htab.c:93-100 */
 {
 	yak_ch_ext *e = (yak_ch_ext*)h;
+	if (YK_MULTI(e)) return yak_ch_get(e->sub[(x & ((1ULL << h->pre) - 1)) * e->n_sub >> h->pre], x);
 	if (yk_ctx_sync_host(e->ctx, (yak_ch_t*)h)) return -1;
 	const yak_ht_t *g = h->h[x & ((1ULL << h->pre) - 1)].h;
 	const uint32_t i = ht_get(g, x >> h->pre << YAK_COUNTER_BITS);
@@ -198,6 +213,7 @@ int yak_ch_get(const yak_ch_t *h, uint64_t x)                /* reference htab.c
 
 int yak_ch_inc(yak_ch_t *h, uint64_t x)                      /* reference htab.c:80-91 */
 {
+	if (YK_MULTI((yak_ch_ext*)h)) { yak_ch_ext *e = (yak_ch_ext*)h; return yak_ch_inc(e->sub[(x & ((1ULL << h->pre) - 1)) * e->n_sub >> h->pre], x); }
 	int c = -1;                                              /* one single-lane kernel on the table image; a valid host mirror is patched in place */
 	if (yk_ctx_inc(((yak_ch_ext*)h)->ctx, x, &c) != 0) { fprintf(stderr, "[E::%s] %s\n", __func__, yakamd_last_error()); return -1; }
 	return c;
@@ -206,12 +222,21 @@ int yak_ch_inc(yak_ch_t *h, uint64_t x)                      /* reference htab.c
 void yak_ch_clear(yak_ch_t *h, int n_thread)                 /* reference htab.c:127-130 */
 {
 	(void)n_thread;
+	if (YK_MULTI((yak_ch_ext*)h)) { yak_ch_ext *e = (yak_ch_ext*)h; for (int r = 0; r < e->n_sub; ++r) yak_ch_clear(e->sub[r], n_thread); return; }
 	yk_ctx_clear(((yak_ch_ext*)h)->ctx);
 }
 
 void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread) /* reference htab.c:199-208 */
 {
 	(void)n_thread;
+	if (YK_MULTI((yak_ch_ext*)h)) {                           /* every GPU shrinks its own sub-tables, side by side */
+		yak_ch_ext *e = (yak_ch_ext*)h;
+		std::vector<std::thread> th;
+		for (int r = 0; r < e->n_sub; ++r) th.emplace_back([=]() { yak_ch_shrink(e->sub[r], min, max, n_thread); });
+		for (auto &t : th) t.join();
+		multi_tot(h);
+		return;
+	}
 	unsigned long long tot = 0;
 	const int hi = (max >= min && max <= YAK_MAX_COUNT) ? max : YAK_MAX_COUNT;
 	if (yk_ctx_shrink(((yak_ch_ext*)h)->ctx, min, hi, &tot) == 0) h->tot = tot;
@@ -220,6 +245,7 @@ void yak_ch_shrink(yak_ch_t *h, int min, int max, int n_thread) /* reference hta
 /* reference htab.c:102-110: resize every sub-table filled to less than a third */
 void yak_ch_tighten(yak_ch_t *h)
 {
+	if (YK_MULTI((yak_ch_ext*)h)) { yak_ch_ext *e = (yak_ch_ext*)h; for (int r = 0; r < e->n_sub; ++r) yak_ch_tighten(e->sub[r]); return; }
 	if (yk_ctx_tighten(((yak_ch_ext*)h)->ctx)) fprintf(stderr, "[E::yak_ch_tighten] %s\n", yakamd_last_error());
 }
 
@@ -227,6 +253,7 @@ void yak_ch_tighten(yak_ch_t *h)
 void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
 {
 	(void)n_thread;
+	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
 	unsigned long long tot = 0;
 	if (yk_ctx_subtract(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
 	else fprintf(stderr, "[E::yak_ch_subtract] %s\n", yakamd_last_error());
@@ -235,6 +262,7 @@ void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
 void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
 {
 	(void)n_thread;
+	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
 	unsigned long long tot = 0;
 	if (yk_ctx_isec(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
 	else fprintf(stderr, "[E::yak_ch_isec] %s\n", yakamd_last_error());
@@ -246,6 +274,7 @@ void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
 void yak_ch_merge(yak_ch_t *h0, yak_ch_t *h1, int min, int max, int n_thread, int pre_resize)
 {
 	(void)n_thread;
+	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
 	yakamd_ctx *c0 = ((yak_ch_ext*)h0)->ctx, *c1 = ((yak_ch_ext*)h1)->ctx;
 	const int hi = (max >= min && max <= YAK_MAX_COUNT) ? max : YAK_MAX_COUNT;
 	u64 *d_hash = 0, n = 0; u32 *d_t = 0;
@@ -269,12 +298,19 @@ void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread) /* 
 {
 	(void)n_thread;
 	memset(cnt, 0, YAK_N_COUNTS * sizeof(int64_t));
+	if (YK_MULTI((const yak_ch_ext*)h)) {
+		const yak_ch_ext *e = (const yak_ch_ext*)h;
+		std::vector<int64_t> part(YAK_N_COUNTS);
+		for (int r = 0; r < e->n_sub; ++r) { yak_ch_hist(e->sub[r], part.data(), n_thread); for (int i = 0; i < YAK_N_COUNTS; ++i) cnt[i] += part[i]; }
+		return;
+	}
 	if (yk_ctx_hist(((yak_ch_ext*)h)->ctx, cnt)) fprintf(stderr, "[E::yak_ch_hist] %s\n", yakamd_last_error());
 }
 
 void yak_ch_setcnt(yak_ch_t *h, int cnt, int n_thread)        /* reference htab.c:219-235: every stored k-mer gets count `cnt` */
 {
 	(void)n_thread;
+	if (YK_MULTI((yak_ch_ext*)h)) { yak_ch_ext *e = (yak_ch_ext*)h; for (int r = 0; r < e->n_sub; ++r) yak_ch_setcnt(e->sub[r], cnt, n_thread); return; }
 	if (yk_ctx_setcnt(((yak_ch_ext*)h)->ctx, cnt)) fprintf(stderr, "[E::yak_ch_setcnt] %s\n", yakamd_last_error());
 }
 
@@ -294,6 +330,7 @@ static uint64_t hash64_inv(uint64_t x, uint64_t m)           /* reference yak-pr
 yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n) /* reference htab.c:353-367 */
 {
 	assert(h->k < 32 && w < 1 << h->pre);
+	if (YK_MULTI((const yak_ch_ext*)h)) { const yak_ch_ext *e = (const yak_ch_ext*)h; return yak_ch_getseq(e->sub[(uint64_t)w * e->n_sub >> h->pre], w, n); }
 	*n = 0;
 	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, (yak_ch_t*)h)) return 0;
 	const yak_ht_t *g = h->h[w].h;
@@ -314,26 +351,36 @@ yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n) /* reference hta
 int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out)
 {
 	*out = 0;
-	if (yk_ctx_sync_host(((yak_ch_ext*)h)->ctx, h)) return -1;
-	const int P = 1 << h->pre;
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	const int P = 1 << h->pre, n_sub = YK_MULTI(e) ? e->n_sub : 1;
+	/* capacities and sizes are host knowledge; the keys come packed from the device(s), 8 bytes per stored key */
+	std::vector<uint32_t> cap(P), cnt(P);
 	size_t sz = 16 + (size_t)8 * P;
-	for (int p = 0; p < P; ++p) sz += (size_t)8 * h->h[p].h->count;
+	for (int r = 0; r < n_sub; ++r) {
+		yak_ch_t *hs = YK_MULTI(e) ? e->sub[r] : h;
+		const int lo = YK_MULTI(e) ? (int)(((int64_t)r << h->pre) / n_sub) : 0, hi = YK_MULTI(e) ? (int)(((int64_t)(r + 1) << h->pre) / n_sub) : P;
+		for (int p = lo; p < hi; ++p) { if (yakamd_subtable(hs, p, &cap[p], &cnt[p]) != 0) return -1; sz += (size_t)8 * cnt[p]; }
+	}
 	uint8_t *o = (uint8_t*)malloc(sz);
+	if (!o) return -1;
 	uint32_t t[3] = { (uint32_t)h->k, (uint32_t)h->pre, YAK_COUNTER_BITS };
 	memcpy(o, YAK_MAGIC, 4); memcpy(o + 4, t, 12);
+	std::vector<uint64_t> keys;
 	size_t off = 16;
-	for (int p = 0; p < P; ++p) {
-		const yak_ht_t *g = h->h[p].h;
-		const uint32_t cap = ht_cap(g);
-		t[0] = cap; t[1] = g->count;
-		memcpy(o + off, t, 8); off += 8;
-		uint64_t *dst = (uint64_t*)(o + off);
-		uint32_t j = 0;
-		for (uint32_t w = 0; w < (cap + 31) / 32; ++w) {
-			uint32_t bits = g->used[w];
-			while (bits) { const uint32_t i = w * 32 + __builtin_ctz(bits); bits &= bits - 1; if (i < cap) dst[j++] = g->keys[i]; }
+	for (int r = 0; r < n_sub; ++r) {
+		yak_ch_t *hs = YK_MULTI(e) ? e->sub[r] : h;
+		const int lo = YK_MULTI(e) ? (int)(((int64_t)r << h->pre) / n_sub) : 0, hi = YK_MULTI(e) ? (int)(((int64_t)(r + 1) << h->pre) / n_sub) : P;
+		size_t all = 0, own_before = 0;
+		uint32_t c2, n2;
+		for (int p = 0; p < P; ++p) { yakamd_subtable(hs, p, &c2, &n2); if (p < lo) own_before += n2; all += n2; }   /* a shard holds nothing outside [lo, hi) */
+		keys.resize(all ? all : 1);
+		if (yk_ctx_dump_keys(((yak_ch_ext*)hs)->ctx, (u64*)keys.data()) != 0) { free(o); return -1; }
+		const uint64_t *src = keys.data() + own_before;
+		for (int p = lo; p < hi; ++p) {
+			t[0] = cap[p]; t[1] = cnt[p];
+			memcpy(o + off, t, 8); off += 8;
+			memcpy(o + off, src, (size_t)8 * cnt[p]); off += (size_t)8 * cnt[p]; src += cnt[p];
 		}
-		off += (size_t)8 * j;
 	}
 	*out = o;
 	return (int64_t)sz;
@@ -629,15 +676,15 @@ static int parse_threads(int n_thread)
 	return n < 1 ? 1 : n > 32 ? 32 : n;
 }
 
-/* Parsed base images live in page-locked host memory (the copy to the device is then a DMA transfer that
- * runs beside the parser threads) unless YAKAMD_PIN=0; the buffers are reused from window to window. */
+/* Parsed base images can live in page-locked host memory (YAKAMD_PIN=1: the copy to the device is then a DMA
+ * transfer); the buffers are reused from window to window. */
 extern "C++" {
 template <class T> struct PinAlloc {
 	typedef T value_type;
 	PinAlloc() {}
 	template <class U> PinAlloc(const PinAlloc<U>&) {}
 	T *allocate(size_t n) {
-		static const bool pin = !(getenv("YAKAMD_PIN") && atoi(getenv("YAKAMD_PIN")) == 0);
+		static const bool pin = getenv("YAKAMD_PIN") && atoi(getenv("YAKAMD_PIN")) != 0;   /* off by default: on the test box page-locking the buffers costs more than the staged copies of pageable memory (CLI run 1.44 s against 2.2 s) */
 		void *p = 0;
 		if (pin && hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess) return (T*)((uintptr_t)p);
 		(void)hipGetLastError();
@@ -754,9 +801,276 @@ static bool parse_parallel(int fd, int64_t size, int min_len, int n_thr, const s
 	return true;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs behind yak_count() (replaces the kt_for over prefixes, count.c:129-143).
+ * YAKAMD_GPUS = N (a divisor of 1 << pre): GPU r owns the contiguous prefixes [r P / N, (r + 1) P / N) --
+ * table, filters and all.  The input is dealt to the GPUs in chunks of YAKAMD_MGPU_CHUNK bytes of sequence:
+ * chunk j goes to GPU j % N, which extracts and groups its k-mers by prefix (yakamd_partition_dev); one
+ * exchange per round of N chunks then moves every record to the owner of its prefix -- RCCL
+ * (ncclGroupStart + ncclSend / ncclRecv pairs over xGMI, one communicator per GPU from ncclCommInitAll),
+ * or plain device copies when two ranks share a GPU (YAKAMD_GPU_LIST=0,0: one-GPU test rigs); the owner
+ * feeds the slices in chunk order, which is the stream order of the file, so the N-GPU bytes are the
+ * 1-GPU bytes.  librccl is opened only when a job asks for several distinct GPUs.
+ * ------------------------------------------------------------------------------------------ */
+struct RcclApi {
+	void *lib;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*GroupStart)(void);
+	ncclResult_t (*GroupEnd)(void);
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	const char *(*GetErrorString)(ncclResult_t);
+};
+static bool rccl_open(RcclApi *R)
+{
+	memset(R, 0, sizeof(*R));
+	R->lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!R->lib) R->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	if (!R->lib) return false;
+#define YK_SYM(f, n) *(void**)&R->f = dlsym(R->lib, n)
+	YK_SYM(CommInitAll, "ncclCommInitAll"); YK_SYM(CommDestroy, "ncclCommDestroy"); YK_SYM(GroupStart, "ncclGroupStart"); YK_SYM(GroupEnd, "ncclGroupEnd");
+	YK_SYM(Send, "ncclSend"); YK_SYM(Recv, "ncclRecv"); YK_SYM(GetErrorString, "ncclGetErrorString");
+#undef YK_SYM
+	return R->CommInitAll && R->CommDestroy && R->GroupStart && R->GroupEnd && R->Send && R->Recv;
+}
+
+struct MultiJob {
+	int N, P;
+	std::vector<int> dev;
+	std::vector<hipStream_t> st;
+	bool use_rccl;
+	RcclApi R;
+	std::vector<ncclComm_t> comm;
+	std::vector<uint8_t*> d_base;                              /* chunk of sequence on each GPU */
+	std::vector<uint64_t*> d_send, d_recv;                     /* records grouped by prefix / by source then prefix */
+	int64_t chunk, send_words, recv_words;
+};
+
+static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev)
+{
+	const char *e = getenv("YAKAMD_GPUS");
+	const int N = e ? atoi(e) : 1;
+	if (N <= 1) return 1;
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
+	if ((1 << opt->pre) % N) { fprintf(stderr, "[W::yak_count] YAKAMD_GPUS=%d does not divide the %d sub-tables: counting on one GPU\n", N, 1 << opt->pre); return 1; }
+	dev->clear();
+	if (const char *l = getenv("YAKAMD_GPU_LIST")) { for (const char *q = l; *q; ) { dev->push_back(atoi(q) % nd); while (*q && *q != ',') ++q; if (*q) ++q; } }
+	for (int r = (int)dev->size(); r < N; ++r) dev->push_back(r % nd);
+	dev->resize(N);
+	return N;
+}
+
+static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
+{
+	J->N = N; J->P = P; J->dev = dev;
+	J->st.assign(N, 0); J->d_base.assign(N, 0); J->d_send.assign(N, 0); J->d_recv.assign(N, 0);
+	const char *c = getenv("YAKAMD_MGPU_CHUNK");
+	J->chunk = c && atoll(c) > 0 ? atoll(c) : (int64_t)1 << 28;
+	J->chunk = (J->chunk + 4095) & ~(int64_t)4095;
+	J->send_words = 2 * J->chunk;                             /* one 16-byte record per position at most */
+	J->recv_words = J->send_words + J->send_words / 2 + 4096 * N;   /* the owner's share of N chunks: 1 / N each on average; refused beyond 1.5 chunks */
+	bool distinct = true;
+	for (int a = 0; a < N; ++a) for (int b = a + 1; b < N; ++b) if (dev[a] == dev[b]) distinct = false;
+	J->use_rccl = distinct && !(getenv("YAKAMD_MGPU_NO_RCCL") && atoi(getenv("YAKAMD_MGPU_NO_RCCL")));
+	if (J->use_rccl) {
+		J->comm.assign(N, 0);
+		if (!rccl_open(&J->R)) { fprintf(stderr, "[W::yak_count] librccl.so not found: exchanging with peer copies\n"); J->use_rccl = false; }
+		else { const ncclResult_t r = J->R.CommInitAll(J->comm.data(), N, dev.data()); if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; } }
+	}
+	for (int r = 0; r < N; ++r) {
+		if (hipSetDevice(dev[r]) != hipSuccess || hipStreamCreate(&J->st[r]) != hipSuccess) return false;
+		if (!J->use_rccl) for (int q = 0; q < N; ++q) if (dev[q] != dev[r]) (void)hipDeviceEnablePeerAccess(dev[q], 0);
+		J->d_base[r] = (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
+		J->d_send[r] = (uint64_t*)yakamd_dev_alloc((size_t)J->send_words * 8);
+		J->d_recv[r] = (uint64_t*)yakamd_dev_alloc((size_t)J->recv_words * 8);
+		if (!J->d_base[r] || !J->d_send[r] || !J->d_recv[r]) return false;
+	}
+	(void)hipGetLastError();
+	return true;
+}
+
+static void multi_close(MultiJob *J)
+{
+	for (int r = 0; r < J->N; ++r) {
+		hipSetDevice(J->dev[r]);
+		yakamd_dev_free(J->d_base[r]); yakamd_dev_free(J->d_send[r]); yakamd_dev_free(J->d_recv[r]);
+		if (J->st[r]) hipStreamDestroy(J->st[r]);
+		if (J->use_rccl && J->comm[r]) J->R.CommDestroy(J->comm[r]);
+	}
+}
+
+/* one round: chunk r (fill[r] bytes, stream offset t0[r]) sits on GPU r.  Partition, exchange, feed. */
+static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
+{
+	const int N = J->N, P = J->P, W = create_new ? 2 : 1;      /* words per record: {hash, position} or the hash alone */
+	std::vector<std::vector<uint64_t> > bst(N, std::vector<uint64_t>(P + 1, 0));
+	std::vector<int64_t> n_rec(N, 0);
+	std::vector<char> ok(N, 1);
+	{	/* every GPU groups the k-mers of its chunk by prefix */
+		std::vector<std::thread> th;
+		for (int r = 0; r < N; ++r) th.emplace_back([&, r]() {
+			if (fill[r] <= 0) return;
+			hipSetDevice(J->dev[r]);
+			n_rec[r] = create_new ? yakamd_partition_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
+			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data());
+			if (n_rec[r] < 0) ok[r] = 0;
+		});
+		for (auto &t : th) t.join();
+	}
+	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
+	/* receive layout of owner d: the slices of source 0, 1, ... one after the other */
+	std::vector<std::vector<uint64_t> > roff(N, std::vector<uint64_t>(N + 1, 0));
+	for (int d = 0; d < N; ++d) {
+		const int lo = d * (P / N), hi = (d + 1) * (P / N);
+		for (int r = 0; r < N; ++r) roff[d][r + 1] = roff[d][r] + (bst[r][hi] - bst[r][lo]);
+		if ((int64_t)(roff[d][N] * W) > J->recv_words) { fprintf(stderr, "[E::yak_count] GPU %d would receive %llu records in one round: prefixes too unevenly filled for YAKAMD_MGPU_CHUNK\n", d, (unsigned long long)roff[d][N]); return false; }
+	}
+	if (J->use_rccl) J->R.GroupStart();
+	for (int r = 0; r < N; ++r)
+		for (int d = 0; d < N; ++d) {
+			const int lo = d * (P / N), hi = (d + 1) * (P / N);
+			const uint64_t cnt = (bst[r][hi] - bst[r][lo]) * W;
+			if (cnt == 0) continue;
+			const uint64_t *src = J->d_send[r] + bst[r][lo] * W;
+			uint64_t *dst = J->d_recv[d] + roff[d][r] * W;
+			if (J->use_rccl && r != d) {
+				if (J->R.Send(src, cnt, ncclUint64, d, J->comm[r], J->st[r]) != ncclSuccess || J->R.Recv(dst, cnt, ncclUint64, r, J->comm[d], J->st[d]) != ncclSuccess) ok[0] = 0;
+			} else {
+				hipSetDevice(J->dev[d]);
+				if (hipMemcpyPeerAsync(dst, J->dev[d], src, J->dev[r], cnt * 8, J->st[d]) != hipSuccess) ok[0] = 0;
+			}
+		}
+	if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
+	for (int r = 0; r < N; ++r) { hipSetDevice(J->dev[r]); if (hipStreamSynchronize(J->st[r]) != hipSuccess) ok[0] = 0; }
+	if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
+	{	/* every owner takes its slices, in chunk order = stream order */
+		std::vector<std::thread> th;
+		for (int d = 0; d < N; ++d) th.emplace_back([&, d]() {
+			hipSetDevice(J->dev[d]);
+			const int lo = d * (P / N), hi = (d + 1) * (P / N);
+			std::vector<uint64_t> ob(P + 1);
+			for (int r = 0; r < N; ++r) {
+				const uint64_t cnt = roff[d][r + 1] - roff[d][r];
+				if (cnt == 0) continue;
+				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[r][q] - bst[r][lo]; }
+				const uint64_t *rec = J->d_recv[d] + roff[d][r] * W;
+				const int rc = create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r])
+				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
+				if (rc != 0) ok[d] = 0;
+			}
+		});
+		for (auto &t : th) t.join();
+	}
+	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
+	return true;
+}
+
+static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t *h0, int N, const std::vector<int> &dev)
+{
+	FxReader fx;
+	if (!fx.open_file(fn)) return 0;
+	const int P = 1 << opt->pre;
+	yak_ch_t *h = h0;
+	const int create_new = h0 ? 0 : 1;
+	if (h0 == 0) {                                             /* N tables, one per GPU, each owning its prefix range */
+		yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
+		e->magic = EXT_MAGIC; e->n_sub = N; e->sub = (yak_ch_t**)calloc(N, sizeof(yak_ch_t*));
+		h = &e->pub;
+		h->k = opt->k; h->pre = opt->pre;
+		h->h = (yak_ch1_t*)calloc((size_t)P, sizeof(yak_ch1_t));
+		bool ok = true;
+		for (int r = 0; r < N && ok; ++r) {
+			yk_ctx_next_device(dev[r]);
+			e->sub[r] = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
+			ok = e->sub[r] && yakamd_set_shard(e->sub[r], r * (P / N), (r + 1) * (P / N)) == 0;
+		}
+		if (!ok) { for (int r = 0; r < N; ++r) if (e->sub[r]) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); fx.close_file(); return 0; }
+		e->ctx = ((yak_ch_ext*)e->sub[0])->ctx;
+		h->n_hash = e->sub[0]->n_hash; h->n_shift = e->sub[0]->n_shift;
+		for (int p = 0; p < P; ++p) h->h[p].b = e->sub[0]->h[p].b;   /* descriptors only: "has a filter" for callers that look */
+	}
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	MultiJob J;
+	bool ok = multi_open(&J, N, P, dev);
+	yk_realtime();
+	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
+	std::vector<int64_t> fill(N, 0);
+	std::vector<uint64_t> t0(N, 0);
+	uint64_t t_stream = 0;
+	int64_t n_seq_tot = 0;
+	int g = 0;                                                 /* the GPU whose chunk is being filled */
+	auto round = [&]() {
+		if (ok) ok = multi_round(&J, e, opt->k, opt->pre, create_new, fill, t0);
+		std::fill(fill.begin(), fill.end(), 0); g = 0;
+	};
+	/* a piece (whole sequences, each followed by '\n') goes to the chunk being filled; a chunk is closed between two
+	 * sequences only, so no k-mer spans two GPUs */
+	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool {
+		n_seq_tot += ns;
+		while (n > 0 && ok) {
+			const size_t room = (size_t)(J.chunk - fill[g]);
+			size_t m = n;
+			if (n > room) {
+				const void *nl = room ? memrchr(img, '\n', room) : 0;
+				if (nl) m = (size_t)((const char*)nl - img) + 1;
+				else if (fill[g] > 0) { if (++g == N) round(); continue; }
+				else { fprintf(stderr, "[E::yak_count] a sequence is longer than YAKAMD_MGPU_CHUNK = %lld bytes: raise it\n", (long long)J.chunk); ok = false; break; }
+			}
+			if (fill[g] == 0) t0[g] = t_stream;
+			hipSetDevice(J.dev[g]);
+			ok = hipMemcpyAsync(J.d_base[g] + fill[g], img, m, hipMemcpyHostToDevice, J.st[g]) == hipSuccess && hipStreamSynchronize(J.st[g]) == hipSuccess;
+			fill[g] += (int64_t)m; t_stream += m; img += m; n -= m;
+			if (fill[g] == J.chunk || n > 0) { if (++g == N) round(); }
+		}
+		return ok;
+	};
+	const int n_thr = parse_threads(opt->n_thread);
+	int64_t par_size = -1;
+	if (fx.fd >= 0 && n_thr > 1) { struct stat sb; if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) par_size = sb.st_size; }
+	if (ok && par_size >= 0) ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, take_piece);
+	else if (ok) {
+		std::vector<char> piece;
+		int64_t l, ns = 0;
+		for (;;) {
+			if ((l = fx.fast(piece, opt->k)) == FxReader::NOT_FAST) {
+				if ((l = fx.next()) < 0) break;
+				if (l >= opt->k) { piece.insert(piece.end(), fx.seq.begin(), fx.seq.end()); piece.push_back('\n'); }
+			}
+			if (l >= opt->k) ++ns;
+			if (piece.size() >= ((size_t)1 << 24)) { if (!take_piece(piece.data(), piece.size(), ns)) break; piece.clear(); ns = 0; }
+		}
+		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns);
+	}
+	if (ok) { bool any = false; for (int r = 0; r < N; ++r) any = any || fill[r] > 0; if (any) round(); }
+	{	/* every GPU finishes its pass: partitions, counting, layout -- side by side */
+		std::vector<int64_t> n_ins(N, 0);
+		std::vector<std::thread> th;
+		for (int r = 0; r < N; ++r) th.emplace_back([&, r]() { n_ins[r] = yakamd_pass_end(e->sub[r]); });
+		for (auto &t : th) t.join();
+		for (int r = 0; r < N; ++r) { if (n_ins[r] < 0) ok = false; else e->sub[r]->tot += (uint64_t)n_ins[r]; }
+	}
+	multi_close(&J);
+	multi_tot(h);
+	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, J.use_rccl ? "RCCL exchange" : "peer copies");
+	fx.close_file();
+	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
+	return h;
+}
+
 /* reference count.c:147-166 */
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 {
+	{
+		std::vector<int> dev;
+		const int N = h0 ? ((yak_ch_ext*)h0)->n_sub : multi_gpus(opt, &dev);
+		if (N > 1) {
+			if (h0) { dev.clear(); for (int r = 0; r < N; ++r) dev.push_back(yk_ctx_device(((yak_ch_ext*)((yak_ch_ext*)h0)->sub[r])->ctx)); }
+			return yak_count_multi(fn, opt, h0, N, dev);
+		}
+	}
 	FxReader fx;
 	if (!fx.open_file(fn)) return 0;                         /* count.c:152 */
 	yak_ch_t *h;
