@@ -469,17 +469,17 @@ def main():
         {"kernel": "k_xpart (extract + level-1 partition, both passes)", "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),
          "launches": 2 * n_batches * (2 if s2 else 1), "bytes": 8.0 * (n1 + n2)},   # histogram + scatter per device batch
         {"kernel": "k_part2 (level-2 partition)", "ms": s1["ms_part2"], "launches": 2, "bytes": 8.0 * n1},
-        {"kernel": "k_lds_count (insert + bloom gate)" if s1["ms_part2"] > 0 else "k_acc_insert", "ms": s1["ms_insert"],
+        {"kernel": "k_lc2 (insert + bloom gate)" if s1["ms_part2"] > 0 else "k_acc_insert", "ms": s1["ms_insert"],
          "launches": max(1, s1["n_dominant_launches"]), "bytes": b_insert * n1, "bytes_no_bloom_model": B_INSERT * n1},
     ]
     if s2:
         st_after = last_stats[0]
-        kern.append({"kernel": "k_img_count (pass 2 lookup)", "ms": s2["ms_insert"], "launches": max(1, s2["n_dominant_launches"]),
+        kern.append({"kernel": "k_img_count_own (pass 2 lookup)", "ms": s2["ms_insert"], "launches": max(1, s2["n_dominant_launches"]),
                      "bytes": (B_LOOKUP + 8.0 * f_hit) * n2})
-        kern.append({"kernel": "k_replay (exact khashl layout: pass 1 + shrink)", "ms": s1["ms_replay"] + st_after["ms_shrink"],
+        kern.append({"kernel": "k_r2_* + k_replay (exact khashl layout: pass 1 + shrink)", "ms": s1["ms_replay"] + st_after["ms_shrink"],
                      "launches": 2, "bytes": 16.0 * (s1["n_new_keys"] + tot_all / max(1, world))})
     else:
-        kern.append({"kernel": "k_replay (exact khashl layout)", "ms": s1["ms_replay"], "launches": 1, "bytes": 16.0 * s1["n_new_keys"]})
+        kern.append({"kernel": "k_r2_* + k_replay (exact khashl layout)", "ms": s1["ms_replay"], "launches": 1, "bytes": 16.0 * s1["n_new_keys"]})
     for k_ in kern:
         k_["avg_launch_ms"] = k_["ms"] / k_["launches"]
         k_["achieved_GBs"] = k_["bytes"] / (k_["ms"] * 1e-3) / 1e9 if k_["ms"] > 0 else 0.0
@@ -488,12 +488,12 @@ def main():
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     except Exception:
         pass
     for k_ in kern:
-        key = k_["kernel"].split(" ")[0]
-        cand = [v for n_, v in pmc.items() if n_.startswith(key) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 else []
+        keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
+        cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift == 37 else []
         k_["traffic_bytes"] = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
     # the pass and the step as a whole against the same roof: SURVEY 8(d)'s algorithmic bytes of every instance
     # the pass consumed / its wall-clock time (pass 1 with and without the exact-layout tail: sort + replay)
@@ -527,7 +527,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS,
                      "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
-                     "traffic_source": "profiles/r01k_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2)",
+                     "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)",
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,
                      "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),
