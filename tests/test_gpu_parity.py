@@ -246,6 +246,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_OWN_LDS="19500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_LC2="0"), dict(YAKAMD_LC2="0", YAKAMD_S2_BITS="4"),
                                  dict(YAKAMD_LC2_WGS="3"),
+                                 dict(YAKAMD_REC8="0"), dict(YAKAMD_REC8_OUT="0"), dict(YAKAMD_REC8_OUT="0", YAKAMD_BATCH="16384"), dict(YAKAMD_BATCH="8192", YAKAMD_S2_BITS="3"),
                                  dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576")],
@@ -255,6 +256,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "count_with_device_atomics", "count_lds_rank_kernel",
                               "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
                               "lc2_three_persistent_workgroups",
+                              "rec16_records", "tagged_in_rec16_out", "tagged_in_rec16_out_multibatch", "tagged_multibatch_s2_3",
                               "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
@@ -334,7 +336,7 @@ def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
     for key, vals in (("YAKAMD_BATCH", [None, None, "4096", "65536", "1048576"]), ("YAKAMD_S2_BITS", [None, None, None, "0", "2", "5", "9"]),
                       ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096", "32768"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
                       ("YAKAMD_COUNT_OWN", [None, None, "0"]), ("YAKAMD_OWN_LDS", [None, None, "18500", "24000"]), ("YAKAMD_OWN_MAXRB", [None, "12"]), ("YAKAMD_LC2", [None, None, None, "0"]),
-                      ("YAKAMD_R2_SMALL_BITS", [None, "5", "6", "8"]), ("YAKAMD_R2_SEG_LOG", [None, "10", "11", "12"]), ("YAKAMD_REPLAY2", [None, None, None, "0"]),
+                      ("YAKAMD_R2_SMALL_BITS", [None, "5", "6", "8"]), ("YAKAMD_R2_SEG_LOG", [None, "10", "11", "12"]), ("YAKAMD_REPLAY2", [None, None, None, "0"]), ("YAKAMD_REC8", [None, None, "0"]), ("YAKAMD_REC8_OUT", [None, None, "0"]),
                       ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_XP_WC", [None, None, "0", "1", "2"]), ("YAKAMD_FAST", [None, None, None, "0"])):
         v = rnd.choice(vals)
         if v is not None:

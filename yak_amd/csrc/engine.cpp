@@ -190,7 +190,7 @@ struct yakamd_ctx {
 	uint8_t *d_stage; int64_t stage_cap;
 	u32 *d_rows; u64 *d_partial, *d_bstart; int rows_blk; int nb_bits;
 	/* fast path: level-1 partitioned batches kept until pass_end */
-	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; bool owned; };
+	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; bool owned; int fmt; };   /* fmt 1: tagged 8-byte records (yk_device.h YK_R8_*) */
 	std::vector<Kept> kept;
 	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set; u64 keys_at_begin;
 	double ms_part2, ms_lds;
@@ -689,6 +689,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 /* leave the fast path: push every kept batch through the accumulator path, in stream order */
 static int fast_abandon(yakamd_ctx *c)
 {
+	for (auto &k : c->kept) if (k.fmt) return fail("a batch was fed out of stream order after tagged 8-byte batches were kept: feed in order, or set YAKAMD_REC8=0");
 	c->fast = false;
 	Rec *keep = c->d_rec;
 	int r = 0;
@@ -714,11 +715,12 @@ static int fast_flush_slice(yakamd_ctx *c)
 
 /* may this batch (n_pos stream positions starting at time t) stay on the fast path?  If so,
  * allocate its level-1 output buffers */
-static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec *borrowed = 0)
+static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec *borrowed = 0, int fmt = 0)
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
-	const u64 cost = borrowed ? 0 : n_cap * 16;                  /* a borrowed buffer is the caller's memory */
+	const u64 cost = borrowed ? 0 : n_cap * (fmt ? 8 : 16);      /* a borrowed buffer is the caller's memory */
 	bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + cost <= c->fast_budget;
+	if (!c->kept.empty() && c->kept.back().fmt != fmt) fits = false;   /* tagged records carry ranks, Rec records stream positions: never in one slice */
 	if (!fits && !c->kept.empty() && t >= c->t_end && n_pos < 0xfffffff0ull && cost <= c->fast_budget && !c->acc.s) {
 		/* the kept batches are a complete prefix of the stream: count them now, exactly as if the pass
 		 * ended here (table, filter and counts carry over; the next slice meets them as existing state --
@@ -729,8 +731,8 @@ static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec
 	}
 	if (!fits) { if (fast_abandon(c)) return -1; return 0; }
 	yakamd_ctx::Kept k;
-	k.d_rec = borrowed; k.n = 0; k.t0 = t; k.span = n_pos; k.owned = !borrowed;
-	if (!borrowed && dmalloc(&k.d_rec, (size_t)n_cap)) return -1;
+	k.d_rec = borrowed; k.n = 0; k.t0 = t; k.span = n_pos; k.owned = !borrowed; k.fmt = fmt;
+	if (!borrowed && dmalloc(&k.d_rec, (size_t)(fmt ? (n_cap + 1) / 2 : n_cap))) return -1;
 	c->kept_bytes += cost;
 	c->kept.push_back(k);
 	*out = k.d_rec;
@@ -766,13 +768,15 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 		u64 n_rec = 0;
 		Rec *out = c->d_rec;
 		if (c->fast) {                                   /* the batch stays resident until pass_end */
-			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &out)) return -1;
+			/* tagged 8-byte records (half the partition traffic) when the hash leaves room for the tag: (hash >> pre) < 2^52 */
+			const int fmt = c->k < 32 && 2 * c->k - c->pre <= 64 - YK_R8_TAG_BITS && c->nb_bits == c->pre && c->nb_bits <= 10 && !c->or_mode && env_i64("YAKAMD_REC8", 1) != 0;
+			if (fast_admit(c, t0 + (u64)pos, (u64)(end - pos), (u64)(end - pos), &out, 0, fmt)) return -1;
 			if (!c->fast) { if (rec_reserve(c, bmax)) return -1; out = c->d_rec; }   /* the pass has just left the fast path */
 		}
 		{
 			EvTimer tm(c->st);
 			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
-			                c->d_rows, c->d_partial, c->d_bstart, out, hash_only, c->st);
+			                c->d_rows, c->d_partial, c->d_bstart, out, (c->fast && c->kept.back().fmt) ? 2 : hash_only, c->st);
 			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 			c->st_cur.ms_extract += tm.stop();
 		}
@@ -1306,6 +1310,8 @@ static int fast_finish(yakamd_ctx *c)
 	const int P = c->P;
 	u64 n_total = 0;
 	for (auto &k : c->kept) n_total += k.n;
+	const int fmt_in = c->kept.empty() ? 0 : c->kept.front().fmt;
+	u64 sort_tmax = c->t_end;
 	FastParams fp;
 	fp.pre = c->pre; fp.k = c->k; fp.bloom_mode = c->bloom_mode; fp.nb = c->nb; fp.n_hash = c->n_hash;
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
@@ -1322,6 +1328,8 @@ static int fast_finish(yakamd_ctx *c)
 	}
 	fp.s2_bits = s2;
 	fp.bf_virgin = 0;
+	fp.rec8_in = fmt_in; fp.tb = YK_R8_TAG_BITS + s2;
+	fp.rec8_out = 0;                                         /* set below, once the largest sub-table stream is known */
 	if (c->bloom_mode) {
 		if (c->bf_virgin && c->nb - 9 - s2 <= 7) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
 		else if (bloom_materialise(c)) return -1;
@@ -1332,6 +1340,7 @@ static int fast_finish(yakamd_ctx *c)
 	std::vector<Chunk2> chunks;
 	std::vector<u32> chunk_first(P + 1, 0);
 	std::vector<u64> bbase(P + 1, 0);
+	u64 np_max = 0;
 	for (int p = 0; p < P; ++p) {
 		chunk_first[p] = (u32)chunks.size();
 		u64 np = 0;
@@ -1339,18 +1348,26 @@ static int fast_finish(yakamd_ctx *c)
 			const u64 a = k.bstart[p], b = k.bstart[p + 1];
 			for (u64 o = a; o < b; o += ch2) {
 				Chunk2 ch;
-				ch.rec = k.d_rec + o; ch.spare = 0;
+				ch.rec = fmt_in ? (const Rec*)((const u64*)k.d_rec + o) : k.d_rec + o; ch.spare = 0;
 				ch.n = (u32)std::min<u64>(ch2, b - o); ch.bucket = (u32)p;
-				ch.tbase = (u32)(k.t0 - c->t_pass0); ch.pad = 0;
+				ch.tbase = fmt_in ? (u32)np : (u32)(k.t0 - c->t_pass0); ch.pad = (u32)fmt_in;   /* tagged: ranks continue from the earlier batches of this sub-table */
+				ch.before = (u32)(o - a); ch.after = (u32)(b - (o + ch.n));
 				chunks.push_back(ch);
 			}
 			np += b - a;
 		}
+		np_max = std::max(np_max, np);
 		bbase[p + 1] = bbase[p] + np;
 		if (chunks.size() > chunk_first[p]) chunks.back().spare = 1;   /* last chunk of its sub-table */
 	}
 	chunk_first[P] = (u32)chunks.size();
 	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
+	if (fmt_in) {
+		if (np_max >= (1ull << 32)) return fail("more than 2^32 k-mer instances of one sub-table in one slice");
+		fp.rec8_out = np_max < (1ull << fp.tb) && env_i64("YAKAMD_REC8_OUT", 1) != 0;   /* the rank must fit below the hash bits; else 16-byte records {hash, rank} */
+		fp.t_pass0 = 0;                                       /* times are ranks inside the sub-table's stream of this slice */
+		sort_tmax = np_max;
+	}
 
 	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0; Rec *d_r2 = 0;
 	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
@@ -1363,7 +1380,7 @@ static int fast_finish(yakamd_ctx *c)
 		dfree(d_scr); dfree(d_scroff);
 	} };
 	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2) ||
-	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, fp.rec8_out ? (n_total + 1) / 2 : n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
 	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
@@ -1436,7 +1453,7 @@ static int fast_finish(yakamd_ctx *c)
 	HIPCK(hipMemcpyAsync(d_segbase, ro.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	{
 		EvTimer tm(c->st);
-		yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, c->t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
+		yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
 		c->st_cur.ms_select += tm.stop();
 	}
 	{
@@ -1450,7 +1467,7 @@ static int fast_finish(yakamd_ctx *c)
 	int cur = 0;
 	{
 		EvTimer tm(c->st);
-		const int tbits = std::max(1, ceil_log2_u64(c->t_end + 1));
+		const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
 		for (int shift = 0; shift < tbits; shift += 8) {
 			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
 			cur ^= 1;

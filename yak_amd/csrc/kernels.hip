@@ -265,7 +265,7 @@ __device__ __forceinline__ u32 bucket_of(u64 h, int pre, int nb_bits)
 	return nb_bits <= pre ? p >> (pre - nb_bits) : p;   /* nb_bits is clamped to pre by the host */
 }
 
-template <int MODE>   /* 0 = histogram, 1 = scatter {hash, position}, 2 = scatter hash only (count-existing passes) */
+template <int MODE>   /* 0 = histogram, 1 = scatter {hash, position}, 2 = scatter hash only (count-existing passes), 3 = histogram that also counts, per bucket, the 1024-position rounds that contribute to it (count | rounds << 24) */
 __global__ __launch_bounds__(XT_THREADS)
 void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
              int nb_bits, u32 *rows, Rec *__restrict__ out)
@@ -274,7 +274,9 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 	__shared__ XtTile S;
 	const int NB = 1 << nb_bits;
 	u32 *row = rows + (size_t)blockIdx.x * NB;
-	for (int j = threadIdx.x; j < NB; j += XT_THREADS) s_bkt[j] = MODE ? row[j] : 0;
+	u32 *s_lastr = s_bkt + NB, *s_nr = s_bkt + 2 * NB;                /* MODE 3 only */
+	if (MODE == 3) for (int j = threadIdx.x; j < NB; j += XT_THREADS) { s_lastr[j] = 0; s_nr[j] = 0; }
+	for (int j = threadIdx.x; j < NB; j += XT_THREADS) s_bkt[j] = (MODE == 1 || MODE == 2) ? row[j] : 0;
 	xt_init(S);
 	const u64 mask = k < 32 ? (1ull << (2 * k)) - 1 : ~0ull, kones = (1ull << k) - 1;
 	const u32 pmask = (1u << pre) - 1;
@@ -290,14 +292,21 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 			const u32 p = (u32)h & pmask;
 			ok = ok && (int)p >= plo && (int)p < phi;
 			if (ok) {
-				const u32 d = atomicAdd(&s_bkt[bucket_of(h, pre, nb_bits)], 1u);
+				const u32 bk = bucket_of(h, pre, nb_bits);
+				const u32 d = atomicAdd(&s_bkt[bk], 1u);
 				if (MODE == 1) out[d] = make_ulonglong2(h, (u64)(u32)(tile0 + r * XT_THREADS + threadIdx.x - t_sub));
 				if (MODE == 2) ((u64*)out)[d] = h;
+				if (MODE == 3) {                                        /* waves drift apart inside a tile: a bit per round, counted at the end */
+					const u32 R = (u32)t * (XT_TILE / 1024) + (u32)r * XT_THREADS / 1024;
+					static_assert(XP_T * (XT_TILE / 1024) <= 64, "one bit per round in two words");
+					atomicOr(R < 32 ? &s_lastr[bk] : &s_nr[bk], 1u << (R & 31));
+				}
 			}
 		}
 		__syncthreads();
 	}
-	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += XT_THREADS) row[j] = s_bkt[j]; }
+	if (MODE == 0) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += XT_THREADS) row[j] = s_bkt[j]; }
+	if (MODE == 3) { __syncthreads(); for (int j = threadIdx.x; j < NB; j += XT_THREADS) row[j] = s_bkt[j] | (u32)(__popc(s_lastr[j]) + __popc(s_nr[j])) << 24; }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -374,6 +383,86 @@ __device__ __forceinline__ void wc_drain(const WcView &w, int NB, void *out)
 	}
 }
 
+/* The same write combining, STABLE at round granularity (tagged 8-byte records, groups of 8): a record that finds its stack
+ * full is stored at once at its final place, head + position in the stack's count, and the flush of that round then empties the
+ * whole stack in front of it -- so inside a bucket the records of a round stay together and the rounds stay in order.  Uses
+ * w.tail as the per-bucket toggle. */
+template <int CAP>
+__device__ __forceinline__ void wcs_place(const WcView &w, u32 b, u64 v, u32 par, u64 *out)
+{
+	const u32 pos = atomicAdd(&w.cnt[b], 1u), h0 = w.head[b];
+	if (pos < (u32)CAP) w.h[b * CAP + pos] = v; else out[h0 + pos] = v;
+	if (pos == 7u - (h0 & 7u)) w.task[atomicAdd(&w.ntask[par], 1u)] = b;
+}
+template <int CAP>
+__device__ __forceinline__ void wcs_flush(const WcView &w, u32 par, u64 *out)
+{
+	const u32 nt = w.ntask[par], q = threadIdx.x & 7;
+	for (u32 ti = threadIdx.x / 8; ti < nt; ti += blockDim.x / 8) {
+		const u32 b = w.task[ti];
+		const u32 cn = w.cnt[b], h0 = w.head[b];
+		if (cn > (u32)CAP) {                                            /* the round overflowed the stack: everything goes, the direct stores sit behind it */
+			for (u32 i = q; i < (u32)CAP; i += 8) out[h0 + i] = w.h[b * CAP + i];
+			__builtin_amdgcn_wave_barrier();
+			if (q == 0) { w.head[b] = h0 + cn; w.cnt[b] = 0; }
+			continue;
+		}
+		const u32 need = 8 - (h0 & 7);
+		const u32 two = cn - need >= 8u;
+		const u32 flushed = need + 8 * two, rem = cn - flushed;
+		if (q < need) out[h0 + q] = w.h[b * CAP + q];
+		if (two) out[h0 + need + q] = w.h[b * CAP + need + q];
+		u64 mh = 0;
+		if (q < rem) mh = w.h[b * CAP + flushed + q];
+		__builtin_amdgcn_wave_barrier();
+		if (q < rem) w.h[b * CAP + q] = mh;
+		if (q == 0) { w.head[b] = h0 + flushed; w.cnt[b] = rem; }
+	}
+	if (threadIdx.x == 0) w.ntask[par ^ 1] = 0;
+}
+
+#define XW_CAP_S 7                                     /* 2 workgroups per CU; the 8th record of a group is stored directly and takes the stack with it */
+template <bool TAG>   /* TAG: tagged records (rows carry the toggle); else bare hashes for the count-existing passes (plain rows) */
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))    /* two workgroups per CU: <= 64 VGPRs and <= 80 SGPRs */
+void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int k, int pre, int plo, int phi,
+                 int nb_bits, const u32 *__restrict__ rows, u64 *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ XtTile S;
+	const int NB = 1 << nb_bits, tid = threadIdx.x;
+	WcView w;
+	wc_carve<8, XW_CAP_S, false>(w, s_dyn, NB, 1024);
+	const u32 *row = rows + (size_t)blockIdx.x * NB;
+	for (int b = tid; b < NB; b += 1024) { const u32 v = row[b]; w.cnt[b] = 0; w.head[b] = TAG ? v & 0x7fffffffu : v; w.tail[b] = v >> 31; }
+	if (tid < 2) w.ntask[tid] = 0;
+	xt_init(S);
+	const u64 mask = (1ull << (2 * k)) - 1, kones = (1ull << k) - 1;
+	const u32 pmask = (1u << pre) - 1;
+	u32 par = 0;
+	for (int t = 0; t < XP_T; ++t) {
+		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
+		if (tile0 >= n) break;
+		xt_load(S, bases, tile0, n);
+		for (int r = 0; r < XT_TILE / 1024; ++r, par ^= 1) {
+			u64 h;
+			bool ok = xt_kmer(S, r * 1024 + tid, k, mask, kones, tile0, n, &h);
+			const u32 p = (u32)h & pmask;
+			ok = ok && (int)p >= plo && (int)p < phi;
+			u32 bk = 0, tg = 0;
+			if (ok) {
+				bk = bucket_of(h, pre, nb_bits);
+				if (TAG) tg = w.tail[bk];
+				wcs_place<XW_CAP_S>(w, bk, TAG ? (h >> pre) << YK_R8_TAG_BITS | (u64)(tg << 10) | (u32)tid : h, par, out);
+			}
+			__syncthreads();
+			if (TAG && ok) w.tail[bk] = tg ^ 1;                           /* every lane of the bucket writes the same value: the next contributing round gets the other toggle */
+			wcs_flush<XW_CAP_S>(w, par, out);
+			__syncthreads();
+		}
+	}
+	wc_drain<8, XW_CAP_S, false>(w, NB, out);
+}
+
 /* k_xpart's scatter with write combining: 1024 threads, one round = one quarter tile */
 #define XW_NT 1024
 #define XW_CAP_T 6          /* {hash, position}: groups of 4 */
@@ -448,6 +537,8 @@ void k_rpart(const u64 *__restrict__ in_hash, const u32 *__restrict__ in_t, int6
  * bstart[b] = first record of bucket b, bstart[NB] = total.  Rows are summed in PS_G groups so the
  * scan is three short, wide kernels instead of one long serial one. */
 #define PS_G 64
+#define PS_PAR (1ull << 63)
+template <bool PAR>   /* PAR: rows hold count | contributing rounds << 24; bit 63 of the sums carries the parity of the rounds */
 __global__ __launch_bounds__(256)
 void k_part_sum(const u32 *rows, int n_blk, int NB, u64 *partial)
 {
@@ -455,7 +546,7 @@ void k_part_sum(const u32 *rows, int n_blk, int NB, u64 *partial)
 	if (b >= NB) return;
 	const int per = (n_blk + PS_G - 1) / PS_G, lo = g * per, hi = lo + per < n_blk ? lo + per : n_blk;
 	u64 acc = 0;
-	for (int i = lo; i < hi; ++i) acc += rows[(size_t)i * NB + b];
+	for (int i = lo; i < hi; ++i) { const u32 v = rows[(size_t)i * NB + b]; if (PAR) acc = (acc + (v & 0xffffffu)) ^ ((u64)(v >> 24 & 1) << 63); else acc += v; }
 	partial[(size_t)g * NB + b] = acc;
 }
 
@@ -469,7 +560,8 @@ void k_part_mid(u64 *partial, int NB, u64 *bstart)
 	for (int b0 = 0; b0 < NB; b0 += 256) {
 		const int b = b0 + threadIdx.x;
 		u64 run = 0;
-		if (b < NB) for (int g = 0; g < PS_G; ++g) { const u64 c = partial[(size_t)g * NB + b]; partial[(size_t)g * NB + b] = run; run += c; }
+		if (b < NB) for (int g = 0; g < PS_G; ++g) { const u64 c = partial[(size_t)g * NB + b]; partial[(size_t)g * NB + b] = run; run = (run + (c & ~PS_PAR)) ^ (c & PS_PAR); }   /* bit 63: parity of the rounds so far (always 0 without PAR) */
+		run &= ~PS_PAR;
 		s_tot[threadIdx.x] = run;
 		__syncthreads();
 		if (threadIdx.x == 0) {
@@ -484,22 +576,31 @@ void k_part_mid(u64 *partial, int NB, u64 *bstart)
 	if (threadIdx.x == 0) bstart[NB] = s_carry;
 }
 
+template <bool PAR>
 __global__ __launch_bounds__(256)
 void k_part_fin(u32 *rows, int n_blk, int NB, const u64 *partial, const u64 *bstart)
 {
 	const int b = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
 	if (b >= NB) return;
 	const int per = (n_blk + PS_G - 1) / PS_G, lo = g * per, hi = lo + per < n_blk ? lo + per : n_blk;
-	u64 run = bstart[b] + partial[(size_t)g * NB + b];
-	for (int i = lo; i < hi; ++i) { const u32 c = rows[(size_t)i * NB + b]; rows[(size_t)i * NB + b] = (u32)run; run += c; }
+	const u64 pg = partial[(size_t)g * NB + b];
+	u64 run = bstart[b] + (pg & ~PS_PAR);
+	u32 par = (u32)(pg >> 63);
+	for (int i = lo; i < hi; ++i) {
+		const u32 c = rows[(size_t)i * NB + b];
+		if (PAR) { rows[(size_t)i * NB + b] = (u32)run | par << 31; run += c & 0xffffffu; par ^= c >> 24 & 1; }   /* start (< 2^31) | toggle of the workgroup's first contributing round */
+		else { rows[(size_t)i * NB + b] = (u32)run; run += c; }
+	}
 }
 
-static void launch_part_scan(u32 *rows, int n_blk, int nb_bits, u64 *partial, u64 *bstart, hipStream_t st)
+static void launch_part_scan(u32 *rows, int n_blk, int nb_bits, u64 *partial, u64 *bstart, hipStream_t st, bool par = false)
 {
 	const int NB = 1 << nb_bits;
-	hipLaunchKernelGGL(k_part_sum, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial);
+	if (par) hipLaunchKernelGGL(k_part_sum<true>, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial);
+	else hipLaunchKernelGGL(k_part_sum<false>, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial);
 	hipLaunchKernelGGL(k_part_mid, dim3(1), dim3(256), 0, st, partial, NB, bstart);
-	hipLaunchKernelGGL(k_part_fin, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial, bstart);
+	if (par) hipLaunchKernelGGL(k_part_fin<true>, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial, bstart);
+	else hipLaunchKernelGGL(k_part_fin<false>, dim3((NB + 255) / 256, PS_G), dim3(256), 0, st, rows, n_blk, NB, partial, bstart);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2544,7 +2645,63 @@ __device__ __forceinline__ u32 sub_of(u64 h, const FastParams &fp)
 		const int bb = fp.nb - 9;
 		return (u32)((x & ((1ull << bb) - 1)) >> (bb - fp.s2_bits));
 	}
-	return (u32)((x * 0x9E3779B97F4A7C15ull) >> (64 - fp.s2_bits));
+	return (u32)x & ((1u << fp.s2_bits) - 1);                          /* yak_hash64 mixes well: any bit slice is uniform */
+}
+
+/* ---- the two 8-byte record formats of the fast path (yk_device.h YK_R8_*, FastParams.rec8_*) ---- */
+/* rank of tagged record i in its bucket's stream: records of one round are contiguous and share the toggle bit; inside the round
+ * the position field orders them.  `src` points at the chunk's first record; [-before, n + after) is the bucket */
+__device__ __forceinline__ u32 r8_rank(const u64 *src, int64_t i, u32 before, u32 n, u32 after)
+{
+	const u64 me = src[i];
+	const u32 tg = (u32)me & YK_R8_TOGGLE, pos = (u32)me & 1023u;
+	int64_t a = i, e = i + 1;
+	while (a > -(int64_t)before && ((u32)src[a - 1] & YK_R8_TOGGLE) == tg) --a;
+	while (e < (int64_t)n + after && ((u32)src[e] & YK_R8_TOGGLE) == tg) ++e;
+	u32 r = 0;
+	for (int64_t j = a; j < e; ++j) r += ((u32)src[j] & 1023u) < pos;
+	return (u32)((int64_t)before + a) + r;
+}
+/* one level-2 input record -> (hash, time): Rec {hash, position} + tbase, or a tagged record of sub-table c.bucket */
+template <bool NEED_T>
+__device__ __forceinline__ void p2_load(const Chunk2 &c, u32 i, const FastParams &fp, u64 *h, u32 *t)
+{
+	if (c.pad == 1) {
+		const u64 *src = (const u64*)c.rec;
+		*h = (src[i] >> YK_R8_TAG_BITS) << fp.pre | c.bucket;
+		if (NEED_T) *t = c.tbase + r8_rank(src, (int64_t)i, c.before, c.n, c.after);
+	} else {
+		const Rec rc = c.rec[i];
+		*h = rc.x;
+		if (NEED_T) *t = (u32)rc.y + c.tbase;
+	}
+}
+/* level-2 output / counting input: the sub-bucket's bits taken out of hash >> pre, the rank below it */
+__device__ __forceinline__ u64 r8_pack(u64 h, u32 t, const FastParams &fp)
+{
+	const u64 x = h >> fp.pre;
+	const int sh = fp.bloom_mode ? fp.nb - 9 - fp.s2_bits : 0;
+	return (((x >> (sh + fp.s2_bits)) << sh) | (x & ((1ull << sh) - 1))) << fp.tb | t;
+}
+__device__ __forceinline__ Rec r8_unpack(u64 r, u32 sb, const FastParams &fp)
+{
+	const u64 xs = r >> fp.tb;
+	const int sh = fp.bloom_mode ? fp.nb - 9 - fp.s2_bits : 0;
+	const u64 x = ((xs >> sh) << (sh + fp.s2_bits)) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << sh) | (xs & ((1ull << sh) - 1));
+	return make_ulonglong2(x << fp.pre | (sb >> fp.s2_bits), r & ((1ull << fp.tb) - 1));
+}
+__device__ __forceinline__ Rec lc_rec(const FastParams &fp, const Rec *rec, u64 i, u32 sb)
+{
+	return fp.rec8_out ? r8_unpack(((const u64*)rec)[i], sb, fp) : rec[i];
+}
+/* the same in two steps, for loads that are requested long before they are used (decoding at once would wait for the data) */
+__device__ __forceinline__ Rec lc_raw(const FastParams &fp, const Rec *rec, u64 i)
+{
+	return fp.rec8_out ? make_ulonglong2(((const u64*)rec)[i], 0) : rec[i];
+}
+__device__ __forceinline__ Rec lc_dec(const FastParams &fp, const Rec raw, u32 sb)
+{
+	return fp.rec8_out ? r8_unpack(raw.x, sb, fp) : raw;
 }
 
 template <int MODE>   /* 0 = histogram, 1 = scatter */
@@ -2558,9 +2715,10 @@ void k_part2(const Chunk2 *chunks, FastParams fp, u32 *rows2, Rec *__restrict__ 
 	for (int j = threadIdx.x; j < S2; j += NT) s_bkt[j] = MODE ? row[j] : 0;
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < c.n; i += NT) {
-		const Rec rc = c.rec[i];
-		const u32 d = atomicAdd(&s_bkt[sub_of(rc.x, fp)], 1u);
-		if (MODE) out[d] = make_ulonglong2(rc.x, (u64)((u32)rc.y + c.tbase));
+		u64 h; u32 t = 0;
+		p2_load<MODE != 0>(c, i, fp, &h, &t);
+		const u32 d = atomicAdd(&s_bkt[sub_of(h, fp)], 1u);
+		if (MODE) { if (fp.rec8_out) ((u64*)out)[d] = r8_pack(h, t, fp); else out[d] = make_ulonglong2(h, (u64)t); }
 	}
 	if (!MODE) { __syncthreads(); for (int j = threadIdx.x; j < S2; j += NT) row[j] = s_bkt[j]; }
 }
@@ -2590,20 +2748,98 @@ void k_part2_wc(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ row
 		}
 		if (tid < 2) w.ntask[tid] = 0;
 		__syncthreads();
-		Rec nxt = tid < c.n ? c.rec[tid] : make_ulonglong2(0, 0);
 		for (u32 rd = 0; rd < n_round; ++rd) {
 			const u32 i = rd * WC_NT + tid, par = rd & 1;
-			const Rec rc = nxt;
-			if (i + WC_NT < c.n) nxt = c.rec[i + WC_NT];
 			if (i < c.n) {
-				const u32 sub = sub_of(rc.x, fp) - (u32)seg0;
-				if (sub < (u32)SEG) wc_place<4, WC_CAP, true>(w, sub, rc.x, (u32)rc.y + c.tbase, par, out);
+				u64 h; u32 t;
+				p2_load<true>(c, i, fp, &h, &t);
+				const u32 sub = sub_of(h, fp) - (u32)seg0;
+				if (sub < (u32)SEG) wc_place<4, WC_CAP, true>(w, sub, h, t, par, out);
 			}
 			__syncthreads();
 			wc_flush<4, WC_CAP, true>(w, par, out);
 			__syncthreads();
 		}
 		wc_drain<4, WC_CAP, true>(w, SEG, out);
+	}
+}
+
+/* the level-2 scatter for 8-byte output records: groups of 8 (64 bytes), one stack of WC8_CAP entries per sub-bucket (no tail
+ * array: a record that finds its stack full is stored at its final place, wcs_place / wcs_flush) */
+#define WC8_CAP 8
+/* Input: tagged records only (fp.rec8_in).  The rank of a record (r8_rank) needs its round's neighbours; chasing them through
+ * global memory is a chain of dependent loads per round, so the tags (11 bits) and toggles of three consecutive rounds of the
+ * stream -- the previous, this and the next 1024 records -- live in an LDS ring: a run is at most 1024 records long, so the
+ * window always holds it whole.  Records are requested two rounds ahead. */
+__global__ __launch_bounds__(WC_NT)
+void k_part2_wc8(const Chunk2 *chunks, FastParams fp, const u32 *__restrict__ rows2, u64 *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+	__shared__ unsigned short s_tag[3][WC_NT];
+	__shared__ u32 s_tb[3][WC_NT / 32];
+	const Chunk2 c = chunks[blockIdx.x];
+	const int S2 = 1 << fp.s2_bits, SEG = S2 < WC_SEG ? S2 : WC_SEG;
+	const u32 tid = threadIdx.x;
+	WcView w;
+	w.h = (u64*)s_dyn; w.t = 0;
+	w.cnt = s_dyn + 2 * (size_t)SEG * WC8_CAP; w.head = w.cnt + SEG; w.tail = 0; w.task = w.head + SEG; w.ntask = w.task + WC_NT;
+	const u32 *row = rows2 + (size_t)blockIdx.x * S2;
+	const int n_round = (int)((c.n + WC_NT - 1) / WC_NT);
+	const u64 *src = (const u64*)c.rec;
+	const int64_t g_lo = -(int64_t)c.before, g_hi = (int64_t)c.n + c.after;      /* the sub-table's stream of this batch, relative to the chunk */
+	auto fetch = [&](int q) -> u64 { const int64_t g = (int64_t)q * WC_NT + tid; return g >= g_lo && g < g_hi ? src[g] : 0; };
+	auto post = [&](int q, u64 r) {                                                  /* round q's tags and toggles -> ring slot (q + 1) % 3 */
+		const u32 sl = (u32)(q + 1) % 3u;
+		s_tag[sl][tid] = (unsigned short)((u32)r & 1023u);
+		const u64 bal = __ballot(((u32)r & YK_R8_TOGGLE) != 0);
+		if ((tid & 63) == 0) { s_tb[sl][tid >> 5] = (u32)bal; s_tb[sl][(tid >> 5) + 1] = (u32)(bal >> 32); }
+	};
+	for (int seg0 = 0; seg0 < S2; seg0 += SEG) {
+		__syncthreads();
+		for (int b = tid; b < SEG; b += WC_NT) { w.cnt[b] = 0; w.head[b] = row[seg0 + b]; }
+		if (tid < 2) w.ntask[tid] = 0;
+		u64 cur, nxt;
+		{ const u64 r = fetch(-1); cur = fetch(0); nxt = fetch(1); post(-1, r); post(0, cur); post(1, nxt); }
+		__syncthreads();
+		for (int rd = 0; rd < n_round; ++rd) {
+			const u32 i = (u32)rd * WC_NT + tid, par = (u32)rd & 1;
+			const u64 nn = fetch(rd + 2);
+			if (i < c.n) {
+				/* linear window: word lw covers records (rd - 1) * 1024 + 32 lw ..; block lw / 32 sits in ring slot (rd + lw / 32) % 3 */
+				const u32 mine = ((u32)cur & YK_R8_TOGGLE) ? ~0u : 0u, pos = (u32)cur & 1023u;
+				auto tw = [&](int lw) -> u32 { return s_tb[(u32)(rd + (lw >> 5)) % 3u][lw & 31] ^ mine; };   /* set bits: the other toggle */
+				const int x = WC_NT + (int)tid;
+				int a = 0, e = 3 * WC_NT;
+				{
+					int lw = x >> 5; u32 m = tw(lw) & ((1u << (x & 31)) - 1);
+					while (!m && lw > 0) m = tw(--lw);
+					if (m) a = (lw << 5) + 32 - __clz(m);
+				}
+				{
+					int lw = x >> 5; u32 m = (x & 31) == 31 ? 0 : tw(lw) & (~0u << ((x & 31) + 1));
+					while (!m && lw < 3 * WC_NT / 32 - 1) m = tw(++lw);
+					if (m) e = (lw << 5) + __ffs(m) - 1;
+				}
+				const int64_t base = ((int64_t)rd - 1) * WC_NT;
+				if (base + a < g_lo) a = (int)(g_lo - base);
+				if (base + e > g_hi) e = (int)(g_hi - base);
+				u32 r = 0;
+				for (int j = a; j < e; ++j) r += (u32)s_tag[(u32)(rd + (j >> 10)) % 3u][j & (WC_NT - 1)] < pos;
+				const u32 t = c.tbase + (u32)(base + a - g_lo) + r;
+				const u64 h = (cur >> YK_R8_TAG_BITS) << fp.pre | c.bucket;
+				const u32 sub = sub_of(h, fp) - (u32)seg0;
+				if (sub < (u32)SEG) wcs_place<WC8_CAP>(w, sub, r8_pack(h, t, fp), par, out);
+			}
+			__syncthreads();
+			wcs_flush<WC8_CAP>(w, par, out);
+			post(rd + 2, nn);                                              /* over the slot of round rd - 1, which nobody reads any more */
+			cur = nxt; nxt = nn;
+			__syncthreads();
+		}
+		for (u32 b = tid / 8; b < (u32)SEG; b += WC_NT / 8) {             /* what is left in the stacks */
+			const u32 q = tid & 7, cn = w.cnt[b];
+			if (q < cn) out[w.head[b] + q] = w.h[b * WC8_CAP + q];
+		}
 	}
 }
 
@@ -2692,9 +2928,9 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 	u32 *s_ndist = s_misc, *s_ovf = s_misc + 1, *s_lp = s_misc + 2, *s_ne = s_misc + 3, *s_run = s_misc + 7;
 	const bool pre0 = lo + tid < hi, pre1 = lo + 256 + tid < hi, pre2 = lo + 512 + tid < hi;
 	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
-	if (pre0) r0 = rec[lo + tid];
-	if (pre1) r1 = rec[lo + 256 + tid];
-	if (pre2) r2 = rec[lo + 512 + tid];
+	if (pre0) r0 = lc_raw(fp, rec, lo + tid);
+	if (pre1) r1 = lc_raw(fp, rec, lo + 256 + tid);
+	if (pre2) r2 = lc_raw(fp, rec, lo + 512 + tid);
 	for (u32 i = tid; i < T.cap; i += 256) { T.K[i] = YK_EMPTY; T.T1[i] = T32_INF; T.T2[i] = T32_INF; T.CN[i] = 0; T.TM[i] = 0; }
 	if (stage_bloom) { for (u32 i = tid; i < (16u << lb); i += 256) T.BL[i] = fp.bf_virgin ? 0u : gw[i]; T.GC[tid] = 0; }
 	if (tid < 8) s_misc[tid] = 0;
@@ -2725,10 +2961,10 @@ __device__ bool lc_body(const FastParams &fp, const LcTab &T, u32 sb, const u64 
 		}
 		tmax = t + 1 > tmax ? t + 1 : tmax;
 	};
-	if (pre0) put(r0);
-	if (pre1) put(r1);
-	if (pre2) put(r2);
-	for (u64 i = lo + 768 + tid; i < hi; i += 256) put(rec[i]);
+	if (pre0) put(lc_dec(fp, r0, sb));
+	if (pre1) put(lc_dec(fp, r1, sb));
+	if (pre2) put(lc_dec(fp, r2, sb));
+	for (u64 i = lo + 768 + tid; i < hi; i += 256) put(lc_rec(fp, rec, i, sb));
 	if (!fp.bloom_mode && tmax) atomicMax(s_lp, tmax);      /* without a filter every instance is a put-call */
 	lc_sync<MODE>();
 	bool give_up = !GLB && (*s_ovf || *s_ndist > T.cap / 4 * 3);
@@ -2988,9 +3224,9 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
 	if (it < n_sb) {
 		lo = sbstart[sb0 + it]; hi = sbstart[sb0 + it + 1];
-		if (lo + tid < hi) r0 = rec[lo + tid];
-		if (lo + 256 + tid < hi) r1 = rec[lo + 256 + tid];
-		if (lo + 512 + tid < hi) r2 = rec[lo + 512 + tid];
+		if (lo + tid < hi) r0 = lc_raw(fp, rec, lo + tid);
+		if (lo + 256 + tid < hi) r1 = lc_raw(fp, rec, lo + 256 + tid);
+		if (lo + 512 + tid < hi) r2 = lc_raw(fp, rec, lo + 512 + tid);
 	}
 	__syncthreads();
 
@@ -3030,15 +3266,15 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 		if (bloom && !virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = gw[i];
 		/* A: count; first / second / last occurrence (same loser rule as k_acc_insert) */
 		tmax = 0;
-		if (lo + tid < hi) put(r0);
-		if (lo + 256 + tid < hi) put(r1);
-		if (lo + 512 + tid < hi) put(r2);
-		for (u64 i = lo + 768 + tid; i < hi; i += 256) put(rec[i]);
+		if (lo + tid < hi) put(lc_dec(fp, r0, sb));
+		if (lo + 256 + tid < hi) put(lc_dec(fp, r1, sb));
+		if (lo + 512 + tid < hi) put(lc_dec(fp, r2, sb));
+		for (u64 i = lo + 768 + tid; i < hi; i += 256) put(lc_rec(fp, rec, i, sb));
 		if (!bloom && tmax) atomicMax(s_lp, tmax);                /* without a filter every instance is a put-call */
 		/* the next sub-bucket's records travel while this one is gated and selected */
-		if (lon + tid < hin) r0 = rec[lon + tid];
-		if (lon + 256 + tid < hin) r1 = rec[lon + 256 + tid];
-		if (lon + 512 + tid < hin) r2 = rec[lon + 512 + tid];
+		if (lon + tid < hin) r0 = lc_raw(fp, rec, lon + tid);
+		if (lon + 256 + tid < hin) r1 = lc_raw(fp, rec, lon + 256 + tid);
+		if (lon + 512 + tid < hin) r2 = lc_raw(fp, rec, lon + 512 + tid);
 		__syncthreads();
 		const u32 ndist = *s_ndist;
 		const bool give_up = *s_ovf || ndist > full;
@@ -3544,6 +3780,21 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 	if (n <= pos0) return;
 	const int n_blk = (int)(((u64)(n - pos0) + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE));
 	const size_t lds = sizeof(u32) << nb_bits;
+	if (hash_only == 2) {                                             /* tagged 8-byte records: needs nb_bits <= 10, k < 32 (the caller checks) */
+		static bool attr3 = false;
+		if (!attr3) { hipFuncSetAttribute((const void*)k_xpart_wcs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr3 = true; }
+		static bool said = false;
+		if (!said && getenv("YAKAMD_VERBOSE") && atoi(getenv("YAKAMD_VERBOSE")) > 1) {
+			int nb = 0; said = true;
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_xpart_wcs<true>, 1024, wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024));
+			fprintf(stderr, "[yak_amd] k_xpart_wcs: %zu B of dynamic LDS, %d workgroups per CU\n", wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024), nb);
+		}
+		hipLaunchKernelGGL(k_xpart<3>, dim3(n_blk), dim3(XT_THREADS), 3 * lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+		launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st, true);
+		hipLaunchKernelGGL(k_xpart_wcs<true>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
+		                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out);
+		return;
+	}
 	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
 	static const int wc = getenv("YAKAMD_XP_WC") ? atoi(getenv("YAKAMD_XP_WC")) : 3;   /* bit 0: {hash, position} scatter, bit 1: hash-only scatter */
@@ -3554,7 +3805,14 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 		attr = true;
 	}
 	if (nb_bits <= 10 && (wc >> (hash_only ? 1 : 0) & 1)) {
-		if (hash_only) hipLaunchKernelGGL(k_xpart_wc<2>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<8, XW_CAP_H, false>(1 << nb_bits, XW_NT)), st,
+		static const int wcs2 = getenv("YAKAMD_XP_WCS") ? atoi(getenv("YAKAMD_XP_WCS")) : 1;
+		if (hash_only && wcs2 && k < 32) {                         /* the round-stable variant needs 7 slots per stack only: two workgroups per CU */
+			static bool attr4 = false;
+			if (!attr4) { hipFuncSetAttribute((const void*)k_xpart_wcs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr4 = true; }
+			hipLaunchKernelGGL(k_xpart_wcs<false>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
+			                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out);
+		}
+		else if (hash_only) hipLaunchKernelGGL(k_xpart_wc<2>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<8, XW_CAP_H, false>(1 << nb_bits, XW_NT)), st,
 		                                  bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
 		else hipLaunchKernelGGL(k_xpart_wc<1>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<4, XW_CAP_T, true>(1 << nb_bits, XW_NT)), st,
 		                        bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
@@ -3763,7 +4021,12 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 	if (n_chunks) hipLaunchKernelGGL(k_part2<0>, dim3(n_chunks), dim3(256), lds, st, chunks, fp, rows2, out);
 	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
 	static const int wc = getenv("YAKAMD_P2_WC") ? atoi(getenv("YAKAMD_P2_WC")) : 1;
-	if (n_chunks && wc && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
+	if (n_chunks && wc && fp.rec8_out && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
+		static bool attr8 = false;
+		if (!attr8) { hipFuncSetAttribute((const void*)k_part2_wc8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr8 = true; }
+		const size_t seg = fp.s2_bits < 11 ? (size_t)1 << fp.s2_bits : WC_SEG;
+		hipLaunchKernelGGL(k_part2_wc8, dim3(n_chunks), dim3(WC_NT), seg * WC8_CAP * 8 + seg * 8 + WC_NT * 4 + 16, st, chunks, fp, (const u32*)rows2, (u64*)out);
+	} else if (n_chunks && wc && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
 		static bool attr2 = false;
 		if (!attr2) { hipFuncSetAttribute((const void*)k_part2_wc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr2 = true; }
 		const size_t l2 = wc_lds_bytes<4, WC_CAP, true>(fp.s2_bits < 11 ? 1 << fp.s2_bits : WC_SEG, WC_NT);

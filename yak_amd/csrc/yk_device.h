@@ -72,7 +72,7 @@ extern "C" {
 void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
                        u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st);
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st);   /* hash_only: 0 = Rec, 1 = bare hashes, 2 = tagged 8-byte records */
 void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
                      int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
 int yk_xpart_blocks(int64_t n_pos);
@@ -144,8 +144,17 @@ struct Chunk2 {                     /* one level-2 partition work item: a run of
 	u64 spare;
 	u32 n, bucket;
 	u32 tbase;                      /* added to tlo: time relative to the start of the pass */
-	u32 pad;
+	u32 pad;                        /* record format of the chunk: 0 = Rec {hash, position}; 1 = tagged 8-byte records (YK_R8_*), tbase = records of this bucket in earlier batches */
+	u32 before, after;              /* format 1: records of the same bucket of the same batch lying before / behind the chunk in memory */
 };
+
+/* Tagged 8-byte level-1 record (k < 32, 2k - pre <= 52): (hash >> pre) << 12 | toggle << 10 | position inside the 1024-position
+ * round of the partitioning workgroup.  Inside a bucket the records of one round are contiguous and the rounds follow each other in
+ * stream order (the write combining is stable at round granularity); the toggle bit flips between consecutive rounds that
+ * contributed to the bucket, across workgroups too (the histogram sweep counts them), so the level-2 partition recovers every
+ * record's rank in the sub-table's stream: the "time" that orders put-calls.  Stream positions are not stored at all. */
+#define YK_R8_TAG_BITS 12
+#define YK_R8_TOGGLE   (1u << 10)
 
 struct FastParams {
 	int pre, k, s2_bits;            /* sub-buckets per sub-table = 1 << s2_bits */
@@ -153,6 +162,7 @@ struct FastParams {
 	int img_nonempty;
 	int plo, phi;
 	int dbg, bf_virgin;             /* dbg: timing ablations only (YAKAMD_DBG); bf_virgin: filter never written (all zero) */
+	int rec8_in, rec8_out, tb;      /* level-2 input is tagged 8-byte records; its output (the counting kernels' input) is 8 bytes: (hash >> pre minus the sub-bucket bits) << tb | rank, tb = 12 + s2_bits */
 	int or_mode;                    /* loads from a .yak file (htab.c:436-470) instead of counting: 1 = the low 4 bits of a record's time are a flag, ORed into the key's low bits; 2 = the low 10 bits are the saved count, kept by new keys only */
 	u64 t_pass0;
 };
