@@ -385,6 +385,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	if (!c) return fail("not an engine table");
 	if (c->in_pass) return fail("pass already open");
 	HIPCK(hipSetDevice(c->dev));
+	(void)hipGetLastError();                                   /* whatever other users of the runtime left behind is not this pass's (see yakamd_pass_end) */
 	c->create_new = create_new;
 	c->bloom_mode = create_new && c->has_bloom && !c->gate_off;
 	c->in_pass = true;
@@ -1489,7 +1490,11 @@ extern "C" int64_t yakamd_pass_end(yak_ch_t *h)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("no pass open");
-	const int64_t r = pass_end_body(c);
+	int64_t r = pass_end_body(c);
+	if (r >= 0) {                                              /* a launch that was refused (bad configuration) reports nothing by itself */
+		const hipError_t e = hipGetLastError();
+		if (e != hipSuccess) r = fail("a HIP call of this pass was refused: %s", hipGetErrorString(e));
+	}
 	if (r < 0) pass_free(c);                                 /* a failed pass is closed too: the table stays usable (the pass's k-mers are lost, the error is reported) */
 	return r;
 }

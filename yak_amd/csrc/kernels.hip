@@ -4022,8 +4022,8 @@ void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first,
 	hipLaunchKernelGGL(k_part2_scan, dim3(P), dim3(256), 0, st, chunk_first, bbase, fp.s2_bits, rows2, sbstart, P);
 	static const int wc = getenv("YAKAMD_P2_WC") ? atoi(getenv("YAKAMD_P2_WC")) : 1;
 	if (n_chunks && wc && fp.rec8_out && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
-		static bool attr8 = false;
-		if (!attr8) { hipFuncSetAttribute((const void*)k_part2_wc8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr8 = true; }
+		static bool attr8 = false;                                  /* the kernel has 6.5 KB of static LDS besides */
+		if (!attr8) { if (hipFuncSetAttribute((const void*)k_part2_wc8, hipFuncAttributeMaxDynamicSharedMemorySize, WC_SEG * WC8_CAP * 8 + WC_SEG * 8 + WC_NT * 4 + 16) != hipSuccess) (void)hipGetLastError(); attr8 = true; }
 		const size_t seg = fp.s2_bits < 11 ? (size_t)1 << fp.s2_bits : WC_SEG;
 		hipLaunchKernelGGL(k_part2_wc8, dim3(n_chunks), dim3(WC_NT), seg * WC8_CAP * 8 + seg * 8 + WC_NT * 4 + 16, st, chunks, fp, (const u32*)rows2, (u64*)out);
 	} else if (n_chunks && wc && fp.s2_bits <= 13 && fp.s2_bits >= 4) {
