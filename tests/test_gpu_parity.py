@@ -245,7 +245,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_COUNT_RNG="0"), dict(YAKAMD_COUNT_OWN="0"),
                                  dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_OWN_LDS="19500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_LC2="0"), dict(YAKAMD_LC2="0", YAKAMD_S2_BITS="4"),
-                                 dict(YAKAMD_LC2_WGS="3"),
+                                 dict(YAKAMD_LC2_WGS="3"), dict(YAKAMD_YTAG="0"), dict(YAKAMD_YTAG="0", YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_R2_SMALL_F="16"), dict(YAKAMD_R2_SMALL_F="1024"),
                                  dict(YAKAMD_REC8="0"), dict(YAKAMD_REC8_OUT="0"), dict(YAKAMD_REC8_OUT="0", YAKAMD_BATCH="16384"), dict(YAKAMD_BATCH="8192", YAKAMD_S2_BITS="3"),
                                  dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
@@ -255,7 +255,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
                               "count_with_device_atomics", "count_lds_rank_kernel",
                               "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
-                              "lc2_three_persistent_workgroups",
+                              "lc2_three_persistent_workgroups", "pass2_plain_hashes", "pass2_plain_hashes_cross_sweep", "replay_prefix_16", "replay_prefix_1024",
                               "rec16_records", "tagged_in_rec16_out", "tagged_in_rec16_out_multibatch", "tagged_multibatch_s2_3",
                               "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
@@ -293,11 +293,11 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
                                  dict(YAKAMD_R2_SMALL_BITS="10", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_R2_SMALL_BITS="9", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_REPLAY2="0"),
-                                 dict(YAKAMD_OWN_LDS="30000", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64"), dict(YAKAMD_REPLAY_LDS="32768"),
+                                 dict(YAKAMD_OWN_LDS="30000", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64", YAKAMD_YTAG="0"), dict(YAKAMD_R2_SMALL_F="32"), dict(YAKAMD_REPLAY_LDS="32768"),
                                  dict(YAKAMD_REPLAY_LDS="2048"), dict(YAKAMD_REPLAY_LDS="1024", YAKAMD_REPLAY_THREADS="256"), dict(YAKAMD_REPLAY_LDS="2048", YAKAMD_DBG="256")],
                          ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow",
                               "streaming_replay_2k_slot_segments", "streaming_replay_from_512_slots_1k_slot_segments", "k_replay_for_16k_slots",
-                              "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "lds_keys_for_small_stages",
+                              "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "pass2_key_owning_ranges_plain_hashes", "replay_prefix_32", "lds_keys_for_small_stages",
                               "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
 def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
     """~7 M distinct k-mers (1x coverage): every sub-table grows to 16 Ki slots, so the layout replay

@@ -569,12 +569,14 @@ static int count_by_ranges(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart)
 
 /* count-existing pass, records grouped by prefix: one workgroup per slot range with the range's keys in LDS
  * (k_img_count_own).  Returns 0 done, -1 error, 1 not applicable. */
-static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash_only)
+/* the ranges of k_img_count_own for the table as it stands: 1 = not applicable, 0 = go (rb == -1: no sub-table has a slot) */
+static int count_own_plan(yakamd_ctx *c, int *rng_log_out, int *rb_out, u32 *kmax_out)
 {
 	if (env_i64("YAKAMD_COUNT_OWN", 1) == 0 || c->nb_bits != c->pre) return 1;
 	const size_t budget = (size_t)env_i64("YAKAMD_OWN_LDS", 156000);     /* one workgroup per CU with as few ranges as possible: every range re-reads the sub-table's records (measured: 8 ranges x 1 WG/CU 16.9 ms, 16 ranges x 2 WG/CU 24.8 ms) */
 	u32 bmax = 0;
 	for (int p = c->plo; p < c->phi; ++p) if (c->h_bits[p] != YK_NOCAP) bmax = std::max(bmax, c->h_bits[p]);
+	*rng_log_out = 0; *rb_out = -1; *kmax_out = 0;
 	if (bmax == 0) return 0;                                         /* no sub-table has a slot: nothing can be found */
 	int rng_log = -1; u32 kmax = 0;
 	for (int rl = (int)bmax; rl >= 5 && rng_log < 0; --rl) {
@@ -589,6 +591,17 @@ static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash
 	}
 	const int rb = rng_log < 0 ? 99 : (int)bmax - rng_log;
 	if (rb > (int)env_i64("YAKAMD_OWN_MAXRB", 4)) return 1;        /* every range's workgroup streams the whole sub-table: too redundant beyond 16 ranges */
+	*rng_log_out = rng_log; *rb_out = rb; *kmax_out = kmax;
+	return 0;
+}
+
+/* ytag: the records are k_xpart_wcs<false>'s with the top bits of the home-slot product in place of the sub-table's own bits */
+static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash_only, int ytag)
+{
+	int rng_log, rb; u32 kmax;
+	const int pl = count_own_plan(c, &rng_log, &rb, &kmax);
+	if (pl) return ytag ? fail("the table changed between the extraction and the count of a pass") : 1;
+	if (rb < 0) return 0;
 	u64 *d_list = 0; u32 *d_ln = 0;
 	const u32 list_cap = (u32)std::min<int64_t>(env_i64("YAKAMD_XLIST_CAP", 1 << 22), 1 << 22);   /* the knob is for tests */
 	if (dmalloc(&d_list, (size_t)1 << 22) || dmalloc(&d_ln, 2)) { dfree(d_list); return -1; }
@@ -596,11 +609,11 @@ static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash
 	const ImgView img = img_view(c);
 	const size_t lds = yk_count_own_lds(1u << rng_log, kmax);
 	if (hipMemsetAsync(d_ln, 0, 8, c->st) != hipSuccess) r = fail("memset");
-	if (!r && yk_launch_img_count_own(c->d_rec, hash_only, 0, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st)) r = fail("key-owning count kernel could not be configured");
+	if (!r && yk_launch_img_count_own(c->d_rec, hash_only, 0, ytag, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st)) r = fail("key-owning count kernel could not be configured");
 	u32 xn[2] = { 0, 0 };
 	if (!r && (hipMemcpyAsync(xn, d_ln, 8, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)) r = fail("key-owning count kernel failed: %s", hipGetErrorString(hipGetLastError()));
 	if (!r) {
-		if (xn[1]) yk_launch_img_count_own(c->d_rec, hash_only, 1, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st);   /* list too small: second sweep */
+		if (xn[1]) yk_launch_img_count_own(c->d_rec, hash_only, 1, ytag, d_bstart, img, c->plo, c->phi, rb, rng_log, kmax, lds, d_list, d_ln, list_cap, c->st);   /* list too small: second sweep */
 		else if (xn[0]) yk_launch_img_count_h(d_list, (int64_t)xn[0], img, c->st);
 		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] key-owning count: 2^%d slots per range (up to 2^%d ranges per sub-table), %u keys of LDS room, %zu B of LDS, %u boundary-crossing instances%s\n",
 		                                          rng_log, rb, kmax, lds, xn[0], xn[1] ? " (list overflow: second sweep)" : "");
@@ -611,7 +624,7 @@ static int count_own(yakamd_ctx *c, int64_t n_rec, const u64 *d_bstart, int hash
 	return r;
 }
 
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart, int hash_only)
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart, int hash_only, int ytag)
 {
 	if (n_rec <= 0) return 0;
 	const ImgView img = img_view(c);
@@ -622,8 +635,8 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
 		 * exclusive-ownership counting, no global atomics */
 		if (d_bstart) {
-			const int r = count_own(c, n_rec, d_bstart, hash_only);
-			if (r <= 0) {
+			const int r = count_own(c, n_rec, d_bstart, hash_only, ytag);
+			if (r <= 0 || ytag) {
 				const double ms = tm.stop();
 				c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
 				return r;
@@ -685,7 +698,7 @@ static int bloom_materialise(yakamd_ctx *c)
 }
 
 /* ---- fast path bookkeeping ---- */
-static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart = 0, int hash_only = 0);
+static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u64 batch_hi, const u64 *d_bstart = 0, int hash_only = 0, int ytag = 0);
 
 /* leave the fast path: push every kept batch through the accumulator path, in stream order */
 static int fast_abandon(yakamd_ctx *c)
@@ -761,7 +774,12 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 	HIPCK(hipSetDevice(c->dev));
 	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 31);
 	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
-	const int hash_only = !c->create_new;                  /* counting existing keys needs no stream positions */
+	int hash_only = !c->create_new;                        /* counting existing keys needs no stream positions */
+	int ytag = 0;
+	if (hash_only && c->k < 32 && c->nb_bits <= 10 && env_i64("YAKAMD_YTAG", 1) != 0) {   /* the key-owning count will run: its range test is prepared by the extraction */
+		int rl, rb; u32 km;
+		if (count_own_plan(c, &rl, &rb, &km) == 0 && rb >= 0) { ytag = 1; hash_only = 3; }
+	}
 	const int64_t bmax = std::min(batch, (n_bytes + 4095) & ~(int64_t)4095);
 	if ((!c->fast && rec_reserve(c, bmax)) || part_reserve(c, yk_xpart_blocks(bmax))) return -1;   /* the fast path keeps every batch in a buffer of its own */
 	for (int64_t pos = 0; pos < n_bytes; pos += batch) {
@@ -782,7 +800,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 			c->st_cur.ms_extract += tm.stop();
 		}
 		if (c->fast) { if (fast_keep(c, n_rec)) return -1; if (t0 + (u64)end > c->t_end) c->t_end = t0 + (u64)end; continue; }
-		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart, hash_only)) return -1;
+		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart, hash_only ? 1 : 0, ytag)) return -1;
 	}
 	return 0;
 }

@@ -425,7 +425,7 @@ __device__ __forceinline__ void wcs_flush(const WcView &w, u32 par, u64 *out)
 template <bool TAG>   /* TAG: tagged records (rows carry the toggle); else bare hashes for the count-existing passes (plain rows) */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))    /* two workgroups per CU: <= 64 VGPRs and <= 80 SGPRs */
 void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int k, int pre, int plo, int phi,
-                 int nb_bits, const u32 *__restrict__ rows, u64 *__restrict__ out)
+                 int nb_bits, const u32 *__restrict__ rows, u64 *__restrict__ out, int ytag)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 	__shared__ XtTile S;
@@ -452,7 +452,10 @@ void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int
 			if (ok) {
 				bk = bucket_of(h, pre, nb_bits);
 				if (TAG) tg = w.tail[bk];
-				wcs_place<XW_CAP_S>(w, bk, TAG ? (h >> pre) << YK_R8_TAG_BITS | (u64)(tg << 10) | (u32)tid : h, par, out);
+				/* bare hashes, ytag: the sub-table's own bits (the bucket says them) make room for the top bits of the home-slot product
+				 * (khashl.h __kh_h2b), so that k_img_count_own's range test is a shift and a compare */
+				const u64 hv = ytag ? (h & ~(u64)pmask) | (((u32)(h >> pre) * 2654435769u) >> (32 - pre)) : h;
+				wcs_place<XW_CAP_S>(w, bk, TAG ? (h >> pre) << YK_R8_TAG_BITS | (u64)(tg << 10) | (u32)tid : hv, par, out);
 			}
 			__syncthreads();
 			if (TAG && ok) w.tail[bk] = tg ^ 1;                           /* every lane of the bucket writes the same value: the next contributing round gets the other toggle */
@@ -2027,7 +2030,7 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 #define R2_SEG  (1u << R2_SEG_LOG)
 #define R2_HEAD 2048u
 #define R2_NONE 0xffffffffu
-#define R2_SMALL_F 1024u                      /* the single-workgroup kernel runs the doubling rounds up to here */
+#define R2_SMALL_F 256u                       /* the single-workgroup kernel runs the doubling rounds up to here */
 #define R2_BASE_MAX 4096u
 #define R2_LONG 8u                             /* runs longer than this are placed by a whole wave */
 #define R2_LMAX 512u
@@ -2218,7 +2221,7 @@ void k_r2_dinit(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG
 
 /* the prefix by the literal rule, then the rounds below R2_SMALL_F; one workgroup per sub-table */
 __global__ __launch_bounds__(256)
-void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail)
+void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, u32 small_f)
 {
 	__shared__ R2Wave s_wave[4];
 	__shared__ u32 s_long[256];
@@ -2262,7 +2265,7 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 	__threadfence();
 	__syncthreads();
 	u32 F = s_F;
-	while (F < n && F < R2_SMALL_F) {
+	while (F < n && F < small_f) {
 		if (tid == 0) {
 			u32 g = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
 			s_dyn = 0; s_nlong = 0;
@@ -3194,6 +3197,7 @@ void k_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *blo
 #define LC2_EXIST 0x4000u
 #define LC2_CMASK 0x0fffu
 
+__device__ u64 d_lc2_prof[8];      /* YAKAMD_DBG & 128: shader clocks per phase, summed over the workgroups (lane 0 of each) */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict__ rec, u32 *bloom32, ImgView img, LcOut O,
            u64 *counters, u32 *ovf_list, u32 n_sb)
@@ -3258,24 +3262,84 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 		tmax = t + 1 > tmax ? t + 1 : tmax;
 	};
 
+	u64 pf[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	while (it < n_sb) {
 		const u32 sb = sb0 + it, itn = it + gridDim.x;
 		u32 *gw = bloom ? bloom32 + ((((u64)(sb >> fp.s2_bits) << fp.nb) | ((u64)(sb & ((1u << fp.s2_bits) - 1)) << (lb + 9))) >> 5) : 0;
 		u64 lon = 0, hin = 0;
 		if (itn < n_sb) { lon = sbstart[sb0 + itn]; hin = sbstart[sb0 + itn + 1]; }
 		if (bloom && !virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = gw[i];
+		const bool prof = (fp.dbg & 128) && tid == 0;
+		u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
+		if (prof) tp0 = __builtin_readcyclecounter();
 		/* A: count; first / second / last occurrence (same loser rule as k_acc_insert) */
 		tmax = 0;
-		if (lo + tid < hi) put(lc_dec(fp, r0, sb));
-		if (lo + 256 + tid < hi) put(lc_dec(fp, r1, sb));
-		if (lo + 512 + tid < hi) put(lc_dec(fp, r2, sb));
+		u64 tpw = 0;
+		if (fp.dbg & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (prof) tpw = __builtin_readcyclecounter(); }
+		{
+			/* the lane's (up to) three records go through the table side by side: every step is three independent LDS
+			 * operations and one wait, instead of three dependent chains one after the other (put, below, is the same
+			 * thing for one record; it takes the records beyond 768 and the probes that do not end at the home slot) */
+			const Rec rc[3] = { lc_dec(fp, r0, sb), lc_dec(fp, r1, sb), lc_dec(fp, r2, sb) };
+			bool v[3] = { lo + tid < hi, lo + 256 + tid < hi, lo + 512 + tid < hi }, res[3], won[3], tried[3];
+			u32 sl[3], at[3], cn[3], old[3];
+			u64 cur[3];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) { sl[i] = home(rc[i].x); cur[i] = v[i] ? s_K[sl[i]] : 0; }
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				res[i] = v[i] && cur[i] == rc[i].x; won[i] = false; tried[i] = v[i] && cur[i] == YK_EMPTY;
+				if (tried[i]) cur[i] = atomicCAS(&s_K[sl[i]], YK_EMPTY, rc[i].x);
+			}
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (tried[i]) { won[i] = cur[i] == YK_EMPTY; res[i] = won[i] || cur[i] == rc[i].x; }
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (won[i]) at[i] = atomicAdd(s_ndist, 1u);
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (won[i] && at[i] < full) s_list[at[i]] = (unsigned short)sl[i];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (v[i] && !res[i]) {                 /* the home slot belongs to another key: walk on */
+				const u64 key = rc[i].x;
+				u32 q = (sl[i] + 1) & (LC2_CAP - 1), n = 1;
+				for (; n < LC2_CAP; ++n, q = (q + 1) & (LC2_CAP - 1)) {
+					u64 c2 = s_K[q];
+					if (c2 == key) break;
+					if (c2 == YK_EMPTY) {
+						c2 = atomicCAS(&s_K[q], YK_EMPTY, key);
+						if (c2 == YK_EMPTY) { const u32 a2 = atomicAdd(s_ndist, 1u); if (a2 < full) s_list[a2] = (unsigned short)q; break; }
+						if (c2 == key) break;
+					}
+				}
+				if (n == LC2_CAP) { *s_ovf = 1; v[i] = false; }
+				sl[i] = q;
+			}
+#pragma unroll
+			for (int i = 0; i < 3; ++i) cn[i] = v[i] ? cn_get(sl[i]) : 0;
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (v[i]) {
+				if ((cn[i] & LC2_CMASK) < 0x800u) atomicAdd(&s_CN[sl[i] >> 1], 1u << (16 * (sl[i] & 1)));   /* only min(count, 1024) is ever used; 256 racing lanes cannot carry out of the field */
+				old[i] = atomicMin(&s_T1[sl[i]], (u32)rc[i].y);
+			}
+#pragma unroll
+			for (int i = 0; i < 3; ++i) if (v[i]) {
+				const u32 t = (u32)rc[i].y;
+				if (bloom) {
+					if (old[i] != T32_INF) atomicMin(&s_T2[sl[i]], old[i] > t ? old[i] : t);
+					atomicMax(&s_TM[sl[i]], t);
+				}
+				tmax = t + 1 > tmax ? t + 1 : tmax;
+			}
+		}
 		for (u64 i = lo + 768 + tid; i < hi; i += 256) put(lc_rec(fp, rec, i, sb));
 		if (!bloom && tmax) atomicMax(s_lp, tmax);                /* without a filter every instance is a put-call */
+		u64 tpp = 0;
+		if (prof) tpp = __builtin_readcyclecounter();
 		/* the next sub-bucket's records travel while this one is gated and selected */
 		if (lon + tid < hin) r0 = lc_raw(fp, rec, lon + tid);
 		if (lon + 256 + tid < hin) r1 = lc_raw(fp, rec, lon + 256 + tid);
 		if (lon + 512 + tid < hin) r2 = lc_raw(fp, rec, lon + 512 + tid);
 		__syncthreads();
+		if (prof) tp1 = __builtin_readcyclecounter();
 		const u32 ndist = *s_ndist;
 		const bool give_up = *s_ovf || ndist > full;
 		if (!give_up && !(fp.dbg & 16)) {
@@ -3310,11 +3374,8 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 					}
 					u64 peers = 0; u32 np = 0;                                    /* up to 6 slot numbers of 10 bits */
 					const u32 r0s = blk << rsh;
-					for (u32 d = 0; miss && d < LC2_CAP; ++d) {
-						const u32 j = (r0s + d) & (LC2_CAP - 1);
-						const u64 ky = s_K[j];
-						if (ky == YK_EMPTY) { if (d + 1 >= R) break; continue; }     /* no key of this block can sit beyond */
-						if (j == s || (u32)((ky >> fp.pre) & lmask) != blk || s_T1[j] >= t1x || (cn_get(j) & LC2_EXIST)) continue;
+					auto consider = [&](const u32 j, const u64 ky) {
+						if (j == s || (u32)((ky >> fp.pre) & lmask) != blk || s_T1[j] >= t1x || (cn_get(j) & LC2_EXIST)) return;
 						if (np < 6) peers |= (u64)j << (10 * np);
 						else {                                                      /* a crowded block: the plain way */
 							const BfSeq y = lc_seq(ky, fp);
@@ -3322,6 +3383,21 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 								for (u32 i = 0, z = q.h1; i < q.nd; ++i, z = (z + q.h2) & 511) if (z == w) miss &= ~(1u << i);
 						}
 						++np;
+					};
+					u32 d = 0;
+					if (R == 8 && miss) {                                         /* the block's eight home slots with four 16-byte reads, no dependent chain */
+						const ulonglong2 *kb = (const ulonglong2*)(s_K + r0s);
+						const ulonglong2 q0 = kb[0], q1 = kb[1], q2 = kb[2], q3 = kb[3];
+						const u64 kk[8] = { q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y };
+#pragma unroll
+						for (u32 i = 0; i < 8; ++i) if (kk[i] != YK_EMPTY) consider(r0s + i, kk[i]);
+						d = kk[7] == YK_EMPTY ? LC2_CAP : 8;                        /* slot 7 unused: no key of this block can sit beyond */
+					}
+					for (; miss && d < LC2_CAP; ++d) {
+						const u32 j = (r0s + d) & (LC2_CAP - 1);
+						const u64 ky = s_K[j];
+						if (ky == YK_EMPTY) { if (d + 1 >= R) break; continue; }     /* no key of this block can sit beyond */
+						consider(j, ky);
 					}
 					if (np > 6) np = 6;
 					if (miss && np) {
@@ -3348,6 +3424,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 				}
 				if (!virgin) __syncthreads();                                  /* every gate has read the filter as it was */
 			}
+			if (prof) tp2 = __builtin_readcyclecounter();
 			/* C' + D + E: set the bits, last put-call, keys entering the table */
 			u32 best = 0;
 			for (u32 li = tid; li < ndist; li += 256) {
@@ -3376,6 +3453,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 			if (best) atomicMax(s_lp, best);
 		}
 		__syncthreads();
+		if (prof) tp3 = __builtin_readcyclecounter();
 		/* write-back, per-sub-bucket results, clean tables for the next sub-bucket */
 		if (give_up) {
 			if (virgin) for (u32 i = tid; i < nbw; i += 256) gw[i] = 0;       /* the next tier expects real zeros */
@@ -3395,7 +3473,13 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 		if (virgin) for (u32 i = tid; i < nbw; i += 256) s_BL[i] = 0;
 		it = itn; lo = lon; hi = hin;
 		__syncthreads();
+		if (prof) {
+			const u64 tp4 = __builtin_readcyclecounter();
+			pf[0] += tp1 - tp0; pf[1] += tp2 > tp1 ? tp2 - tp1 : 0; pf[2] += tp3 - (tp2 > tp1 ? tp2 : tp1);
+			pf[3] += tp4 - tp3; pf[4] += 1; pf[5] += tpw - tp0; pf[6] += tpp - tpw;
+		}
 	}
+	if ((fp.dbg & 128) && tid == 0) for (int i = 0; i < 7; ++i) atomicAdd(&d_lc2_prof[i], pf[i]);
 }
 
 /* keys selected per sub-table = sum over its sub-buckets */
@@ -3638,7 +3722,7 @@ void k_img_count_rng(const u64 *__restrict__ rec, const u64 *__restrict__ sbstar
 template <int W, int CROSS>
 __global__ __launch_bounds__(1024)
 void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart, ImgView img, int plo, int n_p, int rb, int rng_log, u32 kmax,
-                     u64 *__restrict__ list, u32 *list_n, u32 list_cap)
+                     u64 *__restrict__ list, u32 *list_n, u32 list_cap, int ytag)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 	__shared__ u32 s_wsum[16];
@@ -3652,7 +3736,7 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	if (r >> rbp) return;
 	const u32 cap = 1u << bits, nmask = cap - 1, L = cap >> rbp, start = r * L, nw = (L + 31) / 32;
 	const u64 off = img.off[p];
-	u32 *s_bm = s_dyn, *s_rk = s_dyn + nw;
+	u32 *s_br = s_dyn;                                            /* word w of the bitmap at [2w], the rank of its first slot at [2w + 1]: one 8-byte read per probe */
 	u64 *s_k = (u64*)(s_dyn + 2 * ((nw + 1) & ~1u));
 	u32 *s_ct = (u32*)(s_k + kmax);
 	/* bitmap + exclusive popcount scan (every thread owns a contiguous run of words) */
@@ -3660,7 +3744,7 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	u32 mine = 0;
 	for (u32 j = 0; j < per; ++j) {
 		const u32 w = tid * per + j;
-		if (w < nw) { const u32 x = img.used[((off + start) >> 5) + w]; s_bm[w] = x; mine += __popc(x); }
+		if (w < nw) { const u32 x = img.used[((off + start) >> 5) + w]; s_br[2 * w] = x; mine += __popc(x); }
 	}
 	u32 incl = mine;
 	for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o); if (lane >= (u32)o) incl += t; }
@@ -3673,7 +3757,7 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	if (!fits) {                                                   /* cannot happen with the host's sizing rule short of a pathological table */
 		if (CROSS) return;
 		for (u64 i = lo + tid; i < hi; i += 1024) {
-			const u64 h = rec[W * i];
+			const u64 h = ytag ? (rec[W * i] >> img.pre) << img.pre | p : rec[W * i];
 			if (rbp && ((u32)(h >> img.pre) * 2654435769u) >> rsel != r) continue;
 			const int64_t hit = img_find(img, h);
 			if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
@@ -3685,8 +3769,8 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 		for (u32 j = 0; j < per; ++j) {
 			const u32 w = tid * per + j;
 			if (w >= nw) break;
-			s_rk[w] = rr;
-			u32 x = s_bm[w];
+			s_br[2 * w + 1] = rr;
+			u32 x = s_br[2 * w];
 			while (x) { const u32 b = __ffs((int)x) - 1; x &= x - 1; s_k[rr++] = img.keys[off + start + w * 32 + b]; }
 		}
 	}
@@ -3696,10 +3780,11 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 		const u64 kid = h >> img.pre;
 		const u32 first = (((u32)kid * 2654435769u) >> (32 - bits)) - start;
 		u32 s = first;
+		u64 wr = *(const u64*)&s_br[2 * (s >> 5)];                   /* a cluster walk stays inside one bitmap word most of the time: one read, then keys only */
 		for (;;) {
-			const u32 word = s_bm[s >> 5];
+			const u32 word = (u32)wr;
 			if (!(word >> (s & 31) & 1)) break;                          /* khashl get: stop at the first unused slot */
-			const u32 rr = s_rk[s >> 5] + __popc(word & ((1u << (s & 31)) - 1));
+			const u32 rr = (u32)(wr >> 32) + __popc(word & ((1u << (s & 31)) - 1));
 			if (s_k[rr] >> 10 == kid) {
 				if (!CROSS) {
 					const u32 sh = 16 * (rr & 1);
@@ -3708,11 +3793,11 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 				break;
 			}
 			++s;
-			if (rbp == 0) { s &= nmask; if (s == first) break; continue; }   /* the range is the whole table: plain wrap-around */
-			if (s < L) continue;
+			if (rbp == 0) { s &= nmask; if (s == first) break; if ((s & 31) == 0) wr = *(const u64*)&s_br[2 * (s >> 5)]; continue; }   /* the range is the whole table: plain wrap-around */
+			if (s < L) { if ((s & 31) == 0) wr = *(const u64*)&s_br[2 * (s >> 5)]; continue; }
 			if (!CROSS) {                                                /* the probe leaves the range */
 				const u32 at = atomicAdd(&list_n[0], 1u);
-				if (at < list_cap) list[at] = h; else atomicAdd(&list_n[1], 1u);
+				if (at < list_cap) list[at] = ytag ? (h >> img.pre) << img.pre | p : h; else atomicAdd(&list_n[1], 1u);
 			} else {
 				const u32 home = (start + first) & nmask;
 				for (u32 s2 = (start + L) & nmask; s2 != home; s2 = (s2 + 1) & nmask) {
@@ -3729,20 +3814,36 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	 * a per-wave LDS queue and probed 64 at a time, so the probe code runs with full waves */
 	u64 *s_q = (u64*)(s_ct + ((kmax + 1) / 2 + 1 & ~1u)) + wave * 128;
 	u32 qn = 0;
-	for (u64 i0 = lo; i0 < hi; i0 += (u64)1024 * OWN_U) {
-		u64 hv[OWN_U];
+	const u64 STEP = (u64)1024 * OWN_U;
+	const u32 ypm = (1u << img.pre) - 1, ysh = (u32)img.pre - (u32)rbp;          /* ytag records: the product's top `pre` bits sit in the low bits */
+	auto fetch = [&](u64 (&hv)[OWN_U], const u64 i0) {
 #pragma unroll
-		for (int u = 0; u < OWN_U; ++u) { const u64 i = i0 + (u64)u * 1024 + tid; hv[u] = i < hi ? rec[W * i] : 0; }
+		for (int u = 0; u < OWN_U; ++u) { const u64 i = i0 + (u64)u * 1024 + tid; hv[u] = rec[W * (i < hi ? i : hi - 1)]; }   /* always a load: the wait counts stay static (consume checks the index) */
+	};
+	auto consume = [&](const u64 (&hv)[OWN_U], const u64 i0) {
 #pragma unroll
 		for (int u = 0; u < OWN_U; ++u) {
 			const bool valid = i0 + (u64)u * 1024 + tid < hi;
 			if (rbp == 0) { if (valid) probe(hv[u]); continue; }
-			const bool match = valid && ((u32)(hv[u] >> img.pre) * 2654435769u) >> rsel == r;
+			const bool match = valid && (ytag ? ((u32)hv[u] & ypm) >> ysh == r : ((u32)(hv[u] >> img.pre) * 2654435769u) >> rsel == r);
 			const u64 mk = __ballot(match);
 			if (match) s_q[qn + __popcll(mk & lanemask_lt())] = hv[u];
 			qn += (u32)__popcll(mk);
 			if (qn >= 64) { qn -= 64; probe(s_q[qn + lane]); }
 		}
+	};
+	/* two register sets: the next OWN_U records of every lane travel while the current ones are filtered and probed */
+	u64 ha[OWN_U], hb[OWN_U];
+	fetch(ha, lo);
+	for (u64 i0 = lo;;) {
+		fetch(hb, i0 + STEP);
+		consume(ha, i0);
+		i0 += STEP;
+		if (i0 >= hi) break;
+		fetch(ha, i0 + STEP);
+		consume(hb, i0);
+		i0 += STEP;
+		if (i0 >= hi) break;
 	}
 	if (lane < qn) probe(s_q[lane]);
 	if (CROSS) return;
@@ -3750,7 +3851,7 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	for (u32 j = 0; j < per; ++j) {
 		const u32 w = tid * per + j;
 		if (w >= nw) break;
-		u32 x = s_bm[w], rr = s_rk[w];
+		u32 x = s_br[2 * w], rr = s_br[2 * w + 1];
 		while (x) {
 			const u32 b = __ffs((int)x) - 1;
 			x &= x - 1;
@@ -3792,7 +3893,7 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 		hipLaunchKernelGGL(k_xpart<3>, dim3(n_blk), dim3(XT_THREADS), 3 * lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
 		launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st, true);
 		hipLaunchKernelGGL(k_xpart_wcs<true>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
-		                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out);
+		                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, 0);
 		return;
 	}
 	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
@@ -3804,13 +3905,13 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 		hipFuncSetAttribute((const void*)k_xpart_wc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
 		attr = true;
 	}
-	if (nb_bits <= 10 && (wc >> (hash_only ? 1 : 0) & 1)) {
+	if (nb_bits <= 10 && ((wc >> (hash_only ? 1 : 0) & 1) || hash_only == 3)) {
 		static const int wcs2 = getenv("YAKAMD_XP_WCS") ? atoi(getenv("YAKAMD_XP_WCS")) : 1;
-		if (hash_only && wcs2 && k < 32) {                         /* the round-stable variant needs 7 slots per stack only: two workgroups per CU */
+		if (hash_only && (wcs2 || hash_only == 3) && k < 32) {   /* hash_only == 3: bare hashes with the range tag (the caller checked k and nb_bits) */                         /* the round-stable variant needs 7 slots per stack only: two workgroups per CU */
 			static bool attr4 = false;
 			if (!attr4) { hipFuncSetAttribute((const void*)k_xpart_wcs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr4 = true; }
 			hipLaunchKernelGGL(k_xpart_wcs<false>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
-			                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out);
+			                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, hash_only == 3);
 		}
 		else if (hash_only) hipLaunchKernelGGL(k_xpart_wc<2>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<8, XW_CAP_H, false>(1 << nb_bits, XW_NT)), st,
 		                                  bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
@@ -4093,7 +4194,7 @@ void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
 
 size_t yk_count_own_lds(u32 range_len, u32 kmax) { const u32 nw = (range_len + 31) / 32; return (size_t)2 * ((nw + 1) & ~1u) * 4 + (size_t)kmax * 8 + (size_t)((kmax + 1) / 2 + 1 & ~1u) * 4 + 16 * 128 * 8 + 16; }   /* bitmap, ranks, keys, counters, 16 wave queues */
 
-int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
+int yk_launch_img_count_own(const void *rec, int hash_only, int cross, int ytag, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
                             size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st)
 {
 	static bool attr = false;
@@ -4104,7 +4205,7 @@ int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64
 	}
 	const int n_p = phi - plo;
 	const dim3 grid((unsigned)((n_p + 7) / 8 * 8) << rb), blk(1024);
-#define YK_OWN(Wv, Cv) hipLaunchKernelGGL((k_img_count_own<Wv, Cv>), grid, blk, lds, st, (const u64*)rec, bstart, img, plo, n_p, rb, rng_log, kmax, list, list_n, list_cap)
+#define YK_OWN(Wv, Cv) hipLaunchKernelGGL((k_img_count_own<Wv, Cv>), grid, blk, lds, st, (const u64*)rec, bstart, img, plo, n_p, rb, rng_log, kmax, list, list_n, list_cap, ytag)
 	if (hash_only) { if (cross) YK_OWN(1, 1); else YK_OWN(1, 0); }
 	else { if (cross) YK_OWN(2, 1); else YK_OWN(2, 0); }
 #undef YK_OWN
@@ -4119,9 +4220,17 @@ void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0,
 }
 void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, fail);
+	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, fail, (u32)yk_r2_small_f());
 }
-int yk_r2_small_f(void) { return (int)R2_SMALL_F; }
+int yk_r2_small_f(void)                                            /* YAKAMD_R2_SMALL_F: test / tuning knob, a power of two in [16, 4096] */
+{
+	const char *e = getenv("YAKAMD_R2_SMALL_F");
+	int v = e ? atoi(e) : (int)R2_SMALL_F;
+	if (v < 16) v = 16;
+	if (v > 4096) v = 4096;
+	while (v & (v - 1)) v &= v - 1;
+	return v;
+}
 void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail,
                   u64 *long_list, u32 *long_n, u32 long_cap, hipStream_t st)
 {
@@ -4176,6 +4285,15 @@ void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom
 	const int wgs = getenv("YAKAMD_LC2_WGS") ? atoi(getenv("YAKAMD_LC2_WGS")) : 256 * 5;   /* 5 workgroups of 32 KB LDS per CU */
 	const unsigned grid = n_sb < (unsigned)wgs ? n_sb : (unsigned)wgs;
 	if (grid) hipLaunchKernelGGL(k_lc2, dim3(grid), dim3(256), 0, st, fp, sbstart, rec, bloom32, img, O, counters, ovf_list, n_sb);
+	if (grid && (fp.dbg & 128)) {
+		u64 h[8];
+		hipStreamSynchronize(st);
+		hipMemcpyFromSymbol(h, HIP_SYMBOL(d_lc2_prof), sizeof(h));
+		if (h[4]) fprintf(stderr, "[yak_amd] k_lc2 clocks per sub-bucket (lane 0, mean over %llu): A %llu, gate %llu, set+select %llu, write-back+clean %llu; inside A: wait for the records %llu, lane 0's puts %llu\n", (unsigned long long)h[4],
+		                  (unsigned long long)(h[0] / h[4]), (unsigned long long)(h[1] / h[4]), (unsigned long long)(h[2] / h[4]), (unsigned long long)(h[3] / h[4]), (unsigned long long)(h[5] / h[4]), (unsigned long long)(h[6] / h[4]));
+		for (int i = 0; i < 8; ++i) h[i] = 0;
+		hipMemcpyToSymbol(HIP_SYMBOL(d_lc2_prof), h, sizeof(h));
+	}
 }
 
 void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st)

@@ -206,7 +206,7 @@ int yk_r2_small_f(void);
 int yk_r2_seg_log(void);
 int yk_r2_head(void);
 size_t yk_count_own_lds(u32 range_len, u32 kmax);
-int yk_launch_img_count_own(const void *rec, int hash_only, int cross, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
+int yk_launch_img_count_own(const void *rec, int hash_only, int cross, int ytag, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
                             size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
 int yk_lc2_ok(FastParams fp);
 void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters, u32 *ovf_list, hipStream_t st);
