@@ -1,0 +1,55 @@
+"""Full-size goldens from the reference itself, run by the driver's GPU tier.
+
+tests/golden/cfg2_full.json and cfg45_full.json hold the md5 + size of the `.yak` files the REFERENCE binary
+(oracle/_ref/yak, compiled from /root/reference, tests/gen_golden_full.py) wrote for workloads tools/yaksynth
+regenerates from a seed: nothing of the reference is needed at run time.  bench.py compares the device result
+with them (`verify.equals_reference`) and exits non-zero on a mismatch; here each workload is one bench step.
+  * no filter, 10 M reads: 217 M distinct k-mers, one pass, every instance a put-call (htab.c:66-69);
+  * 30 M reads with the filter: 4.5 G stream positions, a pass counted in two slices (> 2^32 - 16 positions);
+  * cfg4 at 1 Gb (10 x 100 Mb contigs, k = 21, count.c:28-43,120-125): sub-tables of 2 Mi slots, streaming replay
+    through five doublings beyond the LDS-resident sizes;
+  * cfg5: `yak qv -p` CT histogram of 75 K x 20 kb reads against the cfg2 table (qv.c:34-135).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("YAKAMD_SKIP_FULLSIZE") == "1", reason="YAKAMD_SKIP_FULLSIZE=1")]
+
+
+def bench_line(*args):
+    import yak_amd
+    if yak_amd.lib().yakamd_device_count() < 1:
+        pytest.skip("no MI355X visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-qv", "--no-pcie"] + list(args),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_no_filter_10m_reads_equals_reference():
+    d = bench_line("--config", "nofilter")
+    assert d["verify"]["equals_reference"] is True and d["verify"]["batch_independent"] is True
+    assert d["final_distinct"] > 200e6
+
+
+def test_30m_reads_sliced_pass_equals_reference():
+    d = bench_line("--reads", "30000000")
+    assert d["verify"]["equals_reference"] is True
+
+
+def test_cfg4_1gb_assembly_equals_reference():
+    d = bench_line("--config", "cfg4", "--contigs", "10", "--contig-len", "100000000")
+    v = d["verify"]
+    assert v["equals_reference"] is True and v["sum_sizes_equals_tot"] and v["count_mass_equals_instances"] and v["load_rule"]
+    assert v["yak_size_bytes"] == 7998181472                   # = 16 + 8 P + 8 D, the reference's file size
+
+
+def test_cfg5_qv_histogram_equals_reference():
+    d = bench_line("--config", "cfg5")
+    assert d["verify"]["equals_reference"] is True and d["verify"]["kmers"] == d["verify"]["kmers_expected"]
