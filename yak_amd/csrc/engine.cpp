@@ -26,6 +26,9 @@
 
 static thread_local char g_err[512] = "";
 
+#ifdef R2_PROF
+extern "C" void yk_r2_prof_print(void);
+#endif
 static int fail(const char *fmt, ...)
 {
 	va_list ap;
@@ -1167,7 +1170,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	u64 n_keys = 0;
 	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
 	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
-	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 2 * (size_t)P) || dmalloc(&misc, 4)) return -1;
+	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 4 * (size_t)P) || dmalloc(&misc, 4)) return -1;
 	HIPCK(hipMemcpyAsync(d_tabs, tabs.data(), P * sizeof(R2Tab), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_acts, acts.data(), acts.size() * sizeof(R2Act), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_ld, ld.data(), P * sizeof(R2Load), hipMemcpyHostToDevice, c->st));
@@ -1196,21 +1199,25 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		if (any_d) {
 			yk_r2_dinit(d_tabs, da, P, bd, K0, K1, TAG, OCC, c->st);
 			lap("dinit", k, bd, &tl);
-			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, d_fail, c->st);
+			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, Fc + 2 * P, d_fail, c->st);
 			lap("dsmall", k, bd, &tl);
 			const u64 n = 1ull << bd, SF = (u64)yk_r2_small_f();
 			int cur = 0;
+			HIPCK(hipMemsetAsync(misc + 2, 0, 8, c->st));           /* the two long-run counters the rounds alternate between */
 			for (u64 reach = SF; reach < 2 * n; reach <<= 1) {       /* F at least doubles... it cannot: G <= 2F; so one round per factor of two, plus slack for short rounds */
 				const u64 span = std::min<u64>(n, 2 * reach);
-				yk_r2_dround(d_tabs, da, P, (u32)span, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, d_fail, spill, misc + 2, spill_cap, c->st);
+				yk_r2_dround(d_tabs, da, P, (u32)span, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, Fc + (2 + cur) * P, Fc + (2 + (cur ^ 1)) * P, d_fail, spill, misc + 2 + cur, misc + 2 + (cur ^ 1), spill_cap, c->st);
 				cur ^= 1;
 			}
 			/* rounds can be shorter than a factor of two (the boundary is the last unused slot before 2F): finish whatever is left */
 			for (int extra = 0; extra < 2; ++extra) {
-				yk_r2_dround(d_tabs, da, P, (u32)n, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, d_fail, spill, misc + 2, spill_cap, c->st);
+				yk_r2_dround(d_tabs, da, P, (u32)n, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, Fc + (2 + cur) * P, Fc + (2 + (cur ^ 1)) * P, d_fail, spill, misc + 2 + cur, misc + 2 + (cur ^ 1), spill_cap, c->st);
 				cur ^= 1;
 			}
 			lap("drounds", k, bd, &tl);
+#ifdef R2_PROF
+			if (prof) yk_r2_prof_print();
+#endif
 			/* every doubling sub-table must have reached its end */
 			std::vector<u32> Fh(P);
 			HIPCK(hipMemcpyAsync(Fh.data(), Fc + cur * P, P * 4, hipMemcpyDeviceToHost, c->st));

@@ -2221,7 +2221,7 @@ void k_r2_dinit(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG
 
 /* the prefix by the literal rule, then the rounds below R2_SMALL_F; one workgroup per sub-table */
 __global__ __launch_bounds__(256)
-void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, u32 small_f)
+void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, u32 small_f)
 {
 	__shared__ R2Wave s_wave[4];
 	__shared__ u32 s_long[256];
@@ -2296,7 +2296,7 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 		__syncthreads();
 		F = G;
 	}
-	if (tid == 0) Fcur[p] = F;
+	if (tid == 0) { Fcur[p] = F; Gcur[p] = F < n ? r2_boundary(S, F, 2 * F < n ? 2 * F : n, n) : n; }   /* the first round of k_r2_dround */
 }
 
 /* One round [F, G) of every sub-table still doubling.  A wave takes R2_CH consecutive old slots: keys and tags come
@@ -2306,41 +2306,70 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
  * the runs keep to their own regions by themselves.  A lane per key, uniform work, no dependent global access; the
  * window goes back with coalesced stores.  Slots a chain of the prefix took are marked from the OCC bits.  Runs longer
  * than R2_CHL, or touching the end of the table, are listed for k_r2_long. */
-#define R2_CH  256u
+#ifndef R2_CH
+#define R2_CH  128u
+#endif
 #define R2_CHL 32u
 #define R2_CHX (R2_CHL + 8)
 #define R2_NA  (R2_CH + R2_CHX + 1)
 #define R2_WN  (2 * (R2_CH + R2_CHX) + 2)
+#ifdef R2_PROF
+__device__ u64 d_r2_prof[8];
+#endif
 __global__ __launch_bounds__(64)
-void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap)
+void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap)
 {
 	__shared__ u64 s_key[R2_NA];                                             /* s_key[x] = old slot c0 - 1 + x */
 	__shared__ u32 s_tag[R2_NA];
 	__shared__ short s_le[R2_NA], s_ne[R2_NA];                               /* last unused slot at or before x (-1: none), next unused slot at or after x (R2_NA: none) */
 	__shared__ u64 s_win[R2_WN];                                             /* (time + 1) << 32 | x; 0 = taken before this round; ~0 = free */
+	__shared__ u32 s_oc[R2_WN / 32 + 2];
 	const u32 p = blockIdx.y, lane = threadIdx.x;
 	const R2Act A = acts[p];
 	if (A.kind != 2) return;
-	const u32 n = 1u << A.bits, nb = A.bits + 1, F = Fcur[p];
-	if (F >= n) { if (blockIdx.x == 0 && lane == 0) Fnext[p] = F; return; }
+	const u32 n = 1u << A.bits, nb = A.bits + 1, F = Fcur[p], G = Gcur[p];   /* the round's end was found by the round before (or k_r2_dsmall) */
+	if (F >= n) { if (blockIdx.x == 0 && lane == 0) { Fnext[p] = F; Gnext[p] = n; } return; }
 	const u64 off = tabs[p].off;
 	u64 *S = (A.src ? K1 : K0) + off, *D = (A.src ? K0 : K1) + off;
 	u32 *TG = TAG + (off >> 1);
 	const u32 *OC = OCC + (off >> 4);
-	const u32 G = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
-	if (G == 0) { if (blockIdx.x == 0 && lane == 0) { *fail = 3; Fnext[p] = n; } return; }
-	if (blockIdx.x == 0 && lane == 0) Fnext[p] = G;
-	const u32 PER = (R2_NA + 63) / 64;
-	for (u32 c0 = F + blockIdx.x * R2_CH; c0 < G; c0 += gridDim.x * R2_CH) {
-		const u32 w0 = 2 * c0;
-		for (u32 x = lane; x < R2_NA; x += 64) {
-			const u32 sl = c0 - 1 + x;                                          /* c0 >= F >= 8 */
-			s_key[x] = sl < n ? S[sl] : YK_EMPTY;
-			s_tag[x] = sl < n ? TG[sl] : R2_NONE;
+	if (G == 0) { if (blockIdx.x == 0 && lane == 0) { *fail = 3; Fnext[p] = n; Gnext[p] = n; } return; }
+	if (blockIdx.x == 0 && lane == 0) { Fnext[p] = G; Gnext[p] = G < n ? r2_boundary(S, G, 2 * G < n ? 2 * G : n, n) : n; }   /* used slots stay used (R2_MOVED): the next boundary can be looked up now */
+	constexpr u32 PER = (R2_NA + 63) / 64, NOC = R2_WN / 32 + 2;
+	/* a workgroup (one wave) walks several chunks; the next chunk's keys, tags and OCC words travel while this one is placed */
+	u64 rk[PER]; u32 rt[PER], roc = 0;
+	auto fetch = [&](const u32 c0) {
+#pragma unroll
+		for (u32 j = 0; j < PER; ++j) {
+			const u32 sl = c0 - 1 + lane + 64 * j;                              /* c0 >= F >= 8 */
+			const u32 cl = sl < n ? sl : n - 1;
+			rk[j] = S[cl]; rt[j] = TG[cl];
 		}
+		roc = OC[((2 * c0) >> 5) + (lane < NOC ? lane : 0)];
+	};
+	u32 c0 = F + blockIdx.x * R2_CH;
+#ifdef R2_PROF
+	u64 pf[6] = { 0, 0, 0, 0, 0, 0 }, tq = __builtin_readcyclecounter(), tq0 = tq;
+#define R2_LAP(i) { const u64 t_ = __builtin_readcyclecounter(); pf[i] += t_ - tq; tq = t_; }
+#else
+#define R2_LAP(i)
+#endif
+	if (c0 < G) fetch(c0);
+	while (c0 < G) {
+		const u32 w0 = 2 * c0;
+#pragma unroll
+		for (u32 j = 0; j < PER; ++j) {
+			const u32 x = lane + 64 * j, sl = c0 - 1 + x;
+			if (x < R2_NA) { s_key[x] = sl < n ? rk[j] : YK_EMPTY; s_tag[x] = sl < n ? rt[j] : R2_NONE; }
+		}
+		if (lane < NOC) s_oc[lane] = roc;
+		const u32 c1 = c0 + gridDim.x * R2_CH;
+		if (c1 < G) fetch(c1);
+		__syncthreads();
+		R2_LAP(0)
 		for (u32 i = lane; i < R2_WN; i += 64) {
-			const u32 q = w0 + i;
-			s_win[i] = (q < 2 * n && (OC[q >> 5] >> (q & 31) & 1)) ? 0ull : ~0ull;
+			const u32 q = w0 + i, b = (w0 & 31) + i;
+			s_win[i] = (q < 2 * n && (s_oc[b >> 5] >> (b & 31) & 1)) ? 0ull : ~0ull;
 		}
 		__syncthreads();
 		{	/* last / next unused slot: every lane owns PER consecutive entries, the lanes are linked by a shuffle scan */
@@ -2361,6 +2390,7 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x >= R2_NA) continue; if (s_key[x] == YK_EMPTY) run_ne = (int)x; s_ne[x] = (short)run_ne; }
 		}
 		__syncthreads();
+		R2_LAP(1)
 		const u32 lim = (G < c0 + R2_CH ? G : c0 + R2_CH) - c0;              /* runs start in [c0, c0 + lim) */
 		for (u32 x = lane + 1; x < R2_NA; x += 64) {
 			const u64 key = s_key[x];
@@ -2389,6 +2419,7 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 			}
 		}
 		__syncthreads();
+		R2_LAP(2)
 		for (u32 i = lane; i < R2_WN; i += 64) {
 			const u64 e = s_win[i];
 			if (e == ~0ull || (e >> 32) == 0) continue;
@@ -2397,15 +2428,21 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 			if (q < n) TG[q] = (u32)(e >> 32) - 1;
 		}
 		__syncthreads();
+		R2_LAP(3)
+		c0 = c1;
 	}
+#ifdef R2_PROF
+	if (lane == 0) { pf[4] = __builtin_readcyclecounter() - tq0; for (int i = 0; i < 5; ++i) atomicAdd(&d_r2_prof[i], pf[i]); atomicAdd(&d_r2_prof[5], 1ull); }
+#endif
 }
 
 /* the long runs of the round just launched, a wave each */
 __global__ __launch_bounds__(64)
-void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u64 *long_list, const u32 *long_n, u32 long_cap, u32 *fail)
+void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u64 *long_list, const u32 *long_n, u32 *long_n_next, u32 long_cap, u32 *fail)
 {
 	__shared__ R2Wave W;
 	const u32 nl = *long_n < long_cap ? *long_n : long_cap;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *long_n_next = 0;           /* the next round counts into the other counter: no fill kernel between the rounds */
 	for (u32 j = blockIdx.x; j < nl; j += gridDim.x) {
 		const u32 p = (u32)(long_list[j] >> 32), a = (u32)long_list[j];
 		const R2Act A = acts[p];
@@ -4218,9 +4255,9 @@ void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0,
 	const u64 N = 2ull << bmax;
 	hipLaunchKernelGGL(k_r2_dinit, dim3((unsigned)std::min<u64>((N + 1023) / 1024, 4096), P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC);
 }
-void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *fail, hipStream_t st)
+void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, fail, (u32)yk_r2_small_f());
+	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Gcur, fail, (u32)yk_r2_small_f());
 }
 int yk_r2_small_f(void)                                            /* YAKAMD_R2_SMALL_F: test / tuning knob, a power of two in [16, 4096] */
 {
@@ -4231,14 +4268,27 @@ int yk_r2_small_f(void)                                            /* YAKAMD_R2_
 	while (v & (v - 1)) v &= v - 1;
 	return v;
 }
-void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, u32 *fail,
-                  u64 *long_list, u32 *long_n, u32 long_cap, hipStream_t st)
+void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail,
+                  u64 *long_list, u32 *long_n, u32 *long_n_next, u32 long_cap, hipStream_t st)
 {
-	hipMemsetAsync(long_n, 0, 4, st);
-	const u32 blocks = (span + R2_CH - 1) / R2_CH;                      /* `span` old slots per sub-table at most in this round */
-	hipLaunchKernelGGL(k_r2_dround, dim3(blocks < (1u << 20) ? blocks : 1u << 20, P), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, fail, long_list, long_n, long_cap);
-	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_cap, fail);
+	static const u32 cpw = getenv("YAKAMD_R2_CPW") ? (u32)std::max(1, atoi(getenv("YAKAMD_R2_CPW"))) : 4;   /* chunks per wave */
+	const u32 chunks = (span + R2_CH - 1) / R2_CH;                      /* `span` old slots per sub-table at most in this round */
+	const u32 blocks = (chunks + cpw - 1) / cpw;
+	hipLaunchKernelGGL(k_r2_dround, dim3(blocks < (1u << 20) ? blocks : 1u << 20, P), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, Gcur, Gnext, fail, long_list, long_n, long_cap);
+	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_n_next, long_cap, fail);
 }
+#ifdef R2_PROF
+void yk_r2_prof_print(void)
+{
+	u64 h[8];
+	hipDeviceSynchronize();
+	hipMemcpyFromSymbol(h, HIP_SYMBOL(d_r2_prof), sizeof(h));
+	if (h[5]) fprintf(stderr, "[yak_amd] k_r2_dround clocks (lane 0 sums / %llu waves): load+stage %llu, window+scans %llu, probing %llu, write-back %llu, whole wave %llu\n", (unsigned long long)h[5],
+	                  (unsigned long long)(h[0] / h[5]), (unsigned long long)(h[1] / h[5]), (unsigned long long)(h[2] / h[5]), (unsigned long long)(h[3] / h[5]), (unsigned long long)(h[4] / h[5]));
+	for (int i = 0; i < 8; ++i) h[i] = 0;
+	hipMemcpyToSymbol(HIP_SYMBOL(d_r2_prof), h, sizeof(h));
+}
+#endif
 int yk_r2_seg_log(void) { const int v = getenv("YAKAMD_R2_SEG_LOG") ? atoi(getenv("YAKAMD_R2_SEG_LOG")) : R2_SEG_LOG; return v < 10 ? 10 : v > R2_SEG_LOG ? R2_SEG_LOG : v; }   /* the knob lets tests split small tables */
 int yk_r2_head(void) { const u32 seg = 1u << yk_r2_seg_log(); return (int)(seg / 2 < R2_HEAD ? seg / 2 : R2_HEAD); }
 void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
