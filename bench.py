@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not queue the pass-2 exchange behind pass 1's computation")
     ap.add_argument("--job-md5", action="store_true", help="also report the md5 of the whole job's .yak bytes (sub-tables gathered from all ranks)")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
+    ap.add_argument("--no-packed", action="store_true", help="skip the packed-image (0.375 B/base) side measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
     maybe_spawn(a)
@@ -236,9 +237,14 @@ def main():
 
     pending = [None]      # the pass-2 exchange of the step in flight (queued while pass 1 computes)
 
+    packed = [None]       # (codes, valid): the side measurement with the image at 0.375 B per base (yakamd_feed_packed_dev)
+
     def one_pass(t, create_new):
         if not sharded:
-            t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
+            if packed[0] is not None:
+                t.count_pass_packed(create_new, [(packed[0][0].data_ptr(), packed[0][1].data_ptr(), n_bytes, 0)])
+            else:
+                t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
             return
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
@@ -377,6 +383,36 @@ def main():
         import __graft_entry__ as ge
         ge.smoke()
 
+    # the same protocol from the PACKED image (2-bit codes + validity bits, 0.375 B per base; north_star: "packed reads"): a side
+    # measurement with its own md5 check -- the default line reads the ASCII image the reference's parser hands over
+    packed_probe = None
+    if not a.no_packed and not sharded:
+        nw = (n_bytes + 31) // 32
+        d_codes = torch.empty(2 * nw + 4, dtype=torch.int32, device=dev)
+        d_valid = torch.empty(nw + 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        tpk = time.perf_counter()
+        if L.yakamd_pack_bases_dev(d_reads.data_ptr(), n_bytes, d_codes.data_ptr(), d_valid.data_ptr(), None) != 0:
+            raise RuntimeError("pack: " + yak_amd._err())
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - tpk) * 1e3
+        packed[0] = (d_codes, d_valid)
+        step()
+        barrier()
+        tpk = time.perf_counter()
+        for _ in range(2):
+            step()
+        barrier()
+        pk_ms = (time.perf_counter() - tpk) / 2 * 1e3
+        t_p, _, _, _ = step(keep=True)
+        md5_p = t_p.dump_md5()[0]; t_p.close()
+        packed[0] = None
+        packed_probe = {"ms_per_step": pk_ms, "bytes_per_base": 0.375, "pack_kernel_ms": pack_ms, "yak_md5": md5_p,
+                        "equals_ascii_run": (md5_p == verify["yak_md5"]) if verify else None}
+        if verify and md5_p != verify["yak_md5"]:
+            raise SystemExit("FAILED: the packed image gives another .yak than the ASCII image")
+        del d_codes, d_valid
+
     # second kernel family (BASELINE configs[4]): the lookup-only kernel of `yak qv`
     # on the table just built, over the same resident reads -- a side measurement, never `value`
     qv_probe = None
@@ -436,10 +472,12 @@ def main():
                 subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(a.reads), "-l", str(READ_LEN), "-g", str(genome), "-s", "42",
                                        "-t", str(min(threads, 32)), "-o", fq])
                 cmd = [cli, "count", f"-k{K}", f"-t{min(threads, 32)}", "-o", os.path.join(tmp, "o.yak")] + ([f"-b{a.bf_shift}"] if a.bf_shift else []) + [fq]
-                subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)        # file into the page cache, HIP start-up files touched
-                tq = time.perf_counter()
-                subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-                e2e = {"ms": (time.perf_counter() - tq) * 1e3, "command": " ".join(os.path.basename(x) if os.sep in x else x for x in cmd),
+                runs = []
+                for _ in range(2):       # a process that starts right after another one released ~60 GB of HBM waits for the driver to hand
+                    tq = time.perf_counter()   # those pages out again (measured: +1.5 s before the first batch): both runs are reported, `ms` is the better one
+                    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+                    runs.append((time.perf_counter() - tq) * 1e3)
+                e2e = {"ms": min(runs), "ms_runs": runs, "command": " ".join(os.path.basename(x) if os.sep in x else x for x in cmd),
                        "fastq_bytes": os.path.getsize(fq), "yak_md5": hashlib.md5(open(os.path.join(tmp, "o.yak"), "rb").read()).hexdigest()}
                 if verify and e2e["yak_md5"] != verify["yak_md5"]:
                     raise SystemExit("FAILED: the CLI's .yak differs from the device-resident run's")
@@ -545,7 +583,7 @@ def main():
         "verify": verify,
         "job_yak_md5": job_md5,
         "qv_lookup_probe": qv_probe,
-        "pcie_inclusive_ms": pcie_ms, "pcie_inclusive_value": (tot_all / (pcie_ms * 1e-3)) if pcie_ms else None,
+        "packed_input": packed_probe, "pcie_inclusive_ms": pcie_ms, "pcie_inclusive_value": (tot_all / (pcie_ms * 1e-3)) if pcie_ms else None,
         "e2e_cli": e2e,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }

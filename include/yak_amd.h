@@ -41,6 +41,14 @@ int yakamd_set_shard(yak_ch_t *h, int prefix_lo, int prefix_hi);
 int yakamd_pass_begin(yak_ch_t *h, int create_new);
 int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0);
 int yakamd_feed_bases_host(yak_ch_t *h, const void *h_bases, int64_t n_bytes, uint64_t t0);
+/* the same stream packed to 0.375 bytes per base (what count.c:28-43 keeps of a base: its 2-bit code, or "not ACGT"): d_codes =
+ * 32-bit words of 16 bases, base j of the stream at bits 2 (j % 16) of word j / 16, code = seq_nt4_table (A 0, C 1, G 2, T 3);
+ * d_valid = one bit per base, bit j % 32 of word j / 32, 0 for N / any other byte / the separator between two records.
+ * Both device pointers, the codes 16-byte aligned; words past n_bases are not read beyond the last partial one.  The counting
+ * passes then read 0.375 B per position instead of 1 */
+int yakamd_feed_packed_dev(yak_ch_t *h, const void *d_codes, const void *d_valid, int64_t n_bases, uint64_t t0);
+/* device-side packer: ASCII image -> d_codes ((n + 31) / 32 * 8 bytes) and d_valid ((n + 31) / 32 * 4 bytes); `stream` = a hipStream_t or 0 */
+int yakamd_pack_bases_dev(const void *d_ascii, int64_t n, void *d_codes, void *d_valid, void *stream);
 /* already hashed k-mers (yak_hash64 output) with their stream positions t0 + t[i], t[i] < t_span;
  * device pointers */
 int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash_u64, const void *d_t_u32, int64_t n,

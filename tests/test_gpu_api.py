@@ -412,3 +412,42 @@ def test_concurrent_get_after_restore(ya, oracle, synth, tmp_path):
         t.join()
     assert all(g == want for g in got) and any(v > 0 for v in want) and any(v < 0 for v in want)
     L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+@pytest.mark.parametrize("k,bf", [(31, 0), (31, 22), (21, 0), (41, 20)])
+def test_packed_image_feed_equals_ascii_feed(k, bf, ya, oracle, synth):
+    """yakamd_feed_packed_dev (2-bit codes + validity bits, 0.375 B per base) must give what the ASCII image gives --
+    count.c:28-43 keeps nothing else of a base -- for both passes of the protocol, Ns and read ends included, and with
+    the image cut where a tile does not end (n not a multiple of 16 / 32 / 4096)"""
+    L, O = ya.lib(), oracle.lib()
+    img = synth(4001, g=20000, s=9, N=0.004)
+    img = img[:len(img) - 7]
+    n = len(img)
+    d_a = L.yakamd_dev_alloc(n + 64); assert d_a
+    nw = (n + 31) // 32
+    d_c = L.yakamd_dev_alloc(8 * nw + 64); d_v = L.yakamd_dev_alloc(4 * nw + 64); assert d_c and d_v
+    buf = (C.c_char * n).from_buffer_copy(img)
+    assert L.yakamd_memcpy_h2d(d_a, buf, n) == 0
+    assert L.yakamd_pack_bases_dev(d_a, n, d_c, d_v, None) == 0
+    # the packer itself against a host restatement
+    codes = (C.c_uint32 * (2 * nw))(); valid = (C.c_uint32 * nw)()
+    assert L.yakamd_memcpy_d2h(codes, d_c, 8 * nw) == 0 and L.yakamd_memcpy_d2h(valid, d_v, 4 * nw) == 0
+    nt4 = {65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3}
+    for j in list(range(0, 200)) + list(range(n - 70, n)):
+        c = nt4.get(img[j])
+        assert (valid[j >> 5] >> (j & 31) & 1) == (c is not None)
+        if c is not None:
+            assert (codes[j >> 4] >> (2 * (j & 15)) & 3) == c
+    tp = ya.Table(k, 10, 4, bf); ta = ya.Table(k, 10, 4, bf)
+    tp.count_pass_packed(1, [(d_c, d_v, n, 0)]); ta.count_pass(1, [(d_a, n, 0)])
+    assert tp.dump_bytes() == ta.dump_bytes() and tp.tot == ta.tot
+    oc = oracle.copt(k=k, bf_shift=bf)
+    o = O.yko_count_mem(img, n, C.byref(oc), None)
+    assert tp.dump_bytes() == oracle.dump_bytes(o)
+    if bf:
+        tp.destroy_bf(); tp.clear(); tp.count_pass_packed(0, [(d_c, d_v, n, 0)])
+        O.yko_ch_destroy_bf(o); O.yko_ch_clear(o); O.yko_count_mem(img, n, C.byref(oc), o)
+        assert tp.dump_bytes() == oracle.dump_bytes(o)
+    tp.close(); ta.close(); O.yko_ch_destroy(o)
+    for d in (d_a, d_c, d_v):
+        L.yakamd_dev_free(d)

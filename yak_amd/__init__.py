@@ -25,7 +25,7 @@ YAK_H_SYMBOLS = [
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
-    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_hashed_dev",
+    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
@@ -99,6 +99,10 @@ def lib():
     L.yakamd_pass_begin.restype = C.c_int; L.yakamd_pass_begin.argtypes = [P(ChT), C.c_int]
     L.yakamd_feed_bases_dev.restype = C.c_int
     L.yakamd_feed_bases_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_feed_packed_dev.restype = C.c_int
+    L.yakamd_feed_packed_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_pack_bases_dev.restype = C.c_int
+    L.yakamd_pack_bases_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.yakamd_feed_bases_host.restype = C.c_int
     L.yakamd_feed_bases_host.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
     L.yakamd_feed_hashed_dev.restype = C.c_int
@@ -170,6 +174,19 @@ class Table:
             raise RuntimeError(_err())
         for ptr, n, t0 in feeds:
             if self.L.yakamd_feed_bases_dev(self.h, ptr, n, t0) != 0:
+                raise RuntimeError(_err())
+        n_ins = self.L.yakamd_pass_end(self.h)
+        if n_ins < 0:
+            raise RuntimeError(_err())
+        self.h.contents.tot += n_ins
+        return n_ins
+
+    def count_pass_packed(self, create_new, feeds):
+        """one pass over packed images: feeds = iterable of (codes_ptr, valid_ptr, n_bases, t0) (yakamd_feed_packed_dev)"""
+        if self.L.yakamd_pass_begin(self.h, create_new) != 0:
+            raise RuntimeError(_err())
+        for codes, valid, n, t0 in feeds:
+            if self.L.yakamd_feed_packed_dev(self.h, codes, valid, n, t0) != 0:
                 raise RuntimeError(_err())
         n_ins = self.L.yakamd_pass_end(self.h)
         if n_ins < 0:

@@ -86,17 +86,20 @@ static inline u32 kh_bits_for(u32 want)
 #include <unordered_map>
 struct DevPool {
 	std::mutex mu;
-	std::multimap<size_t, void*> idle;
+	struct Idle { void *p; u64 stamp; };
+	std::multimap<size_t, Idle> idle;
+	std::map<u64, std::multimap<size_t, Idle>::iterator> by_age;   /* beyond the cap the blocks idle for longest go back to the driver */
 	std::unordered_map<void*, size_t> size_of;
 	size_t cached = 0;
+	u64 clock = 0;
 };
 static DevPool g_pool[16];
 static DevPool &pool_here() { int d = 0; (void)hipGetDevice(&d); return g_pool[d & 15]; }
 
 static void pool_trim(DevPool &P)
 {
-	for (auto &kv : P.idle) { (void)hipFree(kv.second); P.size_of.erase(kv.second); }
-	P.idle.clear(); P.cached = 0;
+	for (auto &kv : P.idle) { (void)hipFree(kv.second.p); P.size_of.erase(kv.second.p); }
+	P.idle.clear(); P.by_age.clear(); P.cached = 0;
 }
 
 static void *pool_alloc(size_t bytes)
@@ -109,8 +112,9 @@ static void *pool_alloc(size_t bytes)
 	if (on) {
 		auto it = P.idle.lower_bound(bytes);
 		if (it != P.idle.end() && it->first <= bytes + bytes / 4) {
-			void *p = it->second;
+			void *p = it->second.p;
 			P.cached -= it->first;
+			P.by_age.erase(it->second.stamp);
 			P.idle.erase(it);
 			return p;
 		}
@@ -128,7 +132,7 @@ static void *pool_alloc(size_t bytes)
 static void pool_free(void *p)
 {
 	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
-	static const size_t cap = (size_t)env_i64("YAKAMD_POOL_MAX_GB", 96) << 30;   /* idle bytes kept per device; beyond that the largest blocks go back to the driver */
+	static const size_t cap = (size_t)env_i64("YAKAMD_POOL_MAX_GB", 96) << 30;   /* idle bytes kept per device */
 	/* the block's owner is the pool that handed it out, whatever device is current now */
 	DevPool *Pp = &pool_here();
 	{
@@ -140,12 +144,13 @@ static void pool_free(void *p)
 	std::lock_guard<std::mutex> lk(P.mu);
 	auto it = P.size_of.find(p);
 	if (!on || it == P.size_of.end()) { if (it != P.size_of.end()) P.size_of.erase(it); (void)hipFree(p); return; }
-	P.idle.insert({ it->second, p });
+	const u64 stamp = ++P.clock;
+	P.by_age[stamp] = P.idle.insert({ it->second, DevPool::Idle{ p, stamp } });
 	P.cached += it->second;
-	while (P.cached > cap && !P.idle.empty()) {
-		auto big = std::prev(P.idle.end());
-		P.cached -= big->first; P.size_of.erase(big->second); (void)hipFree(big->second);
-		P.idle.erase(big);
+	while (P.cached > cap && !P.by_age.empty()) {          /* least recently freed first: the buffers of the running job stay */
+		auto old = P.by_age.begin()->second;
+		P.cached -= old->first; P.size_of.erase(old->second.p); (void)hipFree(old->second.p);
+		P.idle.erase(old); P.by_age.erase(P.by_age.begin());
 	}
 }
 
@@ -768,7 +773,22 @@ static int fast_keep(yakamd_ctx *c, u64 n_rec)
 	return 0;
 }
 
-extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0)
+static int feed_image(yak_ch_t *h, const void *d_bases, const u32 *d_valid, int64_t n_bytes, uint64_t t0);
+extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0) { return feed_image(h, d_bases, 0, n_bytes, t0); }
+/* the same stream at 0.375 bytes per base: 2-bit codes, 16 bases per 32-bit word (base j at bits 2 (j % 16)), and a validity bit
+ * per base (bit j % 32 of word j / 32; 0 = N, any other non-ACGT byte or a record separator).  Position j of the stream is base j */
+extern "C" int yakamd_feed_packed_dev(yak_ch_t *h, const void *d_codes, const void *d_valid, int64_t n_bases, uint64_t t0)
+{
+	if (!d_valid) return fail("packed feed without a validity mask");
+	if (((uintptr_t)d_valid & 3) != 0) return fail("validity mask must be 4-byte aligned");
+	return feed_image(h, d_codes, (const u32*)d_valid, n_bases, t0);
+}
+extern "C" int yakamd_pack_bases_dev(const void *d_ascii, int64_t n, void *d_codes, void *d_valid, void *stream)
+{
+	yk_launch_pack((const uint8_t*)d_ascii, n, (u32*)d_codes, (u32*)d_valid, (hipStream_t)stream);
+	return hipGetLastError() == hipSuccess ? 0 : fail("pack kernel launch failed");
+}
+static int feed_image(yak_ch_t *h, const void *d_bases, const u32 *d_valid, int64_t n_bytes, uint64_t t0)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("feed outside a pass");
@@ -798,7 +818,7 @@ extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n
 		{
 			EvTimer tm(c->st);
 			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
-			                c->d_rows, c->d_partial, c->d_bstart, out, (c->fast && c->kept.back().fmt) ? 2 : hash_only, c->st);
+			                c->d_rows, c->d_partial, c->d_bstart, out, (c->fast && c->kept.back().fmt) ? 2 : hash_only, c->st, d_valid);
 			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
 			c->st_cur.ms_extract += tm.stop();
 		}

@@ -100,13 +100,24 @@ __device__ __forceinline__ void xt_init(XtTile &S)
 }
 
 /* phase 1: translate + pack the tile [tile0 - HALO, tile0 + XT_TILE) into LDS; ends with a barrier */
-__device__ __forceinline__ void xt_load(XtTile &S, const uint8_t *__restrict__ bases, int64_t tile0, int64_t n)
+/* `valid` != 0: the stream comes packed (yakamd_feed_packed_dev) -- `bases` is then the array of 2-bit codes, 16 bases per 32-bit
+ * word in the tile's own layout, `valid` one bit per base; tiles start at multiples of 16 positions, so a word is a word */
+__device__ __forceinline__ void xt_load(XtTile &S, const uint8_t *__restrict__ bases, int64_t tile0, int64_t n, const u32 *__restrict__ valid = 0)
 {
 	const int64_t origin = tile0 - XT_HALO;
 	for (int w = threadIdx.x; w < (XT_TILE + XT_HALO) / 16; w += blockDim.x) {
 		const int64_t pos = origin + 16 * (int64_t)w;
 		u32 code = 0, val = 0;
-		if (pos >= 0 && pos + 16 <= n) {
+		if (valid) {
+			if (pos >= 0 && pos < n) {
+				code = ((const u32*)bases)[pos >> 4];
+				val = (valid[pos >> 5] >> (pos & 16)) & 0xffffu;
+				if (pos + 16 > n) val &= (1u << (n - pos)) - 1;
+				u32 m = 0;                                                    /* invalid positions carry code 0, as the ASCII path leaves them */
+				for (int j = 0; j < 16; ++j) m |= (val >> j & 1u) * (3u << (2 * j));
+				code &= m;
+			}
+		} else if (pos >= 0 && pos + 16 <= n) {
 			const uint4 v = *(const uint4*)(bases + pos);
 			const u32 q[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -268,7 +279,7 @@ __device__ __forceinline__ u32 bucket_of(u64 h, int pre, int nb_bits)
 template <int MODE>   /* 0 = histogram, 1 = scatter {hash, position}, 2 = scatter hash only (count-existing passes), 3 = histogram that also counts, per bucket, the 1024-position rounds that contribute to it (count | rounds << 24) */
 __global__ __launch_bounds__(XT_THREADS)
 void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-             int nb_bits, u32 *rows, Rec *__restrict__ out)
+             int nb_bits, u32 *rows, Rec *__restrict__ out, const u32 *__restrict__ valid)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_bkt[];
 	__shared__ XtTile S;
@@ -283,7 +294,7 @@ void k_xpart(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t
 	for (int t = 0; t < XP_T; ++t) {
 		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
 		if (tile0 >= n) break;
-		xt_load(S, bases, tile0, n);
+		xt_load(S, bases, tile0, n, valid);
 #pragma unroll 4
 		for (int r = 0; r < XT_ROUNDS; ++r) {
 			u64 h;
@@ -425,7 +436,7 @@ __device__ __forceinline__ void wcs_flush(const WcView &w, u32 par, u64 *out)
 template <bool TAG>   /* TAG: tagged records (rows carry the toggle); else bare hashes for the count-existing passes (plain rows) */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))    /* two workgroups per CU: <= 64 VGPRs and <= 80 SGPRs */
 void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int k, int pre, int plo, int phi,
-                 int nb_bits, const u32 *__restrict__ rows, u64 *__restrict__ out, int ytag)
+                 int nb_bits, const u32 *__restrict__ rows, u64 *__restrict__ out, int ytag, const u32 *__restrict__ valid)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 	__shared__ XtTile S;
@@ -442,7 +453,7 @@ void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int
 	for (int t = 0; t < XP_T; ++t) {
 		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
 		if (tile0 >= n) break;
-		xt_load(S, bases, tile0, n);
+		xt_load(S, bases, tile0, n, valid);
 		for (int r = 0; r < XT_TILE / 1024; ++r, par ^= 1) {
 			u64 h;
 			bool ok = xt_kmer(S, r * 1024 + tid, k, mask, kones, tile0, n, &h);
@@ -473,7 +484,7 @@ void k_xpart_wcs(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int
 template <int MODE>   /* 1 = {hash, position}, 2 = hash only */
 __global__ __launch_bounds__(XW_NT)
 void k_xpart_wc(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                int nb_bits, const u32 *__restrict__ rows, const u64 *__restrict__ bstart, void *__restrict__ out)
+                int nb_bits, const u32 *__restrict__ rows, const u64 *__restrict__ bstart, void *__restrict__ out, const u32 *__restrict__ valid)
 {
 	constexpr bool HAS_T = MODE == 1;
 	constexpr int GS = HAS_T ? 4 : 8, CAP = HAS_T ? XW_CAP_T : XW_CAP_H;
@@ -496,7 +507,7 @@ void k_xpart_wc(const uint8_t *__restrict__ bases, int64_t pos0, int64_t n, int6
 	for (int t = 0; t < XP_T; ++t) {
 		const int64_t tile0 = pos0 + ((int64_t)blockIdx.x * XP_T + t) * XT_TILE;
 		if (tile0 >= n) break;
-		xt_load(S, bases, tile0, n);
+		xt_load(S, bases, tile0, n, valid);
 		for (int r = 0; r < XT_TILE / XW_NT; ++r, par ^= 1) {
 			const int q = r * XW_NT + tid;
 			u64 h;
@@ -3869,19 +3880,10 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 			if (qn >= 64) { qn -= 64; probe(s_q[qn + lane]); }
 		}
 	};
-	/* two register sets: the next OWN_U records of every lane travel while the current ones are filtered and probed */
-	u64 ha[OWN_U], hb[OWN_U];
-	fetch(ha, lo);
-	for (u64 i0 = lo;;) {
-		fetch(hb, i0 + STEP);
-		consume(ha, i0);
-		i0 += STEP;
-		if (i0 >= hi) break;
-		fetch(ha, i0 + STEP);
-		consume(hb, i0);
-		i0 += STEP;
-		if (i0 >= hi) break;
-	}
+	/* (a second register set with the next OWN_U records in flight while these are probed was measured: same time, and the eight
+	 * range workgroups of a sub-table drift apart in the stream, so HBM fetches rise from 1.2x to 2.2x of the records) */
+	u64 ha[OWN_U];
+	for (u64 i0 = lo; i0 < hi; i0 += STEP) { fetch(ha, i0); consume(ha, i0); }
 	if (lane < qn) probe(s_q[lane]);
 	if (CROSS) return;
 	__syncthreads();
@@ -3911,9 +3913,28 @@ void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_
 	hipLaunchKernelGGL(k_extract, dim3((unsigned)tiles), dim3(XT_THREADS), 0, st, bases, pos0, n, t_sub, k, pre, plo, phi, out_hash, out_t, cursor);
 }
 
+/* ASCII image -> the packed image of yakamd_feed_packed_dev: 32 bases per lane, two code words and one validity word */
+__global__ __launch_bounds__(256)
+void k_pack(const uint8_t *__restrict__ a, int64_t n, u32 *__restrict__ codes, u32 *__restrict__ valid)
+{
+	const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x, p0 = w * 32;
+	if (p0 >= n) return;
+	u32 c0 = 0, c1 = 0, v = 0;
+	for (int j = 0; j < 32; ++j) {
+		const int64_t p = p0 + j;
+		const u32 c = p < n ? d_nt4[a[p]] : 4u;
+		if (c < 4) { v |= 1u << j; if (j < 16) c0 |= c << (2 * j); else c1 |= c << (2 * (j - 16)); }
+	}
+	codes[2 * w] = c0; codes[2 * w + 1] = c1; valid[w] = v;
+}
+void yk_launch_pack(const uint8_t *a, int64_t n, u32 *codes, u32 *valid, hipStream_t st)
+{
+	if (n > 0) hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, st, a, n, codes, valid);
+}
+
 /* partitioning extraction: returns through bstart[1 << nb_bits] (device) the record count */
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st)
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st, const u32 *valid)
 {
 	if (n <= pos0) return;
 	const int n_blk = (int)(((u64)(n - pos0) + (u64)XP_T * XT_TILE - 1) / ((u64)XP_T * XT_TILE));
@@ -3927,13 +3948,13 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 			hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_xpart_wcs<true>, 1024, wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024));
 			fprintf(stderr, "[yak_amd] k_xpart_wcs: %zu B of dynamic LDS, %d workgroups per CU\n", wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024), nb);
 		}
-		hipLaunchKernelGGL(k_xpart<3>, dim3(n_blk), dim3(XT_THREADS), 3 * lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+		hipLaunchKernelGGL(k_xpart<3>, dim3(n_blk), dim3(XT_THREADS), 3 * lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out, valid);
 		launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st, true);
 		hipLaunchKernelGGL(k_xpart_wcs<true>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
-		                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, 0);
+		                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, 0, valid);
 		return;
 	}
-	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	hipLaunchKernelGGL(k_xpart<0>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out, valid);
 	launch_part_scan(rows, n_blk, nb_bits, partial, bstart, st);
 	static const int wc = getenv("YAKAMD_XP_WC") ? atoi(getenv("YAKAMD_XP_WC")) : 3;   /* bit 0: {hash, position} scatter, bit 1: hash-only scatter */
 	static bool attr = false;
@@ -3948,15 +3969,15 @@ void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_su
 			static bool attr4 = false;
 			if (!attr4) { hipFuncSetAttribute((const void*)k_xpart_wcs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr4 = true; }
 			hipLaunchKernelGGL(k_xpart_wcs<false>, dim3(n_blk), dim3(1024), (wc_lds_bytes<8, XW_CAP_S, false>(1 << nb_bits, 1024)), st,
-			                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, hash_only == 3);
+			                   bases, pos0, n, k, pre, plo, phi, nb_bits, (const u32*)rows, (u64*)out, hash_only == 3, valid);
 		}
 		else if (hash_only) hipLaunchKernelGGL(k_xpart_wc<2>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<8, XW_CAP_H, false>(1 << nb_bits, XW_NT)), st,
-		                                  bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
+		                                  bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out, valid);
 		else hipLaunchKernelGGL(k_xpart_wc<1>, dim3(n_blk), dim3(XW_NT), (wc_lds_bytes<4, XW_CAP_T, true>(1 << nb_bits, XW_NT)), st,
-		                        bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out);
+		                        bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, (const u32*)rows, (const u64*)bstart, (void*)out, valid);
 	}
-	else if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
-	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out);
+	else if (hash_only) hipLaunchKernelGGL(k_xpart<2>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out, valid);
+	else hipLaunchKernelGGL(k_xpart<1>, dim3(n_blk), dim3(XT_THREADS), lds, st, bases, pos0, n, t_sub, k, pre, plo, phi, nb_bits, rows, out, valid);
 }
 
 int yk_part_groups(void) { return PS_G; }
