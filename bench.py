@@ -532,7 +532,8 @@ def main():
     for k_ in kern:
         keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
         cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift == 37 else []
-        k_["traffic_bytes"] = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
+        steps_pmc = max(1, pmc.get("k_lc2", {}).get("launches", 1))     # k_lc2 runs once per step: the steps of the profiled command
+        k_["traffic_bytes"] = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
     # the pass and the step as a whole against the same roof: SURVEY 8(d)'s algorithmic bytes of every instance
     # the pass consumed / its wall-clock time (pass 1 with and without the exact-layout tail: sort + replay)
     bloom_on = a.bf_shift > PRE and s2 is not None
@@ -542,7 +543,8 @@ def main():
     ms_p1 = w.get("pass1", 0.0)
     ms_p1_core = s1["ms_extract"] + s1["ms_insert"]
     frac = lambda by, ms: by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
-    dom = max(kern, key=lambda x: x["ms"])
+    # the dominant KERNEL: the single kernel with the largest time (the extraction and replay rows are groups of several kernels)
+    dom = max([k_ for k_ in kern if not k_["kernel"].startswith(("k_xpart", "k_r2_"))], key=lambda x: x["ms"])
     name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
     bpi, st = dom["bytes"] / max(1, n1), s1
     out = {
@@ -565,6 +567,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS,
                      "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
+                     "frac_of_peak_by_traffic": (dom["traffic_bytes"] / launches / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom.get("traffic_bytes") else None,
                      "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)",
                      "avg_launch_ms": avg_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": dom["bytes"] / launches,

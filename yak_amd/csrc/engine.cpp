@@ -132,7 +132,16 @@ static void *pool_alloc(size_t bytes)
 static void pool_free(void *p)
 {
 	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
-	static const size_t cap = (size_t)env_i64("YAKAMD_POOL_MAX_GB", 96) << 30;   /* idle bytes kept per device */
+	/* idle bytes kept per device: three quarters of the HBM unless YAKAMD_POOL_MAX_GB says otherwise.  A step of the larger configurations
+	 * (1 Gb assembly, 30 M reads) turns over > 100 GB; a cap below the turnover makes every step pay the driver for its buffers again
+	 * (measured with 96 GB: 2.3 s instead of 0.27 s per cfg4 pass).  An allocation that fails drops the whole cache and retries */
+	static const size_t cap = []() -> size_t {
+		const int64_t e = env_i64("YAKAMD_POOL_MAX_GB", -1);
+		if (e >= 0) return (size_t)e << 30;
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)96 << 30; }
+		return tot / 4 * 3;
+	}();
 	/* the block's owner is the pool that handed it out, whatever device is current now */
 	DevPool *Pp = &pool_here();
 	{
