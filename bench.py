@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
+    ap.add_argument("--exchange16", action="store_true", help="N > 1: exchange 16-byte {hash, position} records instead of 8-byte tagged ones")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not queue the pass-2 exchange behind pass 1's computation")
     ap.add_argument("--job-md5", action="store_true", help="also report the md5 of the whole job's .yak bytes (sub-tables gathered from all ranks)")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
@@ -210,9 +211,11 @@ def main():
     n_bytes = d_reads.numel()
     batch_span = [(b * B, min(B, n_bytes - b * B)) for b in range(n_batches)]
 
-    # exchange buffers (sharded path only): 16-byte records {hash, position} grouped by prefix
+    # exchange buffers (sharded path only): records grouped by prefix -- 8-byte tagged records where k / pre allow them
+    # (yakamd_partition_tagged_dev: the stream order of a prefix's records is implied, no position travels), else 16-byte {hash, position}
+    tagged = sharded and L.yakamd_tagged_ok(K, PRE) != 0 and not a.exchange16
     if sharded:
-        s_rec = torch.empty((min(B, n_bytes), 2), dtype=torch.int64, device=dev)
+        s_rec = torch.empty(min(B, n_bytes) if tagged else (min(B, n_bytes), 2), dtype=torch.int64, device=dev)
         s_hash = torch.empty(min(B, n_bytes), dtype=torch.int64, device=dev)
         h_bstart = (C.c_uint64 * (P + 1))()
 
@@ -223,7 +226,7 @@ def main():
         from yak_amd import shard
         off, nb = batch_span[b]
         if create_new:
-            n = L.yakamd_partition_dev(K, PRE, d_reads.data_ptr() + off, nb, s_rec.data_ptr(), h_bstart)
+            n = (L.yakamd_partition_tagged_dev if tagged else L.yakamd_partition_dev)(K, PRE, d_reads.data_ptr() + off, nb, s_rec.data_ptr(), h_bstart)
             send = s_rec[:n]
         else:                                               # counting existing keys only needs the hashes: 8-byte records
             n = L.yakamd_partition_hashes_dev(K, PRE, d_reads.data_ptr() + off, nb, s_hash.data_ptr(), h_bstart)
@@ -265,7 +268,8 @@ def main():
                 if rec.shape[0]:
                     ob = (C.c_uint64 * (P + 1))(*offs)
                     if create_new:
-                        if L.yakamd_feed_partitioned_lent_dev(t.h, rec.data_ptr(), rec.shape[0], ob, (b * world + src) * B, B) != 0:
+                        if (L.yakamd_feed_partitioned_tagged_dev(t.h, rec.data_ptr(), rec.shape[0], ob, (b * world + src) * B, B, 1) if tagged else
+                                L.yakamd_feed_partitioned_lent_dev(t.h, rec.data_ptr(), rec.shape[0], ob, (b * world + src) * B, B)) != 0:
                             raise RuntimeError("feed_partitioned: " + yak_amd._err())
                     elif L.yakamd_count_partitioned_dev(t.h, rec.data_ptr(), rec.shape[0], ob) != 0:
                         raise RuntimeError("count_partitioned: " + yak_amd._err())

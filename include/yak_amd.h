@@ -78,6 +78,15 @@ int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64_t n, const
  * and the engine works on it in place instead of taking a copy */
 int yakamd_feed_partitioned_lent_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart,
                                      uint64_t t0, uint64_t t_span);
+/* The same exchange at 8 bytes per k-mer instance: TAGGED records (hash >> pre) << 12 | toggle << 10 | position in the
+ * 1024-position round -- the stream order of a prefix's records is implied by the order the (round-stable) partition
+ * wrote them in, so no position travels.  yakamd_tagged_ok(k, pre) != 0 iff the format applies (k < 32,
+ * 2k - pre <= 52, pre <= 10); the slice of a source must arrive whole and unpermuted.  lent != 0 as above */
+int yakamd_tagged_ok(int k, int pre);
+int yakamd_pass_fast(yak_ch_t *h);        /* 1 while h's open pass can take tagged records (it runs on the exclusive-ownership path) */
+int64_t yakamd_partition_tagged_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec8_out, uint64_t *h_bstart);
+int yakamd_feed_partitioned_tagged_dev(yak_ch_t *h, const void *d_rec8, int64_t n, const uint64_t *h_bstart,
+                                       uint64_t t0, uint64_t t_span, int lent);
 
 /* The same for passes that only count existing keys (create_new = 0; main.c:57): 8-byte records,
  * just the yak_hash64 values, grouped by prefix the same way. */

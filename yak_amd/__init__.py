@@ -30,6 +30,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
+    "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
     "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
 ]
 
@@ -123,6 +124,11 @@ def lib():
     L.yakamd_feed_partitioned_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, P(C.c_uint64), C.c_uint64, C.c_uint64]
     L.yakamd_feed_partitioned_lent_dev.restype = C.c_int
     L.yakamd_feed_partitioned_lent_dev.argtypes = L.yakamd_feed_partitioned_dev.argtypes
+    L.yakamd_tagged_ok.restype = C.c_int; L.yakamd_tagged_ok.argtypes = [C.c_int, C.c_int]
+    L.yakamd_partition_tagged_dev.restype = C.c_int64
+    L.yakamd_partition_tagged_dev.argtypes = L.yakamd_partition_dev.argtypes
+    L.yakamd_feed_partitioned_tagged_dev.restype = C.c_int
+    L.yakamd_feed_partitioned_tagged_dev.argtypes = list(L.yakamd_feed_partitioned_dev.argtypes) + [C.c_int]
     L.yakamd_partition_hashes_dev.restype = C.c_int64
     L.yakamd_partition_hashes_dev.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_uint64)]
     L.yakamd_count_partitioned_dev.restype = C.c_int

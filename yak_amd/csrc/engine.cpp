@@ -890,12 +890,21 @@ extern "C" int64_t yakamd_partition_dev(int k, int pre, const void *d_bases, int
 	return partition_dev(k, pre, d_bases, n_bytes, d_rec_out, h_bstart, 0);
 }
 
+/* the same partition as 8-byte tagged records (yk_device.h YK_R8_*: half the exchange payload of a sharded pass); for
+ * yakamd_feed_partitioned_tagged_dev on the owner.  yakamd_tagged_ok says whether k / pre allow the format */
+extern "C" int yakamd_tagged_ok(int k, int pre) { return k >= 1 && k < 32 && 2 * k - pre <= 64 - YK_R8_TAG_BITS && pre >= 3 && pre <= 10 && env_i64("YAKAMD_REC8", 1) != 0; }
+extern "C" int64_t yakamd_partition_tagged_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec8_out, uint64_t *h_bstart)
+{
+	if (!yakamd_tagged_ok(k, pre)) { fail("partition: tagged records need k < 32, 2k - pre <= 52, pre <= 10"); return -1; }
+	return partition_dev(k, pre, d_bases, n_bytes, d_rec8_out, h_bstart, 2);
+}
+
 extern "C" int64_t yakamd_partition_hashes_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_hash_out, uint64_t *h_bstart)
 {
 	return partition_dev(k, pre, d_bases, n_bytes, d_hash_out, h_bstart, 1);
 }
 
-static int feed_partitioned(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span, bool borrow)
+static int feed_partitioned(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span, bool borrow, int fmt = 0)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass) return fail("feed outside a pass");
@@ -905,9 +914,10 @@ static int feed_partitioned(yak_ch_t *h, const void *d_rec, int64_t n, const uin
 	const size_t NB = (size_t)1 << c->nb_bits;
 	if (c->fast) {
 		Rec *out = 0;
-		if (fast_admit(c, t0, t_span, (u64)n, &out, borrow ? (Rec*)d_rec : 0)) return -1;
+		if (fmt && !(yakamd_tagged_ok(c->k, c->pre) && !c->or_mode)) return fail("tagged records do not fit this table (k, pre)");
+		if (fast_admit(c, t0, t_span, (u64)n, &out, borrow ? (Rec*)d_rec : 0, fmt)) return -1;
 		if (c->fast) {                                       /* admitted: already grouped by prefix; keep a private copy unless lent */
-			if (!borrow) HIPCK(hipMemcpyAsync(out, d_rec, (size_t)n * sizeof(Rec), hipMemcpyDeviceToDevice, c->st));
+			if (!borrow) HIPCK(hipMemcpyAsync(out, d_rec, (size_t)n * (fmt ? 8 : sizeof(Rec)), hipMemcpyDeviceToDevice, c->st));
 			yakamd_ctx::Kept &k = c->kept.back();
 			k.bstart.assign(h_bstart, h_bstart + NB + 1);
 			k.n = (u64)n;
@@ -916,6 +926,7 @@ static int feed_partitioned(yak_ch_t *h, const void *d_rec, int64_t n, const uin
 			return 0;
 		}
 	}
+	if (fmt) return fail("tagged records need the exclusive-ownership path (the pass left it: input beyond the device budget, or YAKAMD_FAST=0)");
 	Rec *keep = c->d_rec;                                    /* general path / pass 2: consume in place */
 	c->d_rec = (Rec*)d_rec;
 	const int r = consume_records(c, n, t0, t0, t0 + t_span);
@@ -931,6 +942,14 @@ extern "C" int yakamd_feed_partitioned_dev(yak_ch_t *h, const void *d_rec, int64
 extern "C" int yakamd_feed_partitioned_lent_dev(yak_ch_t *h, const void *d_rec, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span)
 {
 	return feed_partitioned(h, d_rec, n, h_bstart, t0, t_span, true);
+}
+
+/* 1 while the open pass of h runs on the exclusive-ownership path (the only one that takes tagged records) */
+extern "C" int yakamd_pass_fast(yak_ch_t *h) { yakamd_ctx *c = ctx_of(h); return c && c->in_pass && c->fast && !c->or_mode; }
+
+extern "C" int yakamd_feed_partitioned_tagged_dev(yak_ch_t *h, const void *d_rec8, int64_t n, const uint64_t *h_bstart, uint64_t t0, uint64_t t_span, int lent)
+{
+	return feed_partitioned(h, d_rec8, n, h_bstart, t0, t_span, lent != 0, 1);
 }
 
 extern "C" int yakamd_count_partitioned_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n, const uint64_t *h_bstart)

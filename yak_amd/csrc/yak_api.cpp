@@ -904,7 +904,8 @@ static void multi_close(MultiJob *J)
 /* one round: chunk r (fill[r] bytes, stream offset t0[r]) sits on GPU r.  Partition, exchange, feed. */
 static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
 {
-	const int N = J->N, P = J->P, W = create_new ? 2 : 1;      /* words per record: {hash, position} or the hash alone */
+	const bool tagged = create_new && yakamd_tagged_ok(k, pre) && e->sub[0] && yakamd_pass_fast(e->sub[0]) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange */
+	const int N = J->N, P = J->P, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
 	std::vector<std::vector<uint64_t> > bst(N, std::vector<uint64_t>(P + 1, 0));
 	std::vector<int64_t> n_rec(N, 0);
 	std::vector<char> ok(N, 1);
@@ -913,7 +914,8 @@ static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_n
 		for (int r = 0; r < N; ++r) th.emplace_back([&, r]() {
 			if (fill[r] <= 0) return;
 			hipSetDevice(J->dev[r]);
-			n_rec[r] = create_new ? yakamd_partition_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
+			n_rec[r] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
+			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
 			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data());
 			if (n_rec[r] < 0) ok[r] = 0;
 		});
@@ -956,7 +958,8 @@ static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_n
 				if (cnt == 0) continue;
 				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[r][q] - bst[r][lo]; }
 				const uint64_t *rec = J->d_recv[d] + roff[d][r] * W;
-				const int rc = create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r])
+				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r], 0)
+				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r])
 				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
 				if (rc != 0) ok[d] = 0;
 			}
