@@ -2046,6 +2046,8 @@ void k_replay(const ReplayTask *tasks, const u64 *old_keys, const u32 *old_used,
 #define R2_LONG 8u                             /* runs longer than this are placed by a whole wave */
 #define R2_LMAX 512u
 #define R2_RMAX (2 * R2_LMAX + 2 + 256)
+#define R2_WS 512u                              /* k_r2_dsmall's LDS windows: old slots [0, R2_WS), new slots [0, R2_WD) */
+#define R2_WD (2 * R2_WS + 64)
 #define R2_MOVED (YK_EMPTY - 1)                 /* old slot whose key a chain of the prefix has re-inserted: still part of its run, no longer a key */
 
 __device__ __forceinline__ u32 r2_home(u64 key, u32 bits) { return yk_h2b((u32)(key >> 10), bits); }
@@ -2230,11 +2232,57 @@ void k_r2_dinit(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG
 	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < N; i += (u64)gridDim.x * 256) { D[i] = YK_EMPTY; if (i < n) TG[i] = R2_NONE; if (i < (N + 31) / 32) OC[i] = 0; }
 }
 
+/* the doubling rounds [F, G), G <= 2F, of ONE sub-table by one workgroup, until F reaches small_f.  COH: S / D / TG are the global
+ * arrays (cross-wave data through L2: fences and agent-scope loads); else they are LDS windows holding slots [0, ws_lim) of the
+ * old table and [0, 2 ws_lim + 64) of the new one -- every access of a round stays below 2G + 2 -- and the function returns early
+ * (*s_dyn = 2) if a self-feeding run would leave the window */
+template <bool COH>
+__device__ u32 r2_small_rounds(u64 *S, u64 *D, u32 *TG, u32 F, const u32 n, const u32 nb, const u32 small_f, const u32 ws_lim,
+                               R2Wave *waves, const u32 n_waves, u32 *s_long, u32 *s_F, u32 *s_dyn, u32 *s_nlong, u32 *fail)
+{
+	const u32 tid = threadIdx.x;
+	while (F < n && F < small_f) {
+		if (tid == 0) {
+			u32 g = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
+			*s_dyn = 0; *s_nlong = 0;
+			if (g == 0) {
+				/* one run covers [F, 2F]: the keys landing on its slots come from the run itself; it is placed alone, by the
+				 * literal rule in sigma order (r2_wave_run<.., true>), up to its own end */
+				*s_dyn = 1;
+				g = 2 * F;
+				while (g < n && S[g] != YK_EMPTY) { ++g; if (!COH && g + 1 >= ws_lim) { *s_dyn = 2; break; } }
+				g = g < n ? g + 1 : n;
+			}
+			*s_F = g;
+		}
+		__syncthreads();
+		const u32 G = *s_F;
+		if (*s_dyn == 2) break;                                              /* (uniform) */
+		if (*s_dyn) { if (tid < 64) r2_wave_run<COH, true>(waves[0], S, D, TG, F, n, nb, fail); }
+		else {
+			for (u32 s = F + tid; s < G; s += blockDim.x)
+				if (S[s] != YK_EMPTY && (s == F || S[s - 1] == YK_EMPTY) && !r2_run<COH>(S, D, TG, s, n, nb)) {
+					const u32 at = atomicAdd(s_nlong, 1u);
+					if (at < 256) s_long[at] = s; else *fail = 8;
+				}
+			__syncthreads();
+			const u32 nl = *s_nlong < 256 ? *s_nlong : 256;
+			if (tid < 64 * n_waves) for (u32 j = tid >> 6; j < nl; j += n_waves) r2_wave_run<COH, false>(waves[tid >> 6], S, D, TG, s_long[j], n, nb, fail);
+		}
+		if (COH) __threadfence();
+		__syncthreads();
+		F = G;
+	}
+	return F;
+}
+
 /* the prefix by the literal rule, then the rounds below R2_SMALL_F; one workgroup per sub-table */
 __global__ __launch_bounds__(256)
 void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, u32 small_f)
 {
-	__shared__ R2Wave s_wave[4];
+	__shared__ R2Wave s_wave[1];
+	__shared__ u64 s_S[R2_WS], s_D[R2_WD];                              /* 31 KB in all: the 1024 workgroups of a launch are resident at once */
+	__shared__ u32 s_T[R2_WD];
 	__shared__ u32 s_long[256];
 	__shared__ u32 s_F, s_dyn, s_nlong;
 	const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -2276,37 +2324,23 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 	__threadfence();
 	__syncthreads();
 	u32 F = s_F;
-	while (F < n && F < small_f) {
-		if (tid == 0) {
-			u32 g = r2_boundary(S, F, 2 * F < n ? 2 * F : n, n);
-			s_dyn = 0; s_nlong = 0;
-			if (g == 0) {
-				/* one run covers [F, 2F]: the keys landing on its slots come from the run itself; it is placed alone, by the
-				 * literal rule in sigma order (r2_wave_run<.., true>), up to its own end */
-				s_dyn = 1;
-				g = 2 * F;
-				while (g < n && S[g] != YK_EMPTY) ++g;
-				g = g < n ? g + 1 : n;
-			}
-			s_F = g;
-		}
+	if (small_f <= R2_WS / 2 && F < small_f && F < n) {
+		/* the rounds below small_f touch old slots < 2 small_f and new slots < 4 small_f + 2 only: they run on LDS copies (a dependent
+		 * access costs ~100 cycles there instead of a trip to L2), the windows go back to the arrays afterwards */
+		const u32 ns = n < R2_WS ? n : R2_WS, nd = 2 * n < R2_WD ? 2 * n : R2_WD, nt = n < R2_WD ? n : R2_WD;
+		for (u32 i = tid; i < ns; i += 256) s_S[i] = __hip_atomic_load(&S[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (u32 i = tid; i < nd; i += 256) s_D[i] = __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (u32 i = tid; i < nt; i += 256) s_T[i] = __hip_atomic_load(&TG[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__syncthreads();
-		const u32 G = s_F;
-		if (s_dyn) { if (tid < 64) r2_wave_run<true, true>(s_wave[0], S, D, TG, F, n, nb, fail); }
-		else {
-			for (u32 s = F + tid; s < G; s += 256)
-				if (S[s] != YK_EMPTY && (s == F || S[s - 1] == YK_EMPTY) && !r2_run<true>(S, D, TG, s, n, nb)) {
-					const u32 at = atomicAdd(&s_nlong, 1u);
-					if (at < 256) s_long[at] = s; else *fail = 8;
-				}
-			__syncthreads();
-			const u32 nl = s_nlong < 256 ? s_nlong : 256;
-			for (u32 j = tid >> 6; j < nl; j += 4) r2_wave_run<true, false>(s_wave[tid >> 6], S, D, TG, s_long[j], n, nb, fail);
-		}
+		F = r2_small_rounds<false>(s_S, s_D, s_T, F, n, nb, small_f, R2_WS, s_wave, 1, s_long, &s_F, &s_dyn, &s_nlong, fail);
+		__syncthreads();
+		for (u32 i = tid; i < ns; i += 256) S[i] = s_S[i];
+		for (u32 i = tid; i < nd; i += 256) D[i] = s_D[i];
+		for (u32 i = tid; i < nt; i += 256) TG[i] = s_T[i];
 		__threadfence();
 		__syncthreads();
-		F = G;
 	}
+	F = r2_small_rounds<true>(S, D, TG, F, n, nb, small_f, 0, s_wave, 1, s_long, &s_F, &s_dyn, &s_nlong, fail);   /* whatever is left (a run that left the window; small_f beyond the window) */
 	if (tid == 0) { Fcur[p] = F; Gcur[p] = F < n ? r2_boundary(S, F, 2 * F < n ? 2 * F : n, n) : n; }   /* the first round of k_r2_dround */
 }
 
