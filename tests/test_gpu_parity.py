@@ -130,6 +130,15 @@ def test_cli_drop_in(ya, oracle, tmp_path):
         subprocess.run([os.path.join(ROOT, "yak_amd", "yak-amd"), "count"] + args + ["-o", a, inp], check=True, stderr=subprocess.DEVNULL)
         subprocess.run([os.path.join(ROOT, "oracle", "yko"), "count"] + args + ["-o", b, inp], check=True, stderr=subprocess.DEVNULL)
         assert open(a, "rb").read() == open(b, "rb").read()
+    # block gzip (bgzip / htslib): members are inflated by the parser's threads, the stream -- and the .yak -- stay the same
+    from test_host_reader import write_bgzf
+    big = str(tmp_path / "big.fq")
+    subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", "12000", "-g", "60000", "-s", "9", "-o", big])
+    write_bgzf(big + ".gz", open(big, "rb").read(), sizes=[65280, 40000, 1])
+    a, b = str(tmp_path / "a2.yak"), str(tmp_path / "b2.yak")
+    r = subprocess.run([os.path.join(ROOT, "yak_amd", "yak-amd"), "count", "-k31", "-b24", "-t4", "-o", a, big + ".gz"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([os.path.join(ROOT, "oracle", "yko"), "count", "-k31", "-b24", "-o", b, big], check=True, stderr=subprocess.DEVNULL)
+    assert open(a, "rb").read() == open(b, "rb").read()
 
 
 @pytest.mark.parametrize("bf", [0, 23])

@@ -86,3 +86,57 @@ def test_awkward_shapes(oracle, tmp_path):
         for k in (0, 31):
             same(fn, oracle, k)
     assert len(body) > 3 << 20
+
+
+def write_bgzf(fn, data, block=65280, level=6, eof_block=True, sizes=None):
+    """block gzip as bgzip / htslib write it: members of <= 64 KiB with the 'BC' extra field holding the member size - 1"""
+    import struct
+    import zlib
+    out, off, i = [], 0, 0
+    while off < len(data) or (off == 0 and not out):
+        n = sizes[i % len(sizes)] if sizes else block
+        chunk = data[off:off + n]
+        off += len(chunk); i += 1
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        if not chunk:
+            break
+    if eof_block:
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    open(fn, "wb").write(b"".join(out))
+
+
+@pytest.mark.parametrize("no_libdeflate", [False, True], ids=["libdeflate_if_present", "zlib_inflate"])
+def test_block_gzip_is_parsed_in_parallel(no_libdeflate, oracle, tmp_path, monkeypatch, capfd):
+    """a BGZF file goes through the parallel parser (its threads inflate the blocks their segment touches); the image is the
+    plain file's, whatever the block sizes, with and without the trailing empty block, and plain gzip still streams"""
+    import yak_amd
+    if no_libdeflate:
+        monkeypatch.setenv("YAKAMD_NO_LIBDEFLATE", "1")
+    fq = str(tmp_path / "r.fq")
+    subprocess.check_call([SYN, "-n", "20000", "-l", "150", "-g", "100000", "-s", "5", "-o", fq])
+    data = open(fq, "rb").read()
+    want = oracle.read_image(fq, 31)
+    for name, kw in (("a.fq.gz", {}), ("b.fq.gz", dict(sizes=[1, 65536, 700, 33333, 2], eof_block=False)), ("c.fq.gz", dict(block=4096, level=1))):
+        gz = str(tmp_path / name)
+        write_bgzf(gz, data, **kw)
+        assert gzip.open(gz, "rb").read() == data               # what we wrote is valid gzip
+        assert same(gz, oracle, 31) == want
+    # the parallel path was really taken (and is really off for plain gzip)
+    monkeypatch.setenv("YAKAMD_PARSE_THREADS", "4"); monkeypatch.setenv("YAKAMD_VERBOSE", "1")
+    capfd.readouterr()
+    assert yak_amd.host_image(str(tmp_path / "a.fq.gz"), 31, fast=True) == want
+    assert "BGZF blocks inflated by the parser threads" in capfd.readouterr().err
+    plain = str(tmp_path / "p.fq.gz")
+    with gzip.open(plain, "wb") as f:
+        f.write(data)
+    assert yak_amd.host_image(plain, 31, fast=True) == want
+    assert "BGZF" not in capfd.readouterr().err
+    # a corrupt block ends the stream there instead of inventing data: flip a byte in the middle of the payload of a.fq.gz
+    raw = bytearray(open(str(tmp_path / "a.fq.gz"), "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.fq.gz"); open(bad, "wb").write(bytes(raw))
+    got = yak_amd.host_image(bad, 31, fast=True)
+    assert want.startswith(got[:got.rfind(b"\n", 0, len(got) - 1) + 1][:1000]) and len(got) < len(want)

@@ -527,11 +527,101 @@ yak_ch_t *yak_ch_restore(const char *fn) { return yak_ch_restore_core(0, fn, YAK
  * quality lines covering at least the sequence length; a truncated quality ends the input.
  * ------------------------------------------------------------------------------------------ */
 extern "C++" {
+/* What the parallel parser reads: a plain file, or the uncompressed stream of a BGZF file (block gzip: every member carries its
+ * compressed size in a 'BC' extra field and holds <= 64 KiB of data, so members can be found without inflating and inflated
+ * independently).  A read at any offset inflates just the blocks it touches, on the calling thread -- the parser's threads each
+ * read their own segment, so inflation is spread over them by itself.  libdeflate is used when the image has it, else zlib. */
+struct ByteSource {
+	struct Blk { int64_t foff, uoff; uint32_t csize, usize; };   /* offset of the deflate payload, offset in the uncompressed stream, bytes of both */
+	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
+	ByteSource() : fd(-1), size(0), bgzf(false) {}
+	typedef void *(*ld_alloc_t)(void); typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*);
+	static void ld_api(ld_alloc_t *al, ld_dec_t *de) {
+		static ld_alloc_t a = 0; static ld_dec_t d = 0; static bool tried = false;
+		if (!tried) {                                              /* benign race: every thread resolves the same pointers */
+			void *l = getenv("YAKAMD_NO_LIBDEFLATE") ? 0 : dlopen("libdeflate.so.0", RTLD_NOW);
+			if (l) { a = (ld_alloc_t)dlsym(l, "libdeflate_alloc_decompressor"); d = (ld_dec_t)dlsym(l, "libdeflate_deflate_decompress"); }
+			if (!a || !d) { a = 0; d = 0; }
+			tried = true;
+		}
+		*al = a; *de = d;
+	}
+	/* index the members of an open file; false if it is not BGZF from the first byte to the last */
+	bool index_bgzf(int f) {
+		struct stat sb;
+		if (fstat(f, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+		int64_t off = 0, uoff = 0;
+		unsigned char h[18], t[4];
+		blk.clear();
+		while (off < sb.st_size) {
+			if (::pread(f, h, 18, off) != 18) return false;
+			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+			const uint32_t xlen = h[10] | h[11] << 8;
+			/* the 'BC' subfield is the first one in every BGZF writer; anything else is not indexed */
+			if (xlen < 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0 || (h[3] & ~4)) return false;
+			const uint32_t bsize = (h[16] | h[17] << 8) + 1u;
+			if (bsize < 12 + xlen + 8 || off + bsize > sb.st_size) return false;
+			if (::pread(f, t, 4, off + bsize - 4) != 4) return false;
+			const uint32_t isize = t[0] | t[1] << 8 | t[2] << 16 | (uint32_t)t[3] << 24;
+			if (isize > 65536) return false;
+			Blk b; b.foff = off + 12 + xlen; b.csize = bsize - 12 - xlen - 8; b.uoff = uoff; b.usize = isize;
+			if (isize) blk.push_back(b);
+			off += bsize; uoff += isize;
+		}
+		fd = f; size = uoff; bgzf = true;
+		return true;
+	}
+	bool inflate_block(const Blk &b, unsigned char *out, std::vector<unsigned char> &cbuf) const {
+		cbuf.resize(b.csize + 8);
+		size_t got = 0;
+		while (got < b.csize + 8) { const ssize_t r = ::pread(fd, cbuf.data() + got, b.csize + 8 - got, b.foff + got); if (r <= 0) return false; got += r; }
+		ld_alloc_t al; ld_dec_t de; ld_api(&al, &de);
+		bool ok = false;
+		if (al) {
+			static thread_local void *dec = 0;
+			if (!dec) dec = al();
+			size_t n = 0;
+			ok = dec && de(dec, cbuf.data(), b.csize, out, b.usize, &n) == 0 && n == b.usize;
+		} else {
+			static thread_local z_stream zs; static thread_local bool init = false;
+			if (!init) { memset(&zs, 0, sizeof(zs)); if (inflateInit2(&zs, -15) != Z_OK) return false; init = true; } else inflateReset(&zs);
+			zs.next_in = cbuf.data(); zs.avail_in = b.csize; zs.next_out = out; zs.avail_out = b.usize;
+			ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+		}
+		if (!ok) return false;
+		const unsigned char *t = cbuf.data() + b.csize;            /* CRC32 of the uncompressed data, as gzread would check it */
+		const uint32_t crc = t[0] | t[1] << 8 | t[2] << 16 | (uint32_t)t[3] << 24;
+		return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, b.usize) == crc;
+	}
+	/* pread(2) semantics on the uncompressed stream; -1 on a corrupt block */
+	ssize_t pread_at(void *dst, size_t n, int64_t off) const {
+		if (!bgzf) return ::pread(fd, dst, n, off);
+		if (off >= size || n == 0) return 0;
+		static thread_local std::vector<unsigned char> ub, cb;
+		static thread_local const ByteSource *who = 0; static thread_local size_t which = (size_t)-1;
+		size_t lo = 0, hi = blk.size();                            /* the block that holds `off` */
+		while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (blk[mid].uoff <= off) lo = mid; else hi = mid; }
+		size_t done = 0;
+		for (size_t bi = lo; bi < blk.size() && done < n; ++bi) {
+			const Blk &b = blk[bi];
+			if (who != this || which != bi) {
+				ub.resize(65536);
+				if (!inflate_block(b, ub.data(), cb)) { who = 0; return -1; }
+				who = this; which = bi;
+			}
+			const size_t skip = (size_t)(off + (int64_t)done - b.uoff), take = std::min<size_t>(b.usize - skip, n - done);
+			memcpy((char*)dst + done, ub.data() + skip, take);
+			done += take;
+		}
+		return (ssize_t)done;
+	}
+};
+
 struct FxReader {
 	gzFile fp; int fd; unsigned char *buf; int beg, end, eof, last;
 	std::vector<char> seq, name; size_t qlen; int qlast;
 	enum { BUF = 1 << 20, NOT_FAST = -3 };
-	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0), mem(false), pfd(-1), poff(0), pos0(0) {}
+	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0), mem(false), psrc(0), poff(0), pos0(0) {}
 	/* open `fn` (NULL or "-": stdin); a plain (not gzip) regular file is then read with read(2), skipping zlib's copy */
 	bool open_file(const char *fn) {
 		const bool is_stdin = fn == 0 || strcmp(fn, "-") == 0;
@@ -543,9 +633,9 @@ struct FxReader {
 		return true;
 	}
 	void close_file() { if (fd >= 0) ::close(fd); if (fp) gzclose(fp); if (!mem) free(buf); fp = 0; fd = -1; buf = 0; }
-	/* positional mode for the parallel parser: read a plain file from offset `from` with pread(2) on a shared descriptor */
-	bool mem; int pfd; int64_t poff, pos0;
-	void open_at(int shared_fd, int64_t from) { pfd = shared_fd; poff = pos0 = from; buf = (unsigned char*)malloc(BUF); beg = end = 0; eof = 0; last = 0; }
+	/* positional mode for the parallel parser: read a shared source (plain file or BGZF stream) from offset `from` */
+	bool mem; const ByteSource *psrc; int64_t poff, pos0;
+	void open_at(const ByteSource *src, int64_t from) { psrc = src; poff = pos0 = from; buf = (unsigned char*)malloc(BUF); beg = end = 0; eof = 0; last = 0; }
 	void close_at() { free(buf); buf = 0; }
 	/* consume up to the next record marker ('>' or '@', kseq.h:196-199) so that `last` holds it; false at EOF */
 	bool seek_marker() {
@@ -561,9 +651,9 @@ struct FxReader {
 		if (beg < end) return true;
 		if (eof) return false;
 		beg = 0;
-		if (pfd >= 0) {
+		if (psrc) {
 			pos0 = poff; end = 0;
-			while (end < BUF) { const ssize_t r = ::pread(pfd, buf + end, BUF - end, poff); if (r <= 0) break; end += (int)r; poff += r; }
+			while (end < BUF) { const ssize_t r = psrc->pread_at(buf + end, BUF - end, poff); if (r <= 0) break; end += (int)r; poff += r; }
 		} else if (fd >= 0) {                                /* read(2) may return short counts before EOF */
 			end = 0;
 			while (end < BUF) { const ssize_t r = ::read(fd, buf + end, BUF - end); if (r <= 0) break; end += (int)r; }
@@ -701,11 +791,11 @@ typedef std::vector<char, PinAlloc<char> > PinVec;
 
 struct ParSeg { int64_t start, end, stop; PinVec img; int64_t n_seq, sum_len; bool hard_end; };
 
-static int64_t guess_record_start(int fd, int64_t from, int64_t limit)
+static int64_t guess_record_start(const ByteSource *src, int64_t from, int64_t limit)
 {
 	std::vector<unsigned char> tmp((size_t)(limit - from));
 	int64_t got = 0;
-	while (got < (int64_t)tmp.size()) { const ssize_t r = ::pread(fd, tmp.data() + got, tmp.size() - got, from + got); if (r <= 0) break; got += r; }
+	while (got < (int64_t)tmp.size()) { const ssize_t r = src->pread_at(tmp.data() + got, tmp.size() - got, from + got); if (r <= 0) break; got += r; }
 	const unsigned char *base = tmp.data(), *p = base, *e = base + got;
 	p = (const unsigned char*)memchr(p, '\n', e - p);
 	if (!p) return -1;
@@ -722,10 +812,10 @@ static int64_t guess_record_start(int fd, int64_t from, int64_t limit)
 	return -1;
 }
 
-static void parse_segment(int fd, int64_t file_end, ParSeg *sg, int min_len)
+static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, int min_len)
 {
 	FxReader r;
-	r.open_at(fd, sg->start);
+	r.open_at(src, sg->start);
 	sg->n_seq = sg->sum_len = 0; sg->hard_end = false;
 	sg->img.clear();
 	if (sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
@@ -744,7 +834,7 @@ static void parse_segment(int fd, int64_t file_end, ParSeg *sg, int min_len)
 
 /* one window: cut [pos, wend) into segments, parse them on n_thr threads, accept the verified prefix.  Returns the
  * number of accepted segments; *next = where the following window starts; *done = the stream has ended */
-static int parse_window(int fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done)
+static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done)
 {
 	const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
 	int n_seg = 0;
@@ -773,11 +863,32 @@ static int parse_window(int fd, int64_t size, int64_t pos, int64_t WIN, int min_
 	return n_ok;
 }
 
+/* the source the parallel parser can take for `fn`, if any: a plain regular file (fx.fd) or a BGZF file, larger than min_size.
+ * *own_fd (>= 0) is a descriptor the caller closes afterwards */
+static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64_t min_size, ByteSource *src, int *own_fd)
+{
+	*own_fd = -1;
+	if (n_thr <= 1) return false;
+	struct stat sb;
+	if (fx.fd >= 0) {
+		if (fstat(fx.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= min_size) return false;
+		src->fd = fx.fd; src->size = sb.st_size; src->bgzf = false;
+		return true;
+	}
+	if (fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_BGZF")) return false;
+	const int f = ::open(fn, O_RDONLY);
+	if (f < 0) return false;
+	if (!src->index_bgzf(f) || src->size <= min_size) { ::close(f); src->fd = -1; src->bgzf = false; return false; }
+	*own_fd = f;
+	return true;
+}
+
 /* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
  * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
  * threads already work on the next one. */
-static bool parse_parallel(int fd, int64_t size, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
+static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
 {
+	const int64_t size = fd->size;
 	const int64_t WIN = (int64_t)env_threads_window();
 	std::vector<ParSeg> seg[2] = { std::vector<ParSeg>(n_thr), std::vector<ParSeg>(n_thr) };
 	int64_t pos = 0, next[2] = { 0, 0 };
@@ -1030,9 +1141,9 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		return ok;
 	};
 	const int n_thr = parse_threads(opt->n_thread);
-	int64_t par_size = -1;
-	if (fx.fd >= 0 && n_thr > 1) { struct stat sb; if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) par_size = sb.st_size; }
-	if (ok && par_size >= 0) ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, take_piece);
+	ByteSource psrc; int psrc_fd = -1;
+	const bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
+	if (ok && par) ok = parse_parallel(&psrc, opt->k, n_thr, take_piece);
 	else if (ok) {
 		std::vector<char> piece;
 		int64_t l, ns = 0;
@@ -1058,6 +1169,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	multi_tot(h);
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, J.use_rccl ? "RCCL exchange" : "peer copies");
+	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
@@ -1094,13 +1206,10 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
 	/* a plain regular file is mapped and parsed by several threads; anything else (gzip, a pipe) streams through the reader */
 	const int n_thr = parse_threads(opt->n_thread);
-	int64_t par_size = -1;
-	if (fx.fd >= 0 && n_thr > 1) {
-		struct stat sb;
-		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) par_size = sb.st_size;
-	}
+	ByteSource psrc; int psrc_fd = -1;
+	const int64_t par_size = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd) ? psrc.size : -1;   /* plain or block-gzipped regular file */
 	if (ok && par_size >= 0) {
-		ok = parse_parallel(fx.fd, par_size, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
+		ok = parse_parallel(&psrc, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
 			bool good = img_n == 0 || yakamd_feed_bases_host(h, img, (int64_t)img_n, t0) == 0;
 			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
@@ -1130,6 +1239,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot);
+	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
@@ -1160,12 +1270,13 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 	int64_t l;
 	const double t_ = yk_realtime();
 	const int n_thr = use_fast_path ? parse_threads(1) : 1;    /* tests set YAKAMD_PARSE_THREADS */
-	if (fx.fd >= 0 && n_thr > 1) {
-		struct stat sb;
-		if (fstat(fx.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+	{
+		ByteSource psrc; int psrc_fd = -1;
+		if (parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd)) {
 			size_t total = 0;
-			parse_parallel(fx.fd, (int64_t)sb.st_size, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part, part + part_n); return true; });
-			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes\n", yk_realtime() - t_, n_thr, total);
+			parse_parallel(&psrc, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part, part + part_n); return true; });
+			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
+			if (psrc_fd >= 0) ::close(psrc_fd);
 			fx.close_file();
 			*out = (char*)malloc(img.size() + 1);
 			memcpy(*out, img.data(), img.size());
