@@ -1188,33 +1188,38 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	}
 	FxReader fx;
 	if (!fx.open_file(fn)) return 0;                         /* count.c:152 */
-	yak_ch_t *h;
-	int create_new;
-	if (h0) {
-		assert(h0->k == opt->k && h0->pre == opt->pre);      /* count.c:157 */
-		h = h0; create_new = 0;
-	} else {
-		create_new = 1;
-		h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
-		if (h == 0) { fx.close_file(); return 0; }
-	}
+	yak_ch_t *h = h0;
+	const int create_new = h0 ? 0 : 1;
+	if (h0) assert(h0->k == opt->k && h0->pre == opt->pre);  /* count.c:157 */
 	yk_realtime();
-	int ok = yakamd_pass_begin(h, create_new) == 0;
-	std::vector<char> chunk;
-	chunk.reserve((size_t)std::min<int64_t>(opt->chunk_size + (opt->chunk_size >> 3) + 65536, (int64_t)1 << 31));
-	uint64_t t0 = 0;
-	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
 	/* a plain regular file is mapped and parsed by several threads; anything else (gzip, a pipe) streams through the reader */
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
 	const int64_t par_size = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd) ? psrc.size : -1;   /* plain or block-gzipped regular file */
-	if (ok && par_size >= 0) {
-		ok = parse_parallel(&psrc, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
+	int ok = 0;
+	auto open_table = [&]() {                                /* a new table: runtime start-up, the filter's 2^bf_shift bits, the pass */
+		if (!h0) h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
+		ok = h != 0 && yakamd_pass_begin(h, create_new) == 0;
+	};
+	std::thread opener;                                      /* ... happen while the first window of the file is being parsed */
+	if (par_size >= 0 && !h0) opener = std::thread(open_table); else open_table();
+	if (!opener.joinable() && h == 0) { if (psrc_fd >= 0) ::close(psrc_fd); fx.close_file(); return 0; }
+	std::vector<char> chunk;
+	if (par_size < 0) chunk.reserve((size_t)std::min<int64_t>(opt->chunk_size + (opt->chunk_size >> 3) + 65536, (int64_t)1 << 31));
+	uint64_t t0 = 0;
+	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
+	if (par_size >= 0) {
+		const bool parsed = parse_parallel(&psrc, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
+			if (opener.joinable()) opener.join();
+			if (!ok) return false;
 			bool good = img_n == 0 || yakamd_feed_bases_host(h, img, (int64_t)img_n, t0) == 0;
 			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
 			return good;
 		});
+		if (opener.joinable()) opener.join();
+		if (h == 0) { if (psrc_fd >= 0) ::close(psrc_fd); fx.close_file(); return 0; }
+		ok = ok && parsed;
 	}
 	auto flush = [&]() {
 		if (!chunk.empty() && ok) ok = yakamd_feed_bases_host(h, chunk.data(), (int64_t)chunk.size(), t0) == 0;
