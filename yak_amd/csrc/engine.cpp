@@ -805,7 +805,7 @@ static int feed_image(yak_ch_t *h, const void *d_bases, const u32 *d_valid, int6
 	if (((uintptr_t)d_bases & 15) != 0) return fail("device base image must be 16-byte aligned");
 	HIPCK(hipSetDevice(c->dev));
 	int64_t batch = env_i64("YAKAMD_BATCH", (int64_t)1 << 31);
-	batch = std::max<int64_t>(4096, batch & ~(int64_t)4095);
+	batch = std::min<int64_t>((int64_t)1 << 31, std::max<int64_t>(4096, batch & ~(int64_t)4095));   /* run starts are 31-bit (tagged records: bit 31 is the toggle) */
 	int hash_only = !c->create_new;                        /* counting existing keys needs no stream positions */
 	int ytag = 0;
 	if (hash_only && c->k < 32 && c->nb_bits <= 10 && env_i64("YAKAMD_YTAG", 1) != 0) {   /* the key-owning count will run: its range test is prepared by the extraction */
@@ -896,6 +896,7 @@ extern "C" int yakamd_tagged_ok(int k, int pre) { return k >= 1 && k < 32 && 2 *
 extern "C" int64_t yakamd_partition_tagged_dev(int k, int pre, const void *d_bases, int64_t n_bytes, void *d_rec8_out, uint64_t *h_bstart)
 {
 	if (!yakamd_tagged_ok(k, pre)) { fail("partition: tagged records need k < 32, 2k - pre <= 52, pre <= 10"); return -1; }
+	if (n_bytes > ((int64_t)1 << 31)) { fail("partition: at most 2^31 stream positions per call with tagged records (31-bit run starts)"); return -1; }
 	return partition_dev(k, pre, d_bases, n_bytes, d_rec8_out, h_bstart, 2);
 }
 
