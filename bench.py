@@ -136,6 +136,7 @@ def main():
                          "cfg4 = configs[3], yak count -k21 on a synthetic assembly (long contigs, singletons kept); cfg5 = configs[4], lookup-only path of yak qv")
     ap.add_argument("--contigs", type=int, default=50, help="cfg4: number of contigs")
     ap.add_argument("--contig-len", type=int, default=100_000_000, help="cfg4: bases per contig")
+    ap.add_argument("--sweeps", type=int, default=1, help="cfg4: > 1 = count through yak_count() in that many sweeps over prefix ranges (sizes beyond one pass: --contigs 50 --sweeps 8 = 5 Gb)")
     ap.add_argument("--qv-reads", type=int, default=75_000, help="cfg5: number of 20 kb query reads")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: reads per GPU fixed (weak) or --total-reads fixed (strong)")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job (BASELINE configs[2]: 600000000)")

@@ -50,7 +50,60 @@ def _timed(torch, steps, warmup, fn):
     return (time.perf_counter() - t0) / steps, r
 
 
+def run_cfg4_sweeps(a, yak_amd):
+    """cfg4 beyond what one pass holds in HBM (5 Gb: 68 GB of table, twice that while a doubling is replayed, 80 GB of selected
+    keys): `yak_count()` itself with YAKAMD_GPUS = N ranks on ONE device -- the pass in N sweeps over prefix ranges (every rank owns
+    P / N sub-tables; ranks that share a device finish their passes one after the other).  File-inclusive: the assembly is written
+    as FASTA and parsed by the library's reader.  Properties only (no reference golden exists at this size: the reference needs
+    more host memory than the build container has)."""
+    K = 21
+    L = yak_amd.lib()
+    threads = min(os.cpu_count() or 8, 32)
+    tmp = tempfile.mkdtemp(prefix="ykc4", dir=os.environ.get("YAKAMD_TMP", None))
+    fa = os.path.join(tmp, "asm.fa")
+    try:
+        subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-T", "-n", str(a.contigs), "-l", str(a.contig_len), "-s", "42", "-w", "60", "-t", str(threads), "-o", fa])
+        inst = a.contigs * (a.contig_len - K + 1)
+        os.environ["YAKAMD_GPUS"] = str(a.sweeps); os.environ["YAKAMD_GPU_LIST"] = ",".join(["0"] * a.sweeps)
+        res = []
+        for chunk in ((1 << 28), (1 << 27)):                    # two chunkings of the stream: the result must not depend on it
+            os.environ["YAKAMD_MGPU_CHUNK"] = str(chunk)
+            o = yak_amd.CoptT(); L.yak_copt_init(C.byref(o)); o.k, o.n_thread = K, threads
+            t0 = time.perf_counter()
+            h = L.yak_count(fa.encode(), C.byref(o), None)
+            dt = time.perf_counter() - t0
+            if not h:
+                raise SystemExit("FAILED: yak_count: " + yak_amd._err())
+            hist = (C.c_int64 * 1024)()
+            L.yak_ch_hist(h, hist, 1)
+            tot = h.contents.tot
+            res.append((dt, tot, list(hist)))
+            L.yak_ch_destroy(h)
+            L.yakamd_trim()
+        for k_ in ("YAKAMD_GPUS", "YAKAMD_GPU_LIST", "YAKAMD_MGPU_CHUNK"):
+            del os.environ[k_]
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+    dt, tot, hist = res[0]
+    verify = {"count_mass_equals_instances": sum(c * hist[c] for c in range(1024)) == inst and hist[1023] == 0, "sum_hist_equals_tot": sum(hist) == tot,
+              "chunking_independent": res[0][1:] == res[1][1:], "yak_size_bytes": 16 + 8 * (1 << PRE) + 8 * tot, "distinct": tot}
+    if not all(v for v in verify.values() if isinstance(v, bool)):
+        raise SystemExit(f"FAILED: {verify}")
+    by = 32.0 * inst
+    return {"metric": "distinct k-mers counted/sec (k=21), yak count on an assembly (no filter, singletons kept), file-inclusive, pass in sweeps over prefix ranges",
+            "value": tot / dt, "unit": "distinct k-mers/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": dt * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"yak count -k{K} -t{threads} on a synthetic assembly FASTA: {a.contigs} contigs x {a.contig_len} bp (tools/yaksynth -T, seed 42), no filter, "
+                                   f"yak_count() in {a.sweeps} sweeps over prefix ranges on one device (YAKAMD_GPUS={a.sweeps}, YAKAMD_GPU_LIST=0,...)", "k": K, "pre": PRE, "bf_shift": 0},
+            "kmer_instances_per_s": inst / dt, "final_distinct": tot, "seconds_second_chunking": res[1][0],
+            "roofline": {"bound": "hbm", "kernel": "whole yak_count() call (parse + sweeps)", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_instance": 32.0},
+            "verify": verify}
+
+
 def run_cfg4(a, torch, yak_amd):
+    if a.sweeps > 1:
+        return run_cfg4_sweeps(a, yak_amd)
     K = 21
     L = yak_amd.lib()
     threads = min(os.cpu_count() or 8, 64)

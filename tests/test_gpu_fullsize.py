@@ -53,3 +53,13 @@ def test_cfg4_1gb_assembly_equals_reference():
 def test_cfg5_qv_histogram_equals_reference():
     d = bench_line("--config", "cfg5")
     assert d["verify"]["equals_reference"] is True and d["verify"]["kmers"] == d["verify"]["kmers_expected"]
+
+
+def test_cfg4_1gb_in_sweeps_over_prefix_ranges():
+    """the same 1 Gb assembly through yak_count() as four ranks on one device (the way sizes beyond one pass -- 5 Gb -- are
+    counted: `--config cfg4 --contigs 50 --sweeps 8`): the distinct count is the reference's, the counts add up to the
+    instances, two chunkings of the stream agree"""
+    d = bench_line("--config", "cfg4", "--contigs", "10", "--contig-len", "100000000", "--sweeps", "4")
+    v = d["verify"]
+    assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
+    assert v["distinct"] == 999771658 and v["yak_size_bytes"] == 7998181472

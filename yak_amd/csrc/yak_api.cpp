@@ -22,6 +22,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <vector>
+#include <algorithm>
 #include <string>
 #include <cmath>
 #include "engine.h"
@@ -1060,7 +1061,8 @@ static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_n
 	if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
 	{	/* every owner takes its slices, in chunk order = stream order */
 		std::vector<std::thread> th;
-		for (int d = 0; d < N; ++d) th.emplace_back([&, d]() {
+		std::vector<int> devs(J->dev); std::sort(devs.begin(), devs.end()); devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+		for (int dv : devs) th.emplace_back([&, dv]() { for (int d = 0; d < N; ++d) if (J->dev[d] == dv) {   /* owners that share a device take turns: a feed may count a whole slice of the pass */
 			hipSetDevice(J->dev[d]);
 			const int lo = d * (P / N), hi = (d + 1) * (P / N);
 			std::vector<uint64_t> ob(P + 1);
@@ -1074,7 +1076,7 @@ static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_n
 				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
 				if (rc != 0) ok[d] = 0;
 			}
-		});
+		} });
 		for (auto &t : th) t.join();
 	}
 	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
@@ -1158,11 +1160,16 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns);
 	}
 	if (ok) { bool any = false; for (int r = 0; r < N; ++r) any = any || fill[r] > 0; if (any) round(); }
-	{	/* every GPU finishes its pass: partitions, counting, layout -- side by side */
+	{	/* every GPU finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
+		 * scratch of only one of them is alive at a time (one device posing as N = the pass in N sweeps over prefix ranges: what lets a
+		 * 5 Gb assembly through 288 GB) */
 		std::vector<int64_t> n_ins(N, 0);
 		std::vector<std::thread> th;
-		for (int r = 0; r < N; ++r) th.emplace_back([&, r]() { n_ins[r] = yakamd_pass_end(e->sub[r]); });
+		std::vector<int> devs(dev); std::sort(devs.begin(), devs.end()); devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+		std::vector<std::string> why(N);                       /* the error text is per thread: bring it back */
+		for (int d : devs) th.emplace_back([&, d]() { for (int r = 0; r < N; ++r) if (dev[r] == d) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) why[r] = yakamd_last_error(); } });
 		for (auto &t : th) t.join();
+		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) fprintf(stderr, "[E::yak_count] rank %d of %d (device %d): %s\n", r, N, dev[r], why[r].c_str());
 		for (int r = 0; r < N; ++r) { if (n_ins[r] < 0) ok = false; else e->sub[r]->tot += (uint64_t)n_ins[r]; }
 	}
 	multi_close(&J);
