@@ -50,3 +50,18 @@ def test_multi_gpu_exchange_formats(args, extra, reads):
     env = dict(os.environ, YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="300000", **extra)
     subprocess.run([YAM, "count"] + args + ["-o", got, reads["fq"]], check=True, env=env, stderr=subprocess.PIPE)
     assert open(got, "rb").read() == open(want, "rb").read()
+
+
+def test_large_unfiltered_plain_files_are_counted_in_sweeps(reads):
+    """no filter + a plain file beyond YAKAMD_AUTO_SWEEP_GB: yak_count() takes the input as N ranks on its one device (an
+    assembly of several Gb does not fit one pass); a filtered count, or YAKAMD_GPUS set, leaves the rule off.  Bytes unchanged."""
+    want, got = os.path.join(reads["dir"], "one3.yak"), os.path.join(reads["dir"], "multi3.yak")
+    env = dict(os.environ, YAKAMD_AUTO_SWEEP_GB="0.000001")
+    env.pop("YAKAMD_GPUS", None); env.pop("YAKAMD_GPU_LIST", None)
+    for args, swept in ((["-k21"], True), (["-k21", "-b22"], False)):
+        subprocess.run([YKO, "count"] + args + ["-o", want, reads["fa"]], check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run([YAM, "count"] + args + ["-o", got, reads["fa"]], check=True, env=env, stderr=subprocess.PIPE)
+        assert (b"sweeps over prefix ranges" in r.stderr) == swept
+        assert open(got, "rb").read() == open(want, "rb").read()
+    r = subprocess.run([YAM, "count", "-k21", "-o", got, reads["fa"]], check=True, env=dict(env, YAKAMD_GPUS="1"), stderr=subprocess.PIPE)
+    assert b"sweeps over prefix ranges" not in r.stderr

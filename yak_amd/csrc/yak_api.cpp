@@ -959,10 +959,43 @@ struct MultiJob {
 	int64_t chunk, send_words, recv_words;
 };
 
-static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev)
+/* no filter + a plain file of more than YAKAMD_AUTO_SWEEP_GB (2.5) GB: nearly every k-mer instance may be a key of its own (an assembly),
+ * and one pass holds ~100 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
+ * prefix ranges (N so that a sweep sees ~0.7 G positions of its own).  YAKAMD_GPUS set to anything switches the rule off */
+static int auto_sweeps(const yak_copt_t *opt, const char *fn)
+{
+	if (fn == 0 || strcmp(fn, "-") == 0 || opt->bf_shift > opt->pre) return 1;
+	const char *g = getenv("YAKAMD_AUTO_SWEEP_GB");
+	const double lim = (g ? atof(g) : 2.5) * 1e9;
+	if (lim <= 0) return 1;
+	struct stat sb;
+	if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode) || (double)sb.st_size <= lim) return 1;
+	unsigned char m[2] = { 0, 0 };
+	const int f = ::open(fn, O_RDONLY);
+	if (f < 0) return 1;
+	const bool gz = ::read(f, m, 2) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+	::close(f);
+	if (gz) return 1;                                           /* compressed: the size says little; the knob is there */
+	int N = 2;
+	while (N < 16 && (double)sb.st_size / N > 0.7e9) N <<= 1;
+	return (1 << opt->pre) % N ? 1 : N;
+}
+
+static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *fn = 0)
 {
 	const char *e = getenv("YAKAMD_GPUS");
-	const int N = e ? atoi(e) : 1;
+	if (!e) {
+		const int S = auto_sweeps(opt, fn);
+		if (S <= 1) return 1;
+		int nd = 0;
+		if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
+		const char *dv = getenv("YAKAMD_DEVICE"), *lr = getenv("LOCAL_RANK");
+		const int d = (dv ? atoi(dv) : lr ? atoi(lr) : 0) % nd;
+		dev->assign(S, d);
+		fprintf(stderr, "[M::yak_count] %s: no filter and a large plain file: counting in %d sweeps over prefix ranges on device %d (YAKAMD_GPUS / YAKAMD_AUTO_SWEEP_GB change that)\n", fn, S, d);
+		return S;
+	}
+	const int N = atoi(e);
 	if (N <= 1) return 1;
 	int nd = 0;
 	if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
@@ -1187,7 +1220,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 {
 	{
 		std::vector<int> dev;
-		const int N = h0 ? ((yak_ch_ext*)h0)->n_sub : multi_gpus(opt, &dev);
+		const int N = h0 ? ((yak_ch_ext*)h0)->n_sub : multi_gpus(opt, &dev, fn);
 		if (N > 1) {
 			if (h0) { dev.clear(); for (int r = 0; r < N; ++r) dev.push_back(yk_ctx_device(((yak_ch_ext*)((yak_ch_ext*)h0)->sub[r])->ctx)); }
 			return yak_count_multi(fn, opt, h0, N, dev);
