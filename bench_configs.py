@@ -102,6 +102,8 @@ def run_cfg4_sweeps(a, yak_amd):
 
 
 def run_cfg4(a, torch, yak_amd):
+    if a.sweeps == 1 and a.contigs * a.contig_len > 2_500_000_000:
+        a.sweeps = 8                                           # beyond one pass's memory (the default 50 x 100 Mb = BASELINE configs[3])
     if a.sweeps > 1:
         return run_cfg4_sweeps(a, yak_amd)
     K = 21
