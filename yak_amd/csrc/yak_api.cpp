@@ -1455,78 +1455,118 @@ static bool solve_full_pivot(double *a, double *b, int n)
 	return true;
 }
 
-/* reference qv.c:146-244 -- host arithmetic on two 1024-bin histograms (hist: k-mer occurrence in the
- * short reads, cnt: occurrences looked up for the assembly's k-mers): raw QV from the share of absent
- * k-mers; coverage at the histogram peak; bounds on the false-positive rate of "absent"; error-corrected
- * counts between the trough and the peak; a quadratic least-squares fit of the successive ratios
- * extrapolated down to count 0; adjusted QV.  Returns -1 when the data cannot support the adjustment. */
-int yak_qv_solve(const int64_t *hist, const int64_t *cnt, int kmer, double fpr, yak_qstat_t *qs)
+/* yak_qv_solve (reference qv.c:146-244): host arithmetic on two 1024-bin histograms -- in_table[c] = stored k-mers
+ * that occur c times in the short reads, in_seqs[c] = k-mers of the assembly found with count c.  The statistics are
+ * the reference's (raw QV from the share of absent k-mers; coverage at the histogram peak; bounds on the false-positive
+ * rate of "absent"; corrected counts between the trough and the peak; successive ratios fitted by a parabola and
+ * extrapolated to count 0; adjusted QV) and the printed digits must equal the reference's, so every floating-point
+ * expression keeps the reference's operand order and association (sums run over ascending k, powers are built by
+ * repeated multiplication).  That is the only thing shared with qv.c: the stages below are this file's own cut. */
+} /* extern "C" */
+namespace {
+struct QvShape { int peak = -1, trough = -1; };
+
+/* the mode of in_seqs over counts [2, 1023) and the lowest point in front of it */
+QvShape qv_shape(const int64_t *in_seqs)
 {
-	const int n_cnt = YAK_N_COUNTS, deg = 2;
-	const double ln10_10 = 4.3429448190325175;              /* 10 / ln 10 */
-	memset(qs, 0, sizeof(*qs));
-	qs->qv = -1.0; qs->err = (double)cnt[0];
-	for (int c = 0; c < n_cnt; ++c) { qs->tot += cnt[c]; qs->adj_cnt[c] = (double)cnt[c]; }
-	qs->qv_raw = (qs->tot > 0 && qs->tot > cnt[0]) ? -ln10_10 * log(log((double)qs->tot / (qs->tot - cnt[0])) / kmer) : -1.0;
+	QvShape s;
+	int32_t top = 0;
+	for (int c = 2; c < YAK_N_COUNTS - 1; ++c) if (top < in_seqs[c]) { top = (int32_t)in_seqs[c]; s.peak = c; }
+	int32_t low = top;
+	for (int c = 2; c < s.peak; ++c) if (low > in_seqs[c]) { low = (int32_t)in_seqs[c]; s.trough = c; }
+	return s;
+}
 
-	int peak = -1, trough = -1;
-	int32_t peak_cnt = 0;
-	for (int c = 2; c < n_cnt - 1; ++c) if (peak_cnt < cnt[c]) { peak_cnt = (int32_t)cnt[c]; peak = c; }
-	if (peak < 0) return -1;                                 /* nothing beyond count 1 */
-	int32_t trough_cnt = peak_cnt;
-	for (int c = 2; c < peak; ++c) if (trough_cnt > cnt[c]) { trough_cnt = (int32_t)cnt[c]; trough = c; }
-	qs->cov = (double)cnt[peak] / hist[peak];
-
+/* brackets the false-positive rate from the counts below the peak and clamps the caller's estimate into them */
+double qv_fpr_bounds(const int64_t *in_table, const int64_t *in_seqs, const QvShape &s, double fpr, yak_qstat_t *qs)
+{
 	qs->fpr_upper = 1.0;
-	for (int c = 2; c < peak; ++c) { const double e = cnt[c] / (qs->cov * hist[c]); if (qs->fpr_upper > e) qs->fpr_upper = e; }
+	for (int c = 2; c < s.peak; ++c) {
+		const double e = in_seqs[c] / (qs->cov * in_table[c]);
+		if (qs->fpr_upper > e) qs->fpr_upper = e;
+	}
 	if (fpr > qs->fpr_upper) fpr = qs->fpr_upper * 0.5;
 	qs->fpr_lower = 0.0;
-	if (trough > 2 && hist[2] > hist[trough]) {
-		const double e = (cnt[2] - cnt[trough]) / (qs->cov * (hist[2] - hist[trough]));
+	if (s.trough > 2 && in_table[2] > in_table[s.trough]) {
+		const double e = (in_seqs[2] - in_seqs[s.trough]) / (qs->cov * (in_table[2] - in_table[s.trough]));
 		if (qs->fpr_lower < e) qs->fpr_lower = e;
 	}
 	if (fpr < qs->fpr_lower) fpr = qs->fpr_lower;
 	if (qs->fpr_lower >= qs->fpr_upper)
 		fprintf(stderr, "Warning: the FPR upper bound is smaller than the lower bound. Trust the lower bound.\n");
+	return fpr;
+}
 
-	if (peak <= 4) return -1;                                /* not high-coverage data */
-	const int n_fit = peak - trough + 1 < 8 ? peak - trough + 1 : 8;
-	if (n_fit < 3) return -1;
+/* least-squares polynomial of degree DEG through (x[k], y[k]), k < n, by the normal equations: coef[i] multiplies x^i.
+ * pw[m][k] = x[k]^m by repeated multiplication; entry (i, j) of the matrix is the sum over k of pw[i + j][k] */
+template <int DEG>
+bool fit_polynomial(const double *x, const double *y, int n, double *coef)
+{
+	std::vector<double> pw((size_t)(2 * DEG + 1) * n);
+	for (int k = 0; k < n; ++k) {
+		double t = 1.0;
+		for (int m = 0; m <= 2 * DEG; ++m) { pw[(size_t)m * n + k] = t; t *= x[k]; }
+	}
+	double M[(DEG + 1) * (DEG + 1)];
+	for (int i = 0; i <= DEG; ++i) {
+		for (int j = 0; j <= i; ++j) {
+			double acc = 0.0;
+			for (int k = 0; k < n; ++k) acc += pw[(size_t)(i + j) * n + k];
+			M[i * (DEG + 1) + j] = M[j * (DEG + 1) + i] = acc;
+		}
+		double acc = 0.0;
+		for (int k = 0; k < n; ++k) acc += pw[(size_t)i * n + k] * y[k];
+		coef[i] = acc;
+	}
+	return solve_full_pivot(M, coef, DEG + 1);
+}
 
-	for (int c = peak - 1; c >= trough; --c) {               /* remove the expected false "present" calls */
-		const double wrong = (hist[c] - cnt[c] / qs->cov) / (1.0 - fpr);
-		qs->adj_cnt[c] = cnt[c] - wrong * qs->cov * fpr;
+template <int DEG> double eval_polynomial(const double *coef, double at)
+{
+	double r = 0.0, t = 1.0;
+	for (int i = 0; i <= DEG; ++i) { r += coef[i] * t; t *= at; }
+	return r;
+}
+} // namespace
+
+extern "C" int yak_qv_solve(const int64_t *in_table, const int64_t *in_seqs, int kmer, double fpr, yak_qstat_t *qs)
+{
+	constexpr int DEG = 2, MAX_FIT = 8;
+	const double db_per_ln = 4.3429448190325175;             /* 10 / ln 10 */
+	memset(qs, 0, sizeof(*qs));
+	for (int c = 0; c < YAK_N_COUNTS; ++c) { qs->tot += in_seqs[c]; qs->adj_cnt[c] = (double)in_seqs[c]; }
+	qs->err = (double)in_seqs[0];
+	qs->qv = -1.0;
+	qs->qv_raw = (qs->tot > 0 && qs->tot > in_seqs[0]) ? -db_per_ln * log(log((double)qs->tot / (qs->tot - in_seqs[0])) / kmer) : -1.0;
+
+	const QvShape s = qv_shape(in_seqs);
+	if (s.peak < 0) return -1;                               /* nothing beyond count 1 */
+	qs->cov = (double)in_seqs[s.peak] / in_table[s.peak];
+	fpr = qv_fpr_bounds(in_table, in_seqs, s, fpr, qs);
+
+	const int n_fit = std::min(MAX_FIT, s.peak - s.trough + 1);
+	if (s.peak <= 4 || n_fit < 3) return -1;                 /* not high-coverage data: no adjustment */
+
+	for (int c = s.peak - 1; c >= s.trough; --c) {           /* take the expected false "present" calls out */
+		const double wrong = (in_table[c] - in_seqs[c] / qs->cov) / (1.0 - fpr);
+		qs->adj_cnt[c] = in_seqs[c] - wrong * qs->cov * fpr;
 		if (qs->adj_cnt[c] < 0.0) qs->adj_cnt[c] = 0.0;
 	}
 
-	/* ratios adj[c+1] / adj[c] at c = trough .. trough + n_fit - 1, fitted by a + b c + c c^2 */
-	double xs[8], ys[8], pw[(2 * deg + 1) * 8], A[(deg + 1) * (deg + 1)], B[deg + 1];
-	for (int k = 0; k < n_fit; ++k) { xs[k] = trough + k; ys[k] = qs->adj_cnt[trough + k + 1] / qs->adj_cnt[trough + k]; }
-	for (int k = 0; k < n_fit; ++k) { double t = 1.0; for (int i = 0; i <= 2 * deg; ++i) { pw[i * n_fit + k] = t; t *= xs[k]; } }
-	for (int i = 0; i <= deg; ++i) {
-		for (int j = 0; j <= i; ++j) {
-			double sum = 0.0;
-			for (int k = 0; k < n_fit; ++k) sum += pw[(i + j) * n_fit + k];
-			A[i * (deg + 1) + j] = A[j * (deg + 1) + i] = sum;
-		}
-		double sum = 0.0;
-		for (int k = 0; k < n_fit; ++k) sum += pw[i * n_fit + k] * ys[k];
-		B[i] = sum;
-	}
-	if (!solve_full_pivot(A, B, deg + 1)) fprintf(stderr, "ERROR: fail\n");
-
-	for (int c = trough - 1; c >= 0; --c) {                  /* extrapolate below the trough */
-		double r = 0.0, t = 1.0;
-		for (int i = 0; i <= deg; ++i) { r += B[i] * t; t *= c; }
+	double at[MAX_FIT], ratio[MAX_FIT], coef[DEG + 1];
+	for (int k = 0; k < n_fit; ++k) { at[k] = s.trough + k; ratio[k] = qs->adj_cnt[s.trough + k + 1] / qs->adj_cnt[s.trough + k]; }
+	if (!fit_polynomial<DEG>(at, ratio, n_fit, coef)) fprintf(stderr, "ERROR: fail\n");
+	for (int c = s.trough - 1; c >= 0; --c) {                /* below the trough: divide down by the fitted ratio, at least 1.01 */
+		double r = eval_polynomial<DEG>(coef, c);
 		if (r < 1.01) r = 1.01;
 		qs->adj_cnt[c] = qs->adj_cnt[c + 1] / r;
 	}
 
 	double adj_sum = 0.0;
-	for (int c = 0; c < n_cnt; ++c) adj_sum += qs->adj_cnt[c];
+	for (int c = 0; c < YAK_N_COUNTS; ++c) adj_sum += qs->adj_cnt[c];
 	if (adj_sum <= (double)qs->tot) {
 		qs->err = qs->tot - adj_sum;
-		qs->qv = -ln10_10 * log(log(qs->tot / adj_sum) / kmer);
+		qs->qv = -db_per_ln * log(log(qs->tot / adj_sum) / kmer);
 	} else {
 		fprintf(stderr, "WARNING: failed to estimate the calibrated QV\n");
 		qs->err = 0;
@@ -1535,4 +1575,4 @@ int yak_qv_solve(const int64_t *hist, const int64_t *cnt, int kmer, double fpr, 
 	return 0;
 }
 
-} /* extern "C" */
+
