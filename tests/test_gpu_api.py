@@ -277,13 +277,19 @@ def test_set_operations_on_the_device(op, ya, oracle, synth, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sweeps", [0, 1], ids=["one_table", "tables_sharded_by_sweeps"])
 @pytest.mark.parametrize("pre_resize", [0, 1], ids=["plain", "resize_before_merge"])
-def test_cntasm_protocol_equals_reference_cli(pre_resize, ya, oracle, tmp_path):
+def test_cntasm_protocol_equals_reference_cli(pre_resize, sweeps, ya, oracle, tmp_path, monkeypatch):
     """`yak cntasm` (main.c:90-161) -- count each assembly, keep its unique k-mers, merge sample after
     sample, shrink, tighten, dump -- as the same call sequence on the library; the file must equal the
-    one the reference binary writes (oracle/_ref/yak, where it travelled) and the oracle's"""
+    one the reference binary writes (oracle/_ref/yak, where it travelled) and the oracle's.  With sweeps
+    every yak_count() returns a table sharded over prefix ranges (what an unfiltered count of a large
+    plain file does by itself): merge, shrink, setcnt, tighten and dump must take it shard by shard"""
     import subprocess
     from conftest import ROOT
+    if sweeps:
+        monkeypatch.setenv("YAKAMD_AUTO_SWEEP_GB", "0.000001")
+        monkeypatch.delenv("YAKAMD_GPUS", raising=False)
     L, O = ya.lib(), oracle.lib()
     syn, ref = os.path.join(ROOT, "tools", "yaksynth"), os.path.join(ROOT, "oracle", "_ref", "yak")
     fas = []
@@ -323,6 +329,50 @@ def test_cntasm_protocol_equals_reference_cli(pre_resize, ya, oracle, tmp_path):
         subprocess.run([ref, "cntasm", f"-k{K}"] + (["-r"] if pre_resize else []) + ["-o", out] + fas, check=True, stderr=subprocess.DEVNULL)
         assert open(out, "rb").read() == got
     L.yak_ch_destroy(h); O.yko_ch_destroy(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["first_sharded", "second_sharded", "both_sharded"])
+@pytest.mark.parametrize("op", ["subtract", "isec", "merge_presize"])
+def test_two_table_operations_on_sharded_tables(op, which, ya, oracle, tmp_path, monkeypatch):
+    """yak_ch_subtract / isec / merge when yak_count() handed out tables sharded over prefix ranges (sweeps): the result
+    must be the one the unsharded tables give (the oracle's)"""
+    import subprocess
+    from conftest import ROOT
+    L, O = ya.lib(), oracle.lib()
+    O.yko_ch_merge.argtypes = [C.POINTER(oracle.Ch), C.POINTER(oracle.Ch), C.c_int, C.c_int, C.c_int]
+    O.yko_ch_subtract.argtypes = [C.POINTER(oracle.Ch)] * 2
+    O.yko_ch_isec.argtypes = [C.POINTER(oracle.Ch)] * 2
+    syn = os.path.join(ROOT, "tools", "yaksynth")
+    fas = []
+    for j, e in enumerate((0.001, 0.01)):
+        fa = str(tmp_path / f"s{j}.fa")
+        subprocess.check_call([syn, "-a", "-n", "10", "-l", "15000", "-g", "120000", "-s", "41", "-e", str(e), "-N", "0.0002", "-o", fa])
+        fas.append(fa)
+    o = ya.CoptT(); L.yak_copt_init(C.byref(o)); o.k = 23
+    oo = oracle.copt(k=23)
+    hs = []
+    for j, fa in enumerate(fas):
+        sharded = which == "both_sharded" or (which == "first_sharded") == (j == 0)
+        if sharded:
+            monkeypatch.setenv("YAKAMD_AUTO_SWEEP_GB", "0.000001")
+        else:
+            monkeypatch.setenv("YAKAMD_AUTO_SWEEP_GB", "0")
+        hs.append(L.yak_count(fa.encode(), C.byref(o), None))
+        assert hs[-1]
+    gs = [O.yko_count_file(fa.encode(), C.byref(oo), None) for fa in fas]
+    if op == "subtract":
+        L.yak_ch_subtract(hs[0], hs[1], 4); O.yko_ch_subtract(gs[0], gs[1])
+    elif op == "isec":
+        L.yak_ch_isec(hs[0], hs[1], 4); O.yko_ch_isec(gs[0], gs[1])
+    else:
+        L.yak_ch_merge(hs[0], hs[1], 0, 1023, 4, 1); O.yko_ch_merge(gs[0], gs[1], 0, 1023, 1)
+    assert _dump(L, hs[0]) == oracle.dump_bytes(gs[0])
+    assert hs[0].contents.tot == gs[0].contents.tot and hs[0].contents.tot > 1000
+    L.yak_ch_destroy(hs[0]); O.yko_ch_destroy(gs[0])
+    if op != "merge_presize":
+        assert _dump(L, hs[1]) == oracle.dump_bytes(gs[1])
+        L.yak_ch_destroy(hs[1]); O.yko_ch_destroy(gs[1])
 
 
 @pytest.mark.gpu

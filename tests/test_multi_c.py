@@ -65,3 +65,15 @@ def test_large_unfiltered_plain_files_are_counted_in_sweeps(reads):
         assert open(got, "rb").read() == open(want, "rb").read()
     r = subprocess.run([YAM, "count", "-k21", "-o", got, reads["fa"]], check=True, env=dict(env, YAKAMD_GPUS="1"), stderr=subprocess.PIPE)
     assert b"sweeps over prefix ranges" not in r.stderr
+
+
+def test_a_sequence_longer_than_a_chunk_is_split_with_an_overlap(reads):
+    """contigs of 40 kb dealt in chunks of 16 KiB: a chunk then ends inside a sequence and the next one starts k - 1 bases earlier
+    (chromosomes beyond YAKAMD_MGPU_CHUNK = 256 Mb take this path in a swept count); the bytes stay the single pass's"""
+    want, got = os.path.join(reads["dir"], "one4.yak"), os.path.join(reads["dir"], "multi4.yak")
+    for args in (["-k21"], ["-k31", "-b22"], ["-k41"]):
+        subprocess.run([YKO, "count"] + args + ["-o", want, reads["fa"]], check=True, stderr=subprocess.DEVNULL)
+        for n_gpu in (2, 4):
+            env = dict(os.environ, YAKAMD_GPUS=str(n_gpu), YAKAMD_GPU_LIST=",".join(["0"] * n_gpu), YAKAMD_MGPU_CHUNK="16384")
+            subprocess.run([YAM, "count"] + args + ["-o", got, reads["fa"]], check=True, env=env, stderr=subprocess.PIPE)
+            assert open(got, "rb").read() == open(want, "rb").read()

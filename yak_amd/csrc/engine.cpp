@@ -1796,7 +1796,9 @@ int yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other)
 	const int P = c->P;
 	std::vector<u32> nb(P, YK_LEAVE);
 	bool any = false;
-	for (int p = 0; p < P; ++p) {
+	/* only the sub-tables both sides own: a shard of a table sharded over prefix ranges says nothing about the others (each sub-table
+	 * must meet its one pre-resize with the true key count of the other side) */
+	for (int p = std::max(c->plo, other->plo); p < std::min(c->phi, other->phi); ++p) {
 		const u64 cap = c->h_bits[p] == YK_NOCAP ? 0 : (u64)1 << c->h_bits[p];
 		const u64 want = ((u64)c->h_count[p] + other->h_count[p]) * 4 / 3 + 1;
 		if (want > cap) { nb[p] = resize_target(c->h_count[p], (u32)want); any = any || nb[p] != YK_LEAVE; }
@@ -1863,6 +1865,7 @@ int yk_ctx_resize_to(yakamd_ctx *c, const uint32_t *want)
 	return any ? resize_tables(c, nb) : 0;
 }
 u64 yk_ctx_keys_total(yakamd_ctx *c) { return c->img_keys_total; }
+void yk_ctx_range(yakamd_ctx *c, int *lo, int *hi) { *lo = c->plo; *hi = c->phi; }
 
 /* reference htab.c:441-447: resize each sub-table to its saved capacity, then put in file order */
 int yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys)

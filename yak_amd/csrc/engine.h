@@ -28,6 +28,7 @@ void *yk_ctx_scratch(yakamd_ctx *c, size_t bytes);
 int  yk_ctx_inc(yakamd_ctx *c, u64 hash, int *count);
 int  yk_ctx_resize_to(yakamd_ctx *c, const uint32_t *want);
 u64  yk_ctx_keys_total(yakamd_ctx *c);
+void yk_ctx_range(yakamd_ctx *c, int *lo, int *hi);   /* the prefix range [lo, hi) this context owns (yakamd_set_shard) */
 int  yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, const uint64_t *keys);
 int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
 u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);

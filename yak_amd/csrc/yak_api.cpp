@@ -22,6 +22,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <vector>
+#include <map>
 #include <algorithm>
 #include <string>
 #include <cmath>
@@ -131,7 +132,7 @@ static void multi_tot(yak_ch_t *h) { yak_ch_ext *e = (yak_ch_ext*)h; uint64_t t 
 static int multi_refuse(const yak_ch_t *h, const char *what)
 {
 	if (!YK_MULTI((const yak_ch_ext*)h)) return 0;
-	fprintf(stderr, "[E::%s] not available on a table sharded over several GPUs (YAKAMD_GPUS): count, clear, shrink, hist, get and dump are\n", what);
+	fprintf(stderr, "[E::%s] not available on a table sharded over prefix ranges (several GPUs, or a large unfiltered count taken in sweeps: YAKAMD_GPUS / YAKAMD_AUTO_SWEEP_GB)\n", what);
 	return 1;
 }
 
@@ -216,7 +217,9 @@ int yak_ch_inc(yak_ch_t *h, uint64_t x)                      /* reference htab.c
 {
 	if (YK_MULTI((yak_ch_ext*)h)) { yak_ch_ext *e = (yak_ch_ext*)h; return yak_ch_inc(e->sub[(x & ((1ULL << h->pre) - 1)) * e->n_sub >> h->pre], x); }
 	int c = -1;                                              /* one single-lane kernel on the table image; a valid host mirror is patched in place */
-	if (yk_ctx_inc(((yak_ch_ext*)h)->ctx, x, &c) != 0) { fprintf(stderr, "[E::%s] %s\n", __func__, yakamd_last_error()); return -1; }
+	yakamd_ctx *ctx = ((yak_ch_ext*)h)->ctx;
+	struct Lock { yakamd_ctx *c; Lock(yakamd_ctx *c_) : c(c_) { yk_ctx_lock(c); } ~Lock() { yk_ctx_unlock(c); } } lock(ctx);   /* shares the stream and the counters with yak_ch_insert_list */
+	if (yk_ctx_inc(ctx, x, &c) != 0) { fprintf(stderr, "[E::%s] %s\n", __func__, yakamd_last_error()); return -1; }
 	return c;
 }
 
@@ -250,49 +253,120 @@ void yak_ch_tighten(yak_ch_t *h)
 	if (yk_ctx_tighten(((yak_ch_ext*)h)->ctx)) fprintf(stderr, "[E::yak_ch_tighten] %s\n", yakamd_last_error());
 }
 
-/* reference htab.c:287-316 / 318-347: keep the k-mers of h0 that are absent from / present in h1 */
-void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
+/* ---- operations on two tables.  Either operand may be sharded over prefix ranges (yak_count() shards by itself: several GPUs, or an
+ * unfiltered count of a large plain file taken in sweeps); every sub-table belongs to exactly one shard of each operand, and the
+ * reference's operations are per sub-table (kt_for over 1 << pre, htab.c:246-347), so they are carried out shard by shard. ---- */
+int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out);
+static std::vector<yak_ch_t*> shards_of(const yak_ch_t *h)
 {
-	(void)n_thread;
-	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
-	unsigned long long tot = 0;
-	if (yk_ctx_subtract(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
-	else fprintf(stderr, "[E::yak_ch_subtract] %s\n", yakamd_last_error());
+	const yak_ch_ext *e = (const yak_ch_ext*)h;
+	return YK_MULTI(e) ? std::vector<yak_ch_t*>(e->sub, e->sub + e->n_sub) : std::vector<yak_ch_t*>(1, (yak_ch_t*)h);
+}
+static inline yakamd_ctx *shard_ctx(yak_ch_t *s) { return ((yak_ch_ext*)s)->ctx; }
+static void set_tot(yak_ch_t *h) { if (YK_MULTI((yak_ch_ext*)h)) multi_tot(h); }
+
+static bool parse_yak_image(const uint8_t *img, size_t sz, uint32_t hdr[3], std::vector<uint32_t> &caps, std::vector<uint32_t> &sizes, std::vector<uint64_t> &keys)
+{
+	if (sz < 16 || memcmp(img, YAK_MAGIC, 4) != 0) return false;
+	memcpy(hdr, img + 4, 12);
+	const int P = 1 << hdr[1];
+	caps.assign(P, 0); sizes.assign(P, 0); keys.clear();
+	size_t off = 16;
+	for (int p = 0; p < P; ++p) {
+		if (off + 8 > sz) return false;
+		uint32_t u[2]; memcpy(u, img + off, 8); off += 8;
+		if (off + (size_t)8 * u[1] > sz) return false;
+		caps[p] = u[0]; sizes[p] = u[1];
+		const size_t at = keys.size();
+		keys.resize(at + u[1]);
+		if (u[1]) memcpy(&keys[at], img + off, (size_t)8 * u[1]);
+		off += (size_t)8 * u[1];
+	}
+	return true;
 }
 
-void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread)
+/* an unsharded copy of `h` on device `dev`, by way of its .yak image (same keys and counts; the slot layout is the restored one, which
+ * membership tests do not look at).  Only for the second operand of subtract / isec when it is sharded or lives on another device */
+static yak_ch_t *unsharded_copy(const yak_ch_t *h, int dev)
 {
-	(void)n_thread;
-	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
-	unsigned long long tot = 0;
-	if (yk_ctx_isec(((yak_ch_ext*)h0)->ctx, ((yak_ch_ext*)h1)->ctx, &tot) == 0) h0->tot = tot;
-	else fprintf(stderr, "[E::yak_ch_isec] %s\n", yakamd_last_error());
+	uint8_t *img = 0;
+	const int64_t sz = yakamd_dump_mem((yak_ch_t*)h, &img);
+	if (sz < 0) return 0;
+	uint32_t hdr[3];
+	std::vector<uint32_t> caps, sizes;
+	std::vector<uint64_t> keys;
+	const bool ok = parse_yak_image(img, (size_t)sz, hdr, caps, sizes, keys);
+	free(img);
+	if (!ok) return 0;
+	yk_ctx_next_device(dev);
+	yak_ch_t *c = yak_ch_init(h->k, h->pre, 0, 0);
+	if (c && yk_ctx_load(shard_ctx(c), caps.data(), sizes.data(), keys.data()) != 0) { yak_ch_destroy(c); c = 0; }
+	return c;
 }
+
+/* reference htab.c:287-316 / 318-347: keep the k-mers of h0 that are absent from (which = 1) / present in (2) h1 */
+static void keep_by_membership(yak_ch_t *h0, const yak_ch_t *h1, int which, const char *fn_name)
+{
+	if (h0->k != h1->k || h0->pre != h1->pre) { fprintf(stderr, "[E::%s] tables of different k / prefix length\n", fn_name); return; }
+	std::map<int, yak_ch_t*> copy_on;                             /* device -> unsharded copy of h1 made for it */
+	bool ok = true;
+	for (yak_ch_t *s0 : shards_of(h0)) {
+		yakamd_ctx *c0 = shard_ctx(s0);
+		const int dev = yk_ctx_device(c0);
+		const yak_ch_t *other = h1;
+		if (YK_MULTI((const yak_ch_ext*)h1) || yk_ctx_device(shard_ctx((yak_ch_t*)h1)) != dev) {
+			if (!copy_on.count(dev)) copy_on[dev] = unsharded_copy(h1, dev);
+			other = copy_on[dev];
+			if (!other) { ok = false; break; }
+		}
+		unsigned long long tot = 0;
+		if ((which == 1 ? yk_ctx_subtract(c0, shard_ctx((yak_ch_t*)other), &tot) : yk_ctx_isec(c0, shard_ctx((yak_ch_t*)other), &tot)) != 0) { ok = false; break; }
+		s0->tot = tot;
+	}
+	for (auto &kv : copy_on) if (kv.second) yak_ch_destroy(kv.second);
+	set_tot(h0);
+	if (!ok) fprintf(stderr, "[E::%s] %s\n", fn_name, *yakamd_last_error() ? yakamd_last_error() : "the second table could not be brought to the device of the first");
+}
+
+void yak_ch_subtract(yak_ch_t *h0, const yak_ch_t *h1, int n_thread) { (void)n_thread; keep_by_membership(h0, h1, 1, __func__); }
+void yak_ch_isec(yak_ch_t *h0, const yak_ch_t *h1, int n_thread) { (void)n_thread; keep_by_membership(h0, h1, 2, __func__); }
 
 /* reference htab.c:246-285: every k-mer of h1 with min <= count <= max is put into h0 (its count in
  * h0 goes up by one, saturating; new k-mers start at 1), sub-table by sub-table in h1's slot order;
- * h1 is destroyed.  One counting pass on the device: the list positions are the stream times. */
+ * h1 is destroyed.  One counting pass per shard of h0: the list positions are the stream times; a shard of
+ * h0 takes the lists of the shards of h1 one after the other (the feed keeps the k-mers of its own prefix range). */
 void yak_ch_merge(yak_ch_t *h0, yak_ch_t *h1, int min, int max, int n_thread, int pre_resize)
 {
 	(void)n_thread;
-	if (multi_refuse(h0, __func__) || multi_refuse(h1, __func__)) return;
-	yakamd_ctx *c0 = ((yak_ch_ext*)h0)->ctx, *c1 = ((yak_ch_ext*)h1)->ctx;
 	const int hi = (max >= min && max <= YAK_MAX_COUNT) ? max : YAK_MAX_COUNT;
-	u64 *d_hash = 0, n = 0; u32 *d_t = 0;
-	int ok = h0->k == h1->k && h0->pre == h1->pre;
-	if (ok && pre_resize) ok = yk_ctx_merge_presize(c0, c1) == 0;
-	ok = ok && yk_ctx_list_hashes(c1, min, hi, &d_hash, &d_t, &n) == 0;
-	if (ok) {
+	bool ok = h0->k == h1->k && h0->pre == h1->pre;
+	if (!ok) fprintf(stderr, "[E::yak_ch_merge] tables of different k / prefix length\n");
+	for (yak_ch_t *s0 : shards_of(h0)) {
+		if (!ok) break;
+		yakamd_ctx *c0 = shard_ctx(s0);
+		int lo0, hi0;
+		yk_ctx_range(c0, &lo0, &hi0);
+		std::vector<yak_ch_t*> from;
+		for (yak_ch_t *s1 : shards_of(h1)) { int lo1, hi1; yk_ctx_range(shard_ctx(s1), &lo1, &hi1); if (std::max(lo0, lo1) < std::min(hi0, hi1)) from.push_back(s1); }
+		if (pre_resize) for (yak_ch_t *s1 : from) ok = ok && yk_ctx_merge_presize(c0, shard_ctx(s1)) == 0;
+		if (!ok) break;
 		yk_ctx_gate(c0, false);
-		ok = yakamd_pass_begin(h0, 1) == 0;
-		if (ok && n) ok = yakamd_feed_hashed_dev(h0, d_hash, d_t, (int64_t)n, 0, n) == 0;
-		if (ok) ok = yakamd_pass_end(h0) >= 0;
+		ok = yakamd_pass_begin(s0, 1) == 0;
+		uint64_t t0 = 0;
+		for (yak_ch_t *s1 : from) {
+			u64 *d_hash = 0, n = 0; u32 *d_t = 0;
+			ok = ok && hipSetDevice(yk_ctx_device(shard_ctx(s1))) == hipSuccess && yk_ctx_list_hashes(shard_ctx(s1), min, hi, &d_hash, &d_t, &n) == 0;
+			if (ok && n) ok = yakamd_feed_hashed_dev(s0, d_hash, d_t, (int64_t)n, t0, n) == 0;   /* (a list on another device is read through peer access) */
+			t0 += n;
+			yk_pool_release(d_hash); yk_pool_release(d_t);
+		}
+		if (yakamd_pass_end(s0) < 0) ok = false;                 /* closes the pass whatever the feeds did */
 		yk_ctx_gate(c0, true);
+		if (ok) s0->tot = yk_ctx_keys_total(c0);                /* htab.c:284: tot = sum of the sub-table sizes */
 	}
-	yk_pool_release(d_hash); yk_pool_release(d_t);
-	if (ok) h0->tot = yk_ctx_keys_total(c0);                /* htab.c:284: tot = sum of the sub-table sizes */
-	else fprintf(stderr, "[E::yak_ch_merge] %s\n", yakamd_last_error());
-	yak_ch_destroy(h1);
+	set_tot(h0);
+	if (!ok) fprintf(stderr, "[E::yak_ch_merge] %s\n", yakamd_last_error());
+	yak_ch_destroy(h1);                                          /* htab.c:283: h1 is consumed whatever happened */
 }
 
 void yak_ch_hist(const yak_ch_t *h, int64_t cnt[YAK_N_COUNTS], int n_thread) /* reference htab.c:156-169 */
@@ -464,6 +538,7 @@ yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...)
 	 * bits of their list position (4 bits for a flag, 10 for a count), run in as many passes as the 32-bit
 	 * position field needs: a pass meets the keys of the earlier ones as existing state, exactly as the
 	 * reference's sequential puts do. */
+	if (ch0 && multi_refuse(ch0, __func__)) return 0;           /* a load into a table sharded over prefix ranges: not carried out shard by shard (yet) */
 	yak_ch_t *h = ch0 ? ch0 : yak_ch_init((int)hdr[0], (int)hdr[1], 0, 0);
 	if (h == 0) return 0;
 	assert((int)hdr[0] == h->k && (int)hdr[1] == h->pre);       /* htab.c:437 */
@@ -535,18 +610,23 @@ extern "C++" {
 struct ByteSource {
 	struct Blk { int64_t foff, uoff; uint32_t csize, usize; };   /* offset of the deflate payload, offset in the uncompressed stream, bytes of both */
 	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
-	ByteSource() : fd(-1), size(0), bgzf(false) {}
-	typedef void *(*ld_alloc_t)(void); typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*);
-	static void ld_api(ld_alloc_t *al, ld_dec_t *de) {
-		static ld_alloc_t a = 0; static ld_dec_t d = 0; static bool tried = false;
+	uint64_t gen;                                                 /* identity of this source for the per-thread block cache (an address can be reused by the next job's source) */
+	static uint64_t next_gen() { static uint64_t g = 0; return __atomic_add_fetch(&g, 1, __ATOMIC_RELAXED); }
+	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()) {}
+	typedef void *(*ld_alloc_t)(void); typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*); typedef void (*ld_free_t)(void*);
+	static void ld_api(ld_alloc_t *al, ld_dec_t *de, ld_free_t *fr = 0) {
+		static ld_alloc_t a = 0; static ld_dec_t d = 0; static ld_free_t f = 0; static bool tried = false;
 		if (!tried) {                                              /* benign race: every thread resolves the same pointers */
 			void *l = getenv("YAKAMD_NO_LIBDEFLATE") ? 0 : dlopen("libdeflate.so.0", RTLD_NOW);
-			if (l) { a = (ld_alloc_t)dlsym(l, "libdeflate_alloc_decompressor"); d = (ld_dec_t)dlsym(l, "libdeflate_deflate_decompress"); }
-			if (!a || !d) { a = 0; d = 0; }
+			if (l) { a = (ld_alloc_t)dlsym(l, "libdeflate_alloc_decompressor"); d = (ld_dec_t)dlsym(l, "libdeflate_deflate_decompress"); f = (ld_free_t)dlsym(l, "libdeflate_free_decompressor"); }
+			if (!a || !d) { a = 0; d = 0; f = 0; }
 			tried = true;
 		}
-		*al = a; *de = d;
+		*al = a; *de = d; if (fr) *fr = f;
 	}
+	/* per-thread inflate state, released when the thread ends (the parser starts fresh threads for every window) */
+	struct LdState { void *dec; ld_free_t fr; LdState() : dec(0), fr(0) {} ~LdState() { if (dec && fr) fr(dec); } };
+	struct ZState { z_stream zs; bool init; ZState() : init(false) { memset(&zs, 0, sizeof(zs)); } ~ZState() { if (init) inflateEnd(&zs); } };
 	/* index the members of an open file; false if it is not BGZF from the first byte to the last */
 	bool index_bgzf(int f) {
 		struct stat sb;
@@ -579,13 +659,14 @@ struct ByteSource {
 		ld_alloc_t al; ld_dec_t de; ld_api(&al, &de);
 		bool ok = false;
 		if (al) {
-			static thread_local void *dec = 0;
-			if (!dec) dec = al();
+			static thread_local LdState st;
+			if (!st.dec) { st.dec = al(); ld_free_t fr = 0; ld_api(&al, &de, &fr); st.fr = fr; }
 			size_t n = 0;
-			ok = dec && de(dec, cbuf.data(), b.csize, out, b.usize, &n) == 0 && n == b.usize;
+			ok = st.dec && de(st.dec, cbuf.data(), b.csize, out, b.usize, &n) == 0 && n == b.usize;
 		} else {
-			static thread_local z_stream zs; static thread_local bool init = false;
-			if (!init) { memset(&zs, 0, sizeof(zs)); if (inflateInit2(&zs, -15) != Z_OK) return false; init = true; } else inflateReset(&zs);
+			static thread_local ZState st;
+			z_stream &zs = st.zs;
+			if (!st.init) { if (inflateInit2(&zs, -15) != Z_OK) return false; st.init = true; } else inflateReset(&zs);
 			zs.next_in = cbuf.data(); zs.avail_in = b.csize; zs.next_out = out; zs.avail_out = b.usize;
 			ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
 		}
@@ -599,16 +680,16 @@ struct ByteSource {
 		if (!bgzf) return ::pread(fd, dst, n, off);
 		if (off >= size || n == 0) return 0;
 		static thread_local std::vector<unsigned char> ub, cb;
-		static thread_local const ByteSource *who = 0; static thread_local size_t which = (size_t)-1;
+		static thread_local uint64_t who = 0; static thread_local size_t which = (size_t)-1;
 		size_t lo = 0, hi = blk.size();                            /* the block that holds `off` */
 		while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (blk[mid].uoff <= off) lo = mid; else hi = mid; }
 		size_t done = 0;
 		for (size_t bi = lo; bi < blk.size() && done < n; ++bi) {
 			const Blk &b = blk[bi];
-			if (who != this || which != bi) {
+			if (who != gen || which != bi) {
 				ub.resize(65536);
 				if (!inflate_block(b, ub.data(), cb)) { who = 0; return -1; }
-				who = this; which = bi;
+				who = gen; which = bi;
 			}
 			const size_t skip = (size_t)(off + (int64_t)done - b.uoff), take = std::min<size_t>(b.usize - skip, n - done);
 			memcpy((char*)dst + done, ub.data() + skip, take);
@@ -1049,7 +1130,8 @@ static void multi_close(MultiJob *J)
 /* one round: chunk r (fill[r] bytes, stream offset t0[r]) sits on GPU r.  Partition, exchange, feed. */
 static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
 {
-	const bool tagged = create_new && yakamd_tagged_ok(k, pre) && e->sub[0] && yakamd_pass_fast(e->sub[0]) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange */
+	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
+	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
 	const int N = J->N, P = J->P, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
 	std::vector<std::vector<uint64_t> > bst(N, std::vector<uint64_t>(P + 1, 0));
 	std::vector<int64_t> n_rec(N, 0);
@@ -1136,7 +1218,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 			ok = e->sub[r] && yakamd_set_shard(e->sub[r], r * (P / N), (r + 1) * (P / N)) == 0;
 		}
 		if (!ok) { for (int r = 0; r < N; ++r) if (e->sub[r]) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); fx.close_file(); return 0; }
-		e->ctx = ((yak_ch_ext*)e->sub[0])->ctx;
+		e->ctx = 0;                                               /* no context of its own: every yakamd_* entry point refuses a sharded table instead of working on one shard */
 		h->n_hash = e->sub[0]->n_hash; h->n_shift = e->sub[0]->n_shift;
 		for (int p = 0; p < P; ++p) h->h[p].b = e->sub[0]->h[p].b;   /* descriptors only: "has a filter" for callers that look */
 	}
@@ -1160,17 +1242,23 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		n_seq_tot += ns;
 		while (n > 0 && ok) {
 			const size_t room = (size_t)(J.chunk - fill[g]);
-			size_t m = n;
+			size_t m = n, back = 0;
 			if (n > room) {
 				const void *nl = room ? memrchr(img, '\n', room) : 0;
 				if (nl) m = (size_t)((const char*)nl - img) + 1;
 				else if (fill[g] > 0) { if (++g == N) round(); continue; }
-				else { fprintf(stderr, "[E::yak_count] a sequence is longer than YAKAMD_MGPU_CHUNK = %lld bytes: raise it\n", (long long)J.chunk); ok = false; break; }
+				else {
+					/* one sequence longer than a whole chunk (a chromosome beyond YAKAMD_MGPU_CHUNK bases): the chunk ends inside it and the
+					 * next one starts k - 1 bases earlier -- the k-mers that end in this chunk are counted here, those that end behind it
+					 * there (a chunk's first k - 1 positions complete no k-mer), and stream positions simply continue */
+					m = room; back = (size_t)opt->k - 1;
+				}
 			}
 			if (fill[g] == 0) t0[g] = t_stream;
 			hipSetDevice(J.dev[g]);
 			ok = hipMemcpyAsync(J.d_base[g] + fill[g], img, m, hipMemcpyHostToDevice, J.st[g]) == hipSuccess && hipStreamSynchronize(J.st[g]) == hipSuccess;
-			fill[g] += (int64_t)m; t_stream += m; img += m; n -= m;
+			fill[g] += (int64_t)m;
+			t_stream += m - back; img += m - back; n -= m - back;
 			if (fill[g] == J.chunk || n > 0) { if (++g == N) round(); }
 		}
 		return ok;
@@ -1361,6 +1449,7 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 	memset(cnt, 0, n_cnt * sizeof(int64_t));
 	yak_ch_t *h = (yak_ch_t*)ch;
 	if (ch->k >= 32) { fprintf(stderr, "[E::yak_qv] k must be below 32\n"); return; }   /* qv.c:44 asserts */
+	if (multi_refuse(ch, __func__)) return;                      /* the lookup kernel reads one table image: restore the .yak file for qv */
 	FxReader fx;
 	if (!fx.open_file(fn)) return;
 	uint64_t *d_hist = (uint64_t*)yakamd_dev_alloc(n_cnt * 8);
