@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--job-md5", action="store_true", help="also report the md5 of the whole job's .yak bytes (sub-tables gathered from all ranks)")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--no-packed", action="store_true", help="skip the packed-image (0.375 B/base) side measurement")
+    ap.add_argument("--no-retain", action="store_true", help="pass 2 extracts and hashes the input again instead of counting the records pass 1 retained")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
     maybe_spawn(a)
@@ -248,7 +249,7 @@ def main():
             if packed[0] is not None:
                 t.count_pass_packed(create_new, [(packed[0][0].data_ptr(), packed[0][1].data_ptr(), n_bytes, 0)])
             else:
-                t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)])
+                t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)], same_input=not a.no_retain)
             return
         if L.yakamd_pass_begin(t.h, create_new) != 0:
             raise RuntimeError("pass_begin")
@@ -293,6 +294,8 @@ def main():
         t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
         if sharded:
             L.yakamd_set_shard(t.h, lo, hi)
+        elif a.bf_shift > 0 and not a.no_retain:
+            L.yakamd_retain_input(t.h, 1)           # pass 2 reads the same input (main.c:57): its hashed k-mers stay on the device
         tp = tick("init", tp)
         one_pass(t, 1)
         tp = tick("pass1", tp)

@@ -96,6 +96,18 @@ int yakamd_count_partitioned_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n,
 /* create_new = 0 pass on bare yak_hash64 values (any order): count the ones present in the table */
 int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int64_t n);
 
+/* The second pass of the filtered protocol reads the SAME input as the first (reference main.c:53-57: `yak count -b`
+ * with one file).  yakamd_retain_input(h, 1) before the create_new = 1 pass keeps that pass's hashed, prefix-grouped
+ * k-mers (8-byte tagged records) in device memory -- all of them or, beyond an eighth of the device memory
+ * (YAKAMD_RETAIN_GB), none; inside the following create_new = 0 pass yakamd_count_retained(h) counts them instead of
+ * a feed: 0 = every instance counted (nothing else must be fed), 1 = nothing usable was kept: feed the input as
+ * usual, < 0 = error.  The records are released by the count, by the end of any count pass, by the next create_new
+ * pass and by yakamd_retain_input(h, 0).  The caller vouches that both passes see the same input; yak_count() does it
+ * by itself when the second call names the file of the first (same device, inode, size and modification time). */
+int yakamd_retain_input(yak_ch_t *h, int on);
+int yakamd_count_retained(yak_ch_t *h);
+int64_t yakamd_retained_instances(yak_ch_t *h);
+
 /* Lookup-only path (`yak qv`, reference qv.c:34-86, k < 32).  yakamd_lookup_dev(): d_out_u16[i] =
  * max(0, yak_ch_get()) of the canonical k-mer ENDING at byte i of the base image, 0xffff where no
  * k-mer ends (window shorter than k or holding a non-ACGT byte).  yakamd_qv_reduce_dev(): sequence j

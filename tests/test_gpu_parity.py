@@ -141,6 +141,54 @@ def test_cli_drop_in(ya, oracle, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BATCH="65536"), dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_COUNT_OWN="0")],
+                         ids=["one_batch", "many_batches", "budget_refuses", "count_kernel_not_applicable"])
+@pytest.mark.parametrize("opt", [dict(k=31, bf_shift=24), dict(k=21, bf_shift=20), dict(k=31, bf_shift=22, n_hash=7)], ids=["k31b24", "k21b20", "k31b22H7"])
+def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch):
+    """main.c:53-57: both passes read the same input.  With yakamd_retain_input the create_new pass keeps its hashed k-mers on the
+    device and the count pass counts those (yakamd_count_retained) -- or reports that nothing usable was kept and takes the input
+    again; either way the bytes are the oracle's, and the retained path must really have been taken where it applies"""
+    L = ya.lib()
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    img = synth(9000, g=40000, s=19)
+    want, wtot = oracle.count_protocol_mem(img, **opt)
+    d = L.yakamd_dev_alloc(len(img) + 64)
+    assert L.yakamd_memcpy_h2d(d, img, len(img)) == 0
+    t = ya.Table(opt["k"], 10, opt.get("n_hash", 4), opt["bf_shift"])
+    assert L.yakamd_retain_input(t.h, 1) == 0
+    t.count_pass(1, [(d, len(img), 0)])
+    kept = L.yakamd_retained_instances(t.h)
+    assert (kept > 0) == (env.get("YAKAMD_RETAIN_GB") != "0")
+    t.destroy_bf(); t.clear()
+    assert L.yakamd_pass_begin(t.h, 0) == 0
+    r = L.yakamd_count_retained(t.h)
+    assert r == (0 if kept and "YAKAMD_COUNT_OWN" not in env else 1)
+    if r:
+        assert L.yakamd_feed_bases_dev(t.h, d, len(img), 0) == 0
+    n_ins = L.yakamd_pass_end(t.h)
+    assert n_ins == 0 and L.yakamd_retained_instances(t.h) == 0
+    t.shrink(2, 1023)
+    assert t.dump_bytes() == want and t.tot == wtot
+    t.close()
+    L.yakamd_dev_free(d)
+
+
+def test_yak_count_reuses_the_first_pass_when_the_second_names_the_same_file(ya, oracle, tmp_path):
+    """yak_count(fn, opt, NULL) of a filtered count keeps the k-mers; yak_count(fn, opt, h) on the SAME file counts them without
+    reading it again (the log line says so); another file, a changed file or YAKAMD_NO_RETAIN take the ordinary path.  Same bytes"""
+    fq, fq2 = str(tmp_path / "r.fq"), str(tmp_path / "r2.fq")
+    yam, yko, syn = (os.path.join(ROOT, *p_) for p_ in (("yak_amd", "yak-amd"), ("oracle", "yko"), ("tools", "yaksynth")))
+    subprocess.check_call([syn, "-n", "8000", "-g", "40000", "-s", "8", "-o", fq])
+    subprocess.check_call([syn, "-n", "5000", "-g", "40000", "-s", "8", "-o", fq2])
+    a, b = str(tmp_path / "a.yak"), str(tmp_path / "b.yak")
+    for files, env, reused in (([fq], {}, True), ([fq, fq2], {}, False), ([fq], {"YAKAMD_NO_RETAIN": "1"}, False), ([fq, fq], {}, True)):
+        r = subprocess.run([yam, "count", "-k31", "-b24", "-o", a] + files, check=True, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        subprocess.run([yko, "count", "-k31", "-b24", "-o", b] + files, check=True, stderr=subprocess.DEVNULL)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        assert (b"kept on the device" in r.stderr) == reused
+
+
 @pytest.mark.parametrize("bf", [0, 23])
 def test_partitioned_exchange_path_on_one_gpu(bf, ya, oracle, synth):
     """same with the production exchange format: yakamd_partition_dev once per source, the owner

@@ -32,6 +32,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
     "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
+    "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances",
 ]
 
 
@@ -149,6 +150,9 @@ def lib():
     L.yak_qopt_init.argtypes = [P(QoptT)]
     L.yak_qv.restype = None; L.yak_qv.argtypes = [P(QoptT), C.c_char_p, P(ChT), P(C.c_int64)]
     L.yakamd_lookup_dev.restype = C.c_int; L.yakamd_lookup_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_void_p]
+    L.yakamd_retain_input.restype = C.c_int; L.yakamd_retain_input.argtypes = [P(ChT), C.c_int]
+    L.yakamd_count_retained.restype = C.c_int; L.yakamd_count_retained.argtypes = [P(ChT)]
+    L.yakamd_retained_instances.restype = C.c_int64; L.yakamd_retained_instances.argtypes = [P(ChT)]
     L.yakamd_qv_reduce_dev.restype = C.c_int
     L.yakamd_qv_reduce_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
@@ -174,11 +178,15 @@ class Table:
             raise RuntimeError("yak_ch_init failed: " + _err())
 
     # -- reference protocol pieces ---------------------------------------------------------
-    def count_pass(self, create_new, feeds):
-        """one pass: feeds = iterable of (device_ptr, n_bytes, t0)"""
+    def count_pass(self, create_new, feeds, same_input=False):
+        """one pass: feeds = iterable of (device_ptr, n_bytes, t0).  same_input (create_new = 0 only): the feeds are the ones of
+        the create_new pass before -- the records that pass retained (yakamd_retain_input) are counted instead, if there are any"""
         if self.L.yakamd_pass_begin(self.h, create_new) != 0:
             raise RuntimeError(_err())
-        for ptr, n, t0 in feeds:
+        r = self.L.yakamd_count_retained(self.h) if (same_input and not create_new) else 1
+        if r < 0:
+            raise RuntimeError(_err())
+        for ptr, n, t0 in (feeds if r else ()):
             if self.L.yakamd_feed_bases_dev(self.h, ptr, n, t0) != 0:
                 raise RuntimeError(_err())
         n_ins = self.L.yakamd_pass_end(self.h)

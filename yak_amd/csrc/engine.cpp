@@ -215,6 +215,12 @@ struct yakamd_ctx {
 	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
 	yakamd_stats_t st_cur, st_last;
 
+	/* level-1 records of the last create_new pass, kept for a count pass over the SAME input (yakamd_retain_input / yakamd_count_retained):
+	 * the second pass of the bloom protocol (reference main.c:53-57) then neither reads nor hashes the input again */
+	struct Retained { u64 *d_rec; u64 n; std::vector<u64> bstart; };
+	std::vector<Retained> retained; bool retain_on, retain_broken; u64 retained_bytes;
+	u64 src_id[5]; bool src_set;       /* identity of the file the retained records came from + its sequence count (yak_count) */
+
 	std::mutex api_mu;                 /* serialises whole-table entry points that callers may reach from several threads (yak_ch_insert_list) */
 	void *d_scratch; size_t scratch_bytes;
 
@@ -293,6 +299,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	if (c->nb_bits > 13) c->nb_bits = 13;
 	c->fast = false; c->kept_bytes = 0; c->fast_budget = 0; c->t_pass0 = 0; c->t_pass0_set = false;
 	c->host_valid = false; c->hm_keys = 0; c->hm_used = 0; c->hm_slots = 0; c->hts = 0;
+	c->retain_on = false; c->retain_broken = false; c->retained_bytes = 0; c->src_set = false;
 	c->dev = (int)env_i64("YAKAMD_DEVICE", 0);
 	{
 		const char *lr = getenv("LOCAL_RANK");
@@ -321,6 +328,12 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	return c;
 }
 
+static void retained_drop(yakamd_ctx *c)
+{
+	for (auto &r : c->retained) dfree(r.d_rec);
+	c->retained.clear(); c->retained_bytes = 0; c->src_set = false;
+}
+
 static void pass_free(yakamd_ctx *c)
 {
 	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
@@ -336,6 +349,7 @@ void yk_ctx_destroy(yakamd_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->dev);
 	pass_free(c);
+	retained_drop(c);
 	dfree(c->d_stage); dfree(c->d_rows); dfree(c->d_partial); dfree(c->d_bstart);
 	{ uint8_t *q = (uint8_t*)c->d_scratch; dfree(q); c->d_scratch = 0; }
 	dfree(c->d_bits); dfree(c->d_used); dfree(c->d_delta); dfree(c->d_off); dfree(c->d_keys);
@@ -404,6 +418,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipSetDevice(c->dev));
 	(void)hipGetLastError();                                   /* whatever other users of the runtime left behind is not this pass's (see yakamd_pass_end) */
 	c->create_new = create_new;
+	if (create_new) { retained_drop(c); c->retain_broken = false; }
 	c->bloom_mode = create_new && c->has_bloom && !c->gate_off;
 	c->in_pass = true;
 	c->t_end = 0;
@@ -722,6 +737,7 @@ static int fast_abandon(yakamd_ctx *c)
 {
 	for (auto &k : c->kept) if (k.fmt) return fail("a batch was fed out of stream order after tagged 8-byte batches were kept: feed in order, or set YAKAMD_REC8=0");
 	c->fast = false;
+	c->retain_broken = true; retained_drop(c);                 /* the pass leaves the path whose records can be kept */
 	Rec *keep = c->d_rec;
 	int r = 0;
 	for (auto &k : c->kept) {
@@ -983,6 +999,64 @@ extern "C" int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int6
 	c->st_cur.n_instances += n;
 	c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
 	return 0;
+}
+
+/* ---- the count pass over the input of the pass before (reference main.c:53-57: both passes read the same file) ---- */
+extern "C" int yakamd_retain_input(yak_ch_t *h, int on)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c) return fail("not an engine table");
+	if (c->in_pass) return fail("yakamd_retain_input inside a pass");
+	HIPCK(hipSetDevice(c->dev));
+	c->retain_on = on != 0;
+	if (!on) retained_drop(c);
+	return 0;
+}
+
+extern "C" int64_t yakamd_retained_instances(yak_ch_t *h)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || c->retain_broken) return 0;
+	u64 n = 0;
+	for (auto &r : c->retained) n += r.n;
+	return (int64_t)n;
+}
+
+/* inside an open create_new = 0 pass: count every instance of the retained records (k_img_count_own reads the tagged level-1 records
+ * as they are).  0 = counted, the records are released; 1 = nothing usable was retained (the caller feeds the input again); -1 = error */
+extern "C" int yakamd_count_retained(yak_ch_t *h)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass || c->create_new) return fail("yakamd_count_retained needs an open create_new = 0 pass");
+	HIPCK(hipSetDevice(c->dev));
+	if (c->retained.empty() || c->retain_broken || env_i64("YAKAMD_RETAIN", 1) == 0) { retained_drop(c); return 1; }
+	{
+		int rl, rb; u32 km;
+		if (count_own_plan(c, &rl, &rb, &km) != 0) { retained_drop(c); return 1; }   /* tables beyond the key-owning count kernel: the general count path wants plain hashes */
+	}
+	const size_t NB = (size_t)1 << c->nb_bits;
+	if (part_reserve(c, 1)) return -1;
+	Rec *keep = c->d_rec;
+	int r = 0;
+	for (auto &b : c->retained) {
+		if (r) break;
+		if (hipMemcpyAsync(c->d_bstart, b.bstart.data(), (NB + 1) * 8, hipMemcpyHostToDevice, c->st) != hipSuccess) { r = fail("memcpy"); break; }
+		c->d_rec = (Rec*)b.d_rec;
+		r = consume_records(c, (int64_t)b.n, 0, 0, 0, c->d_bstart, 1, 2);
+		if (!r && hipStreamSynchronize(c->st) != hipSuccess) r = fail("count of the retained records failed");
+	}
+	c->d_rec = keep;
+	retained_drop(c);
+	return r ? -1 : 0;
+}
+
+/* yak_count(): the file whose records are retained (device, inode, size, mtime) and its sequence count, for the log line */
+void yk_ctx_set_source(yakamd_ctx *c, const uint64_t id[4], int64_t n_seq) { memcpy(c->src_id, id, 32); c->src_id[4] = (u64)n_seq; c->src_set = true; }
+bool yk_ctx_same_source(yakamd_ctx *c, const uint64_t id[4], int64_t *n_seq)
+{
+	if (!c->src_set || c->retained.empty() || c->retain_broken || memcmp(c->src_id, id, 32) != 0) return false;
+	*n_seq = (int64_t)c->src_id[4];
+	return true;
 }
 
 /* ---- lookup-only path (yak qv) ---- */
@@ -1466,7 +1540,21 @@ static int fast_finish(yakamd_ctx *c)
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 += c->ms_part2;
 	}
-	for (auto &k : c->kept) if (k.owned) dfree(k.d_rec);
+	{
+		/* the level-1 records stay for the count pass over the same input when the caller asked for that and they fit the budget
+		 * (an eighth of the device memory unless YAKAMD_RETAIN_GB says otherwise): all of the pass's records, or none */
+		size_t fr = 0, tot = 0;
+		const int64_t cap_gb = env_i64("YAKAMD_RETAIN_GB", -1);
+		u64 budget = cap_gb >= 0 ? (u64)cap_gb << 30 : 0;
+		if (cap_gb < 0 && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = tot / 8;
+		bool keep = c->retain_on && !c->retain_broken && fmt_in == 1 && c->bloom_mode && !c->or_mode && c->retained_bytes + n_total * 8 <= budget;
+		for (auto &k : c->kept) keep = keep && k.owned;
+		if (c->retain_on && !keep && !c->kept.empty()) { c->retain_broken = true; retained_drop(c); }
+		for (auto &k : c->kept) {
+			if (keep && k.n) { yakamd_ctx::Retained r; r.d_rec = (u64*)k.d_rec; r.n = k.n; r.bstart.swap(k.bstart); c->retained.push_back(std::move(r)); c->retained_bytes += k.n * 8; }
+			else if (k.owned) dfree(k.d_rec);
+		}
+	}
 	c->kept.clear(); c->kept_bytes = 0;
 	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
 	/* the keys a sub-bucket selects are written over the front of its own record range in lo.kc / lo.T */
@@ -1583,6 +1671,7 @@ static int64_t pass_end_body(yakamd_ctx *c)
 		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
 		c->host_valid = false;
+		retained_drop(c);                                        /* used or not: the next pass is another input's */
 	} else if (c->or_mode && !(c->fast && !c->acc.s)) {
 		pass_free(c);
 		return fail("flag-mode loads need the exclusive-ownership path (prefix length <= 13, input within the device budget)");

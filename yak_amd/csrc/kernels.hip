@@ -3839,7 +3839,7 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 	if (!fits) {                                                   /* cannot happen with the host's sizing rule short of a pathological table */
 		if (CROSS) return;
 		for (u64 i = lo + tid; i < hi; i += 1024) {
-			const u64 h = ytag ? (rec[W * i] >> img.pre) << img.pre | p : rec[W * i];
+			const u64 h = ytag == 2 ? (rec[W * i] >> YK_R8_TAG_BITS) << img.pre | p : ytag ? (rec[W * i] >> img.pre) << img.pre | p : rec[W * i];
 			if (rbp && ((u32)(h >> img.pre) * 2654435769u) >> rsel != r) continue;
 			const int64_t hit = img_find(img, h);
 			if (hit >= 0) atomicAdd(&img.delta[hit], 1u);
@@ -3906,10 +3906,12 @@ void k_img_count_own(const u64 *__restrict__ rec, const u64 *__restrict__ bstart
 #pragma unroll
 		for (int u = 0; u < OWN_U; ++u) {
 			const bool valid = i0 + (u64)u * 1024 + tid < hi;
-			if (rbp == 0) { if (valid) probe(hv[u]); continue; }
-			const bool match = valid && (ytag ? ((u32)hv[u] & ypm) >> ysh == r : ((u32)(hv[u] >> img.pre) * 2654435769u) >> rsel == r);
+			/* ytag == 2: tagged level-1 records of the pass before (yakamd_count_retained): hash >> pre above the 12 tag bits */
+			const u64 hq = ytag == 2 ? (hv[u] >> YK_R8_TAG_BITS) << img.pre : hv[u];
+			if (rbp == 0) { if (valid) probe(hq); continue; }
+			const bool match = valid && (ytag == 1 ? ((u32)hv[u] & ypm) >> ysh == r : ((u32)(hq >> img.pre) * 2654435769u) >> rsel == r);
 			const u64 mk = __ballot(match);
-			if (match) s_q[qn + __popcll(mk & lanemask_lt())] = hv[u];
+			if (match) s_q[qn + __popcll(mk & lanemask_lt())] = hq;
 			qn += (u32)__popcll(mk);
 			if (qn >= 64) { qn -= 64; probe(s_q[qn + lane]); }
 		}

@@ -1314,11 +1314,42 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 			return yak_count_multi(fn, opt, h0, N, dev);
 		}
 	}
+	/* the file's identity: the filtered protocol counts the same file twice (main.c:53-57); the first call then keeps its hashed k-mers on
+	 * the device (yakamd_retain_input) and the second counts those instead of parsing, copying and hashing the file again */
+	uint64_t sid[4] = { 0, 0, 0, 0 };
+	bool have_sid = false;
+	{
+		struct stat sb;
+		if (fn && strcmp(fn, "-") != 0 && stat(fn, &sb) == 0 && S_ISREG(sb.st_mode) && !getenv("YAKAMD_NO_RETAIN")) {
+			sid[0] = (uint64_t)sb.st_dev; sid[1] = (uint64_t)sb.st_ino; sid[2] = (uint64_t)sb.st_size;
+			sid[3] = (uint64_t)sb.st_mtim.tv_sec * 1000000000ull + (uint64_t)sb.st_mtim.tv_nsec;
+			have_sid = true;
+		}
+	}
+	bool pass_open = false;
+	if (h0) {
+		assert(h0->k == opt->k && h0->pre == opt->pre);         /* count.c:157 */
+		int64_t n_seq_kept = 0;
+		if (have_sid && yk_ctx_same_source(((yak_ch_ext*)h0)->ctx, sid, &n_seq_kept)) {
+			yk_realtime();
+			if (yakamd_pass_begin(h0, 0) != 0) return 0;
+			const int r = yakamd_count_retained(h0);
+			if (r < 0) { yakamd_pass_end(h0); return 0; }
+			if (r == 0) {
+				const int64_t n_ins = yakamd_pass_end(h0);
+				if (n_ins < 0) return 0;
+				h0->tot += (uint64_t)n_ins;
+				fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total (the k-mers of the first pass over this file, kept on the device); %ld distinct k-mers in the hash table\n", "yak_count",
+				        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_kept, (long)h0->tot);
+				return h0;
+			}
+			pass_open = true;                                     /* nothing usable was kept: the pass goes on with the file */
+		}
+	}
 	FxReader fx;
-	if (!fx.open_file(fn)) return 0;                         /* count.c:152 */
+	if (!fx.open_file(fn)) { if (pass_open) yakamd_pass_end(h0); return 0; }   /* count.c:152 */
 	yak_ch_t *h = h0;
 	const int create_new = h0 ? 0 : 1;
-	if (h0) assert(h0->k == opt->k && h0->pre == opt->pre);  /* count.c:157 */
 	yk_realtime();
 	/* a plain regular file is mapped and parsed by several threads; anything else (gzip, a pipe) streams through the reader */
 	const int n_thr = parse_threads(opt->n_thread);
@@ -1327,7 +1358,8 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	int ok = 0;
 	auto open_table = [&]() {                                /* a new table: runtime start-up, the filter's 2^bf_shift bits, the pass */
 		if (!h0) h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
-		ok = h != 0 && yakamd_pass_begin(h, create_new) == 0;
+		if (!h0 && h && have_sid && opt->bf_shift > opt->pre) yakamd_retain_input(h, 1);   /* a filtered count: a second pass over this file is to be expected */
+		ok = h != 0 && (pass_open || yakamd_pass_begin(h, create_new) == 0);
 	};
 	std::thread opener;                                      /* ... happen while the first window of the file is being parsed */
 	if (par_size >= 0 && !h0) opener = std::thread(open_table); else open_table();
@@ -1369,6 +1401,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	if (ok) {
 		const int64_t n_ins = yakamd_pass_end(h);
 		if (n_ins < 0) ok = 0; else h->tot += (uint64_t)n_ins;   /* count.c:138 */
+		if (ok && create_new && have_sid && yakamd_retained_instances(h) > 0) yk_ctx_set_source(((yak_ch_ext*)h)->ctx, sid, n_seq_tot);
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot);
