@@ -1322,10 +1322,16 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		if (any_d) {
 			yk_r2_dinit(d_tabs, da, P, bd, K0, K1, TAG, OCC, c->st);
 			lap("dinit", k, bd, &tl);
+			int n_dbl = 0;
+			for (int p = 0; p < P; ++p) n_dbl += acts[k * P + p].kind == 2;
+			int cur = 0;
 			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, Fc + 2 * P, d_fail, c->st);
 			lap("dsmall", k, bd, &tl);
+			/* the rounds from there on: one launch (k_r2_double: a workgroup per sub-table walks its rounds behind workgroup barriers) ... */
+			const bool fused = yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st) == 0;
+			if (fused) { cur = 1; lap("double (fused rounds)", k, bd, &tl); }
+			else {                                                   /* ... or a launch per round (YAKAMD_R2_FUSED=0) */
 			const u64 n = 1ull << bd, SF = (u64)yk_r2_small_f();
-			int cur = 0;
 			HIPCK(hipMemsetAsync(misc + 2, 0, 8, c->st));           /* the two long-run counters the rounds alternate between */
 			for (u64 reach = SF; reach < 2 * n; reach <<= 1) {       /* F at least doubles... it cannot: G <= 2F; so one round per factor of two, plus slack for short rounds */
 				const u64 span = std::min<u64>(n, 2 * reach);
@@ -1341,6 +1347,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 #ifdef R2_PROF
 			if (prof) yk_r2_prof_print();
 #endif
+			}
 			/* every doubling sub-table must have reached its end */
 			std::vector<u32> Fh(P);
 			HIPCK(hipMemcpyAsync(Fh.data(), Fc + cur * P, P * 4, hipMemcpyDeviceToHost, c->st));

@@ -2120,19 +2120,26 @@ __device__ __forceinline__ bool r2_run(u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u3
  * all precede its scan positions, and no chain continues inside it (its region starts at 2a >= b): first come first
  * served in sigma order is then ordered probing with priority = rank in sigma order, all keys at once.  DYN: the run
  * covers [F, 2F] and feeds its own slots (only below R2_SMALL_F): one lane walks it with the literal rule, on LDS. */
-struct R2Wave { u64 keys[R2_LMAX]; u32 sig[R2_LMAX]; u32 own[R2_RMAX]; unsigned short byrank[R2_LMAX], rk[R2_LMAX]; u32 mv[R2_LMAX / 32]; };
+template <u32 LM> struct R2WaveT {                     /* LM: longest run the buffers hold; its region + the shared wrap-around head */
+	static constexpr u32 LMAX = LM, RMAX = 2 * LM + 2 + 256;
+	u64 keys[LM]; u32 sig[LM]; u32 own[2 * LM + 2 + 256]; unsigned short byrank[LM], rk[LM]; u32 mv[LM / 32];
+};
+typedef R2WaveT<R2_LMAX> R2Wave;
+#define R2_MMAX 160u                                  /* "medium" runs: placed by the wave that met them, in the LDS of its chunk (k_r2_double) */
+typedef R2WaveT<R2_MMAX> R2WaveM;
 
 __device__ __forceinline__ void r2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-template <bool COH, bool DYN>
-__device__ void r2_wave_run(R2Wave &W, u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u32 nb, u32 *fail)
+template <bool COH, bool DYN, class WT>
+__device__ __forceinline__ void r2_wave_run(WT &W, u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u32 nb, u32 *fail)
 {
+	constexpr u32 R2_LMAX_ = WT::LMAX, R2_RMAX_ = WT::RMAX;
 	const u32 lane = threadIdx.x & 63, Nmask = 2 * n - 1;
 	u32 L = 0;
 	for (;;) {                                                              /* length of the run */
 		const u32 idx = a + L + lane;
 		const u64 m = __ballot(idx < n && S[idx] != YK_EMPTY);
-		if (m == ~0ull) { L += 64; if (L > R2_LMAX) break; continue; }
+		if (m == ~0ull) { L += 64; if (L > R2_LMAX_) break; continue; }
 		L += (u32)__ffsll((long long)~m) - 1;
 		break;
 	}
@@ -2143,7 +2150,7 @@ __device__ void r2_wave_run(R2Wave &W, u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u3
 		wrap = 2 * j0 + 2;
 	}
 	const u32 R = 2 * L + 2 + wrap;
-	if (L > R2_LMAX || R > R2_RMAX) { if (lane == 0) *fail = 6; return; }
+	if (L > R2_LMAX_ || R > R2_RMAX_) { if (lane == 0) *fail = 6; return; }
 	for (u32 i = lane; i < L; i += 64) {
 		const u32 sl = a + i;
 		const u64 k = S[sl];
@@ -2152,7 +2159,7 @@ __device__ void r2_wave_run(R2Wave &W, u64 *S, u64 *D, u32 *TG, u32 a, u32 n, u3
 		W.sig[i] = k == R2_MOVED ? R2_NONE : (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
 	}
 	for (u32 i = lane; i < R; i += 64) W.own[i] = D[(2 * a + i) & Nmask] != YK_EMPTY ? 0u : 0xffffffffu;
-	if (lane < R2_LMAX / 32) W.mv[lane] = 0;
+	if (lane < R2_LMAX_ / 32) W.mv[lane] = 0;
 	r2_wave_sync();
 	for (u32 i = lane; i < L; i += 64) {                                    /* rank in sigma order */
 		const u32 g = W.sig[i];
@@ -2362,24 +2369,29 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 __device__ u64 d_r2_prof[8];
 #endif
 __global__ __launch_bounds__(64)
-void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap)
+void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap,
+                 u32 nbx, int n_tab)
 {
 	__shared__ u64 s_key[R2_NA];                                             /* s_key[x] = old slot c0 - 1 + x */
 	__shared__ u32 s_tag[R2_NA];
 	__shared__ short s_le[R2_NA], s_ne[R2_NA];                               /* last unused slot at or before x (-1: none), next unused slot at or after x (R2_NA: none) */
 	__shared__ u64 s_win[R2_WN];                                             /* (time + 1) << 32 | x; 0 = taken before this round; ~0 = free */
 	__shared__ u32 s_oc[R2_WN / 32 + 2];
-	const u32 p = blockIdx.y, lane = threadIdx.x;
+	const u32 lane = threadIdx.x;
+	/* the launch is PERSISTENT: a few thousand one-wave workgroups walk the nbx x P (chunk group, sub-table) tasks of the round.  One workgroup per
+	 * task made the big rounds (65536 workgroups living ~10 us each) wait for the dispatcher: 11 % of the wave slots busy */
+	for (u32 vt = blockIdx.x; vt < nbx * (u32)n_tab; vt += gridDim.x) {
+	const u32 p = vt / nbx, bx = vt - p * nbx;
 	const R2Act A = acts[p];
-	if (A.kind != 2) return;
+	if (A.kind != 2) continue;
 	const u32 n = 1u << A.bits, nb = A.bits + 1, F = Fcur[p], G = Gcur[p];   /* the round's end was found by the round before (or k_r2_dsmall) */
-	if (F >= n) { if (blockIdx.x == 0 && lane == 0) { Fnext[p] = F; Gnext[p] = n; } return; }
+	if (F >= n) { if (bx == 0 && lane == 0) { Fnext[p] = F; Gnext[p] = n; } continue; }
 	const u64 off = tabs[p].off;
 	u64 *S = (A.src ? K1 : K0) + off, *D = (A.src ? K0 : K1) + off;
 	u32 *TG = TAG + (off >> 1);
 	const u32 *OC = OCC + (off >> 4);
-	if (G == 0) { if (blockIdx.x == 0 && lane == 0) { *fail = 3; Fnext[p] = n; Gnext[p] = n; } return; }
-	if (blockIdx.x == 0 && lane == 0) { Fnext[p] = G; Gnext[p] = G < n ? r2_boundary(S, G, 2 * G < n ? 2 * G : n, n) : n; }   /* used slots stay used (R2_MOVED): the next boundary can be looked up now */
+	if (G == 0) { if (bx == 0 && lane == 0) { *fail = 3; Fnext[p] = n; Gnext[p] = n; } continue; }
+	if (bx == 0 && lane == 0) { Fnext[p] = G; Gnext[p] = G < n ? r2_boundary(S, G, 2 * G < n ? 2 * G : n, n) : n; }   /* used slots stay used (R2_MOVED): the next boundary can be looked up now */
 	constexpr u32 PER = (R2_NA + 63) / 64, NOC = R2_WN / 32 + 2;
 	/* a workgroup (one wave) walks several chunks; the next chunk's keys, tags and OCC words travel while this one is placed */
 	u64 rk[PER]; u32 rt[PER], roc = 0;
@@ -2392,7 +2404,7 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 		}
 		roc = OC[((2 * c0) >> 5) + (lane < NOC ? lane : 0)];
 	};
-	u32 c0 = F + blockIdx.x * R2_CH;
+	u32 c0 = F + bx * R2_CH;
 #ifdef R2_PROF
 	u64 pf[6] = { 0, 0, 0, 0, 0, 0 }, tq = __builtin_readcyclecounter(), tq0 = tq;
 #define R2_LAP(i) { const u64 t_ = __builtin_readcyclecounter(); pf[i] += t_ - tq; tq = t_; }
@@ -2408,7 +2420,7 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 			if (x < R2_NA) { s_key[x] = sl < n ? rk[j] : YK_EMPTY; s_tag[x] = sl < n ? rt[j] : R2_NONE; }
 		}
 		if (lane < NOC) s_oc[lane] = roc;
-		const u32 c1 = c0 + gridDim.x * R2_CH;
+		const u32 c1 = c0 + nbx * R2_CH;
 		if (c1 < G) fetch(c1);
 		__syncthreads();
 		R2_LAP(0)
@@ -2479,6 +2491,7 @@ void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 #ifdef R2_PROF
 	if (lane == 0) { pf[4] = __builtin_readcyclecounter() - tq0; for (int i = 0; i < 5; ++i) atomicAdd(&d_r2_prof[i], pf[i]); atomicAdd(&d_r2_prof[5], 1ull); }
 #endif
+	}
 }
 
 /* the long runs of the round just launched, a wave each */
@@ -2495,6 +2508,195 @@ void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG,
 		r2_wave_run<false, false>(W, (A.src ? K1 : K0) + off, (A.src ? K0 : K1) + off, TAG + (off >> 1), a, 1u << A.bits, A.bits + 1, fail);
 		__syncthreads();
 	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The whole doubling of a sub-table in ONE launch, one workgroup per sub-table (k_r2_double).  Nothing leaves the workgroup, so the
+ * rounds [F, G) follow each other behind workgroup barriers instead of kernel boundaries (k_r2_dsmall + ~11 x (k_r2_dround + k_r2_long)
+ * took 25 launches per doubling, the big ones bound by the dispatcher, the small ones by launch latency).  Inside a round the waves
+ * take the chunks of F2_CH old slots in turn, each on LDS buffers of its own (wave-level synchronisation only): the chunk routine of
+ * k_r2_dround with a window for runs of up to F2_CHL slots; a longer run is placed by the wave that met it right after the chunk, in
+ * the same LDS (up to R2_MMAX slots), and the few beyond that by wave 0 at the end of the round (up to R2_LMAX).  The boundary of the
+ * next round is looked up by wave 0 while the others already place.
+ * ------------------------------------------------------------------------------------------ */
+#define F2_CH  128u
+#define F2_CHL 64u
+#define F2_CHX (F2_CHL + 8)
+#define F2_NA  (F2_CH + F2_CHX + 1)
+#define F2_WN  (2 * (F2_CH + F2_CHX) + 2)
+#define F2_NOC (F2_WN / 32 + 2)
+#define F2_LST 24u
+struct R2Chunk {
+	union {
+		struct { u64 key[F2_NA]; u64 win[F2_WN]; u32 tag[F2_NA]; short le[F2_NA + 1], ne[F2_NA + 1]; u32 oc[F2_NOC]; } c;
+		R2WaveM m;                                                             /* the same memory while a medium run is placed */
+	} u;
+	u32 lst[F2_LST]; u32 nlst, pad;                                            /* runs of this chunk left to the wave routine */
+};
+
+/* largest g in (F, x] such that old slot g - 1 is unused (g == n is always a boundary); 0 if there is none.  One wave, 64 slots per step */
+__device__ __forceinline__ u32 r2_boundary_wave(const u64 *S, u32 F, u32 x, u32 n)
+{
+	const u32 lane = threadIdx.x & 63;
+	if (x >= n) return n;
+	for (;;) {
+		const u32 g = x - lane;                                                /* candidates x, x - 1, ..., x - 63 */
+		const bool hit = x >= lane && g > F && S[g - 1] == YK_EMPTY;
+		const u64 m = __ballot(hit);
+		if (m) return x - ((u32)__ffsll((long long)m) - 1);
+		if (x < 64 + F + 1) return 0;
+		x -= 64;
+	}
+}
+
+/* the chunks c0 = F + F2_CH (wave + n_waves i) of the round [F, G) that belong to this wave */
+__device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, u32 *TG, const u32 *OC, const u32 F, const u32 G, const u32 n, const u32 nb,
+                              const u32 wave, const u32 n_waves, u32 *s_big, u32 *s_nbig, u32 *fail)
+{
+	const u32 lane = threadIdx.x & 63;
+	constexpr u32 PER = (F2_NA + 63) / 64;
+	u64 rk[PER]; u32 rt[PER], roc = 0;
+	auto fetch = [&](const u32 c0) {
+#pragma unroll
+		for (u32 j = 0; j < PER; ++j) {
+			const u32 sl = c0 - 1 + lane + 64 * j;                              /* c0 >= F >= 8 */
+			const u32 cl = sl < n ? sl : n - 1;
+			rk[j] = S[cl]; rt[j] = __hip_atomic_load(&TG[cl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		roc = OC[((2 * c0) >> 5) + (lane < F2_NOC ? lane : 0)];
+	};
+	u32 c0 = F + wave * F2_CH;
+	if (c0 < G) fetch(c0);
+	while (c0 < G) {
+		const u32 w0 = 2 * c0;
+#pragma unroll
+		for (u32 j = 0; j < PER; ++j) {
+			const u32 x = lane + 64 * j, sl = c0 - 1 + x;
+			if (x < F2_NA) { C.u.c.key[x] = sl < n ? rk[j] : YK_EMPTY; C.u.c.tag[x] = sl < n ? rt[j] : R2_NONE; }
+		}
+		if (lane < F2_NOC) C.u.c.oc[lane] = roc;
+		if (lane == 0) C.nlst = 0;
+		const u32 c1 = c0 + n_waves * F2_CH;
+		if (c1 < G) fetch(c1);
+		r2_wave_sync();
+		for (u32 i = lane; i < F2_WN; i += 64) {
+			const u32 q = w0 + i, b = (w0 & 31) + i;
+			C.u.c.win[i] = (q < 2 * n && (C.u.c.oc[b >> 5] >> (b & 31) & 1)) ? 0ull : ~0ull;
+		}
+		{	/* last / next unused slot: every lane owns PER consecutive entries, the lanes are linked by a shuffle scan */
+			const u32 x0 = lane * PER;
+			int le = -1, ne = (int)F2_NA;
+			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x < F2_NA && C.u.c.key[x] == YK_EMPTY) le = (int)x; }
+			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x < F2_NA && C.u.c.key[x] == YK_EMPTY) ne = (int)x; }
+			int lei = le, nei = ne;
+			for (int o = 1; o < 64; o <<= 1) {
+				const int t = __shfl_up(lei, o), u = __shfl_down(nei, o);
+				if ((int)lane >= o && t > lei) lei = t;
+				if ((int)lane + o < 64 && u < nei) nei = u;
+			}
+			int run_le = __shfl_up(lei, 1), run_ne = __shfl_down(nei, 1);
+			if (lane == 0) run_le = -1;
+			if (lane == 63) run_ne = (int)F2_NA;
+			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x >= F2_NA) break; if (C.u.c.key[x] == YK_EMPTY) run_le = (int)x; C.u.c.le[x] = (short)run_le; }
+			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x >= F2_NA) continue; if (C.u.c.key[x] == YK_EMPTY) run_ne = (int)x; C.u.c.ne[x] = (short)run_ne; }
+		}
+		r2_wave_sync();
+		const u32 lim = (G < c0 + F2_CH ? G : c0 + F2_CH) - c0;              /* runs start in [c0, c0 + lim) */
+		for (u32 x = lane + 1; x < F2_NA; x += 64) {
+			const u64 key = C.u.c.key[x];
+			if (key == YK_EMPTY) continue;
+			const int le = C.u.c.le[x], ne = C.u.c.ne[x];
+			if (le < 0 || (u32)le >= lim) continue;                             /* its run starts before / behind this chunk */
+			const u32 L = (u32)(ne - le - 1), a = c0 + (u32)le;
+			if (ne >= (int)F2_NA || L > F2_CHL || a + L >= n) {                 /* too long for the window, or it reaches the end of the table: the wave routine */
+				if ((int)x == le + 1) {
+					const u32 at = atomicAdd(&C.nlst, 1u);
+					if (at < F2_LST) C.lst[at] = a; else *fail = 8;
+				}
+				continue;
+			}
+			if (key == R2_MOVED) continue;
+			const u32 sl = c0 - 1 + x, t = C.u.c.tag[x];
+			const u32 sig = (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
+			u64 e = (u64)(sig + 1) << 32 | x;
+			u32 q = r2_home(key, nb) - w0;
+			for (;;) {
+				if (q >= F2_WN) { *fail = 9; break; }
+				const u64 old = atomicMin((unsigned long long*)&C.u.c.win[q], (unsigned long long)e);
+				if (old == ~0ull) break;
+				if (old > e) e = old;                                           /* we took the slot; carry the displaced later key on */
+				++q;
+			}
+		}
+		r2_wave_sync();
+		for (u32 i = lane; i < F2_WN; i += 64) {
+			const u64 e = C.u.c.win[i];
+			if (e == ~0ull || (e >> 32) == 0) continue;
+			const u32 q = w0 + i;
+			D[q] = C.u.c.key[(u32)e];
+			if (q < n) TG[q] = (u32)(e >> 32) - 1;
+		}
+		r2_wave_sync();
+		/* the runs this chunk left out: every run of a round is independent of the others, so they are placed now, in the chunk's own LDS */
+		const u32 nl = C.nlst < F2_LST ? C.nlst : F2_LST;
+		for (u32 j = 0; j < nl; ++j) {
+			const u32 a = C.lst[j];
+			u32 L = 0;
+			for (;;) {
+				const u32 idx = a + L + lane;
+				const u64 m = __ballot(idx < n && S[idx] != YK_EMPTY);
+				if (m == ~0ull) { L += 64; if (L > R2_MMAX) break; continue; }
+				L += (u32)__ffsll((long long)~m) - 1;
+				break;
+			}
+			if (L <= R2_MMAX) r2_wave_run<true, false>(C.u.m, (u64*)S, D, TG, a, n, nb, fail);
+			else if (lane == 0) { const u32 at = atomicAdd(s_nbig, 1u); if (at < 64) s_big[at] = a; else *fail = 8; }
+			r2_wave_sync();
+		}
+		c0 = c1;
+	}
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5)))      /* <= 96 VGPRs: four 5-wave workgroups per CU */
+void k_r2_double(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail)
+{
+	__shared__ union { R2Chunk ch[NW]; R2Wave big; } U;
+	__shared__ u32 s_big[64];
+	__shared__ u32 s_G, s_nbig;
+	const u32 p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const R2Act A = acts[p];
+	if (A.kind != 2) return;
+	const u64 off = tabs[p].off;
+	const u32 n = 1u << A.bits, nb = A.bits + 1;
+	u64 *S = (A.src ? K1 : K0) + off;
+	u64 *D = (A.src ? K0 : K1) + off;
+	u32 *TG = TAG + (off >> 1);
+	const u32 *OC = OCC + (off >> 4);
+	u32 F = Fin[p];                                                           /* k_r2_dsmall did the prefix and the rounds below small_f */
+	if (tid == 0) s_nbig = 0;
+	if (wave == 0 && F < n) { const u32 g = r2_boundary_wave(S, F, 2 * F < n ? 2 * F : n, n); if (lane == 0) s_G = g; }
+	__syncthreads();
+	while (F < n) {
+		const u32 G = s_G;
+		if (G == 0) { if (tid == 0) *fail = 3; break; }                       /* a run covers [F, 2F] beyond small_f: not handled here (uniform) */
+		__syncthreads();                                                       /* everybody has read s_G */
+		if (wave == 0 && G < n) { const u32 g = r2_boundary_wave(S, G, 2 * G < n ? 2 * G : n, n); if (lane == 0) s_G = g; }   /* used slots stay used: the next boundary can be looked up now */
+		r2_round_wave(U.ch[wave], S, D, TG, OC, F, G, n, nb, wave, NW, s_big, &s_nbig, fail);
+		__threadfence();
+		__syncthreads();
+		if (s_nbig) {                                                          /* (uniform) runs beyond R2_MMAX slots: wave 0, one after the other */
+			if (wave == 0) {
+				const u32 nbg = s_nbig < 64 ? s_nbig : 64;
+				for (u32 j = 0; j < nbg; ++j) { r2_wave_run<true, false>(U.big, S, D, TG, s_big[j], n, nb, fail); r2_wave_sync(); }
+				if (lane == 0) s_nbig = 0;
+			}
+			__threadfence();
+			__syncthreads();
+		}
+		F = G;
+	}
+	if (tid == 0) Fout[p] = F;
 }
 
 /* keys of a stage grouped by the segment of their home slot: pk/pr[rec_off + i0 + ...], seg_start[seg0 + s] relative to the stage's first key */
@@ -4331,8 +4533,23 @@ void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0
 	static const u32 cpw = getenv("YAKAMD_R2_CPW") ? (u32)std::max(1, atoi(getenv("YAKAMD_R2_CPW"))) : 4;   /* chunks per wave */
 	const u32 chunks = (span + R2_CH - 1) / R2_CH;                      /* `span` old slots per sub-table at most in this round */
 	const u32 blocks = (chunks + cpw - 1) / cpw;
-	hipLaunchKernelGGL(k_r2_dround, dim3(blocks < (1u << 20) ? blocks : 1u << 20, P), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, Gcur, Gnext, fail, long_list, long_n, long_cap);
+	static const u32 resident = getenv("YAKAMD_R2_WGS") ? (u32)std::max(1, atoi(getenv("YAKAMD_R2_WGS"))) : 256u * 24u;   /* one-wave workgroups that fit the device at once (5.5 KB of LDS, 64 VGPRs each) */
+	const u64 tasks = (u64)blocks * (u64)P;
+	hipLaunchKernelGGL(k_r2_dround, dim3((unsigned)std::min<u64>(tasks, resident)), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, Gcur, Gnext, fail, long_list, long_n, long_cap, blocks, P);
 	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_n_next, long_cap, fail);
+}
+/* the rounds of a doubling step from k_r2_dsmall's end (Fin) on in one launch (k_r2_double): n_dbl = sub-tables that double in this step.  0 = launched, 1 = switched off (YAKAMD_R2_FUSED=0) */
+int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail, hipStream_t st)
+{
+	static const int on = getenv("YAKAMD_R2_FUSED") ? atoi(getenv("YAKAMD_R2_FUSED")) : 1;
+	if (!on) return 1;
+	static const int force_nw = getenv("YAKAMD_R2_NW") ? atoi(getenv("YAKAMD_R2_NW")) : 0;
+	/* many sub-tables: 5 waves each, four workgroups per CU (all 1024 sub-tables of a default table resident at once); few, large ones (a shard of
+	 * a multi-GPU job): 16 waves each */
+	const int nw = force_nw ? force_nw : n_dbl <= 256 ? 16 : 5;
+	if (nw >= 16) hipLaunchKernelGGL(k_r2_double<16>, dim3(P), dim3(64 * 16), 0, st, tabs, acts, K0, K1, TAG, (const u32*)OCC, (const u32*)Fin, Fout, fail);
+	else hipLaunchKernelGGL(k_r2_double<5>, dim3(P), dim3(64 * 5), 0, st, tabs, acts, K0, K1, TAG, (const u32*)OCC, (const u32*)Fin, Fout, fail);
+	return 0;
 }
 #ifdef R2_PROF
 void yk_r2_prof_print(void)
