@@ -15,9 +15,11 @@ the long-contig k = 21 assembly; the lookup-only path of `yak qv`) with the same
 
 Prints ONE JSON line (rank 0).  `value` = distinct k-mers in the final table (h->tot, the number
 the reference logs) per second, whole job over all ranks; `kmer_instances_per_s` = k-mer windows
-consumed per second (both passes).  `roofline` is for the dominant kernel, timed with HIP events on
-the engine's own stream inside the library; `cpu_baseline` is the reference (oracle/_ref) or the
-oracle port timed on this host on a bounded sample.
+consumed per second (both passes).  `roofline` is the whole protocol step (SURVEY 8(d)'s algorithmic bytes of every
+instance over the step's wall-clock time; `roofline.traffic` the rocprofv3 counter bytes of the same step);
+`roofline.dominant_kernel` is the single kernel with the largest time, timed with HIP events on the engine's own
+stream inside the library (to be compared with profiles/*_kernel_stats.csv); `cpu_baseline` is the reference
+(oracle/_ref) or the oracle port timed on this host on a bounded sample.
 """
 import argparse
 import ctypes as C
@@ -149,6 +151,7 @@ def main():
     ap.add_argument("--job-md5", action="store_true", help="also report the md5 of the whole job's .yak bytes (sub-tables gathered from all ranks)")
     ap.add_argument("--no-qv", action="store_true", help="skip the lookup-kernel side measurement")
     ap.add_argument("--no-packed", action="store_true", help="skip the packed-image (0.375 B/base) side measurement")
+    ap.add_argument("--no-nofilter", action="store_true", help="skip the unfiltered-protocol side measurement (roofline.no_bloom_step_frac)")
     ap.add_argument("--no-retain", action="store_true", help="pass 2 extracts and hashes the input again instead of counting the records pass 1 retained")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
@@ -445,6 +448,28 @@ def main():
         t_q.close()
         del d_t16
 
+    # the unfiltered protocol on the same resident reads (main.c:53, one pass, singletons kept): its roofline fraction at SURVEY 8(d)'s
+    # 32 B per instance carries no bloom-block credit -- printed beside the default line, never `value`
+    nb_probe = None
+    if not a.no_nofilter and not sharded and a.bf_shift > 0:
+        def nofilter_step():
+            t_ = yak_amd.Table(K, PRE, N_HASH, 0)
+            t_.count_pass(1, [(d_reads.data_ptr(), n_bytes, 0)])
+            st_ = t_.stats()
+            tot_ = t_.tot
+            t_.close()
+            return tot_, st_
+        nofilter_step()
+        barrier()
+        tq = time.perf_counter()
+        for _ in range(2):
+            tot_nb, st_nb = nofilter_step()
+        barrier()
+        ms_nb = (time.perf_counter() - tq) / 2 * 1e3
+        nb_probe = {"ms_per_step": ms_nb, "distinct": tot_nb, "instances": st_nb["n_instances"], "bytes_per_instance": 32.0,
+                    "step_frac": 32.0 * st_nb["n_instances"] / (ms_nb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "phase_ms": {k: round(v, 3) for k, v in st_nb.items() if k.startswith("ms_")}}
+
     # the rate with the base image handed over from HOST memory in both passes (yakamd_feed_bases_host, what
     # yak_count() does after parsing) and the whole `yak-amd count` command on the same reads as a FASTQ file
     # (process start, parsing, PCIe, counting, writing the .yak) -- side figures, never `value`
@@ -516,9 +541,11 @@ def main():
     f_hit = (qv_probe["present"] / max(1, qv_probe["kmers_looked_up"])) if qv_probe else 0.9
     dev_batch = int(os.environ.get("YAKAMD_BATCH", 1 << 31))
     n_batches = -(-n_bytes // dev_batch)
+    p2_extracted = bool(s2) and s2["ms_extract"] > 0          # False: pass 2 counted the records pass 1 retained (no second extraction)
     kern = [
-        {"kernel": "k_xpart (extract + level-1 partition, both passes)", "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),
-         "launches": 2 * n_batches * (2 if s2 else 1), "bytes": 8.0 * (n1 + n2)},   # histogram + scatter per device batch
+        {"kernel": "k_xpart (extract + level-1 partition" + (", both passes)" if p2_extracted else ", pass 1; pass 2 reads its records)"),
+         "ms": s1["ms_extract"] - s1["ms_part2"] + (s2["ms_extract"] if s2 else 0),
+         "launches": 2 * n_batches * (2 if p2_extracted else 1), "bytes": 8.0 * (n1 + (n2 if p2_extracted else 0))},   # histogram + scatter per device batch
         {"kernel": "k_part2 (level-2 partition)", "ms": s1["ms_part2"], "launches": 2, "bytes": 8.0 * n1},
         {"kernel": "k_lc2 (insert + bloom gate)" if s1["ms_part2"] > 0 else "k_acc_insert", "ms": s1["ms_insert"],
          "launches": max(1, s1["n_dominant_launches"]), "bytes": b_insert * n1, "bytes_no_bloom_model": B_INSERT * n1},
@@ -537,16 +564,27 @@ def main():
         k_["frac"] = k_["achieved_GBs"] / HBM_PEAK_GBS
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    except Exception:
-        pass
+    pmc, pmc_src = {}, None
+    for cand_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", cand_)))
+            pmc_src = "profiles/" + cand_
+            break
+        except Exception:
+            pass
     for k_ in kern:
         keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
         cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift == 37 else []
         steps_pmc = max(1, pmc.get("k_lc2", {}).get("launches", 1))     # k_lc2 runs once per step: the steps of the profiled command
         k_["traffic_bytes"] = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
+        # how busy the HBM really is while this kernel (group) runs: counter bytes / its time / peak
+        k_["hbm_util"] = (k_["traffic_bytes"] / (k_["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (k_["traffic_bytes"] and k_["ms"] > 0) else None
+    default_cfg = a.reads == 10_000_000 and world == 1 and a.bf_shift == 37
+    step_traffic = None
+    if default_cfg and pmc:                                       # every kernel of one protocol step, whatever its name
+        steps_pmc = max(1, pmc.get("k_lc2", {}).get("launches", 1))
+        step_traffic = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"])
+                           for v in pmc.values() if isinstance(v, dict) and "launches" in v)
     # the pass and the step as a whole against the same roof: SURVEY 8(d)'s algorithmic bytes of every instance
     # the pass consumed / its wall-clock time (pass 1 with and without the exact-layout tail: sort + replay)
     bloom_on = a.bf_shift > PRE and s2 is not None
@@ -554,12 +592,12 @@ def main():
     b_pass2 = (16.0 + 8.0 + 8.0 * f_hit) * n2
     w = wall_timed
     ms_p1 = w.get("pass1", 0.0)
-    ms_p1_core = s1["ms_extract"] + s1["ms_insert"]
     frac = lambda by, ms: by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
+    b_step = b_pass1 + b_pass2
+    step_gbs = b_step / (ms_step * 1e-3) / 1e9 if world == 1 else None
     # the dominant KERNEL: the single kernel with the largest time (the extraction and replay rows are groups of several kernels)
     dom = max([k_ for k_ in kern if not k_["kernel"].startswith(("k_xpart", "k_r2_"))], key=lambda x: x["ms"])
     name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
-    bpi, st = dom["bytes"] / max(1, n1), s1
     out = {
         "metric": "distinct k-mers counted/sec (k=31), yak count -b37 two-pass protocol, .yak bit-exact",
         "value": tot_all / (dt / a.steps), "unit": "distinct k-mers/s",
@@ -577,24 +615,33 @@ def main():
         "phase_wall_ms_last_step": {k: round(v, 2) for k, v in wall_timed.items()},
         "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
         "bloom_exact_resolutions": s1["n_bloom_candidates"],
-        "roofline": {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS,
-                     "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
-                     "frac_of_peak_by_traffic": (dom["traffic_bytes"] / launches / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom.get("traffic_bytes") else None,
-                     "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)",
-                     "avg_launch_ms": avg_ms, "launches": launches,
-                     "algorithmic_bytes_per_launch": dom["bytes"] / launches,
-                     "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),
-                     "model": "SURVEY 8(d) per-instance bytes of the mode the workload runs in (bloom mode pass 1: 16 + 128 + 16 f_ins; "
-                              "insert kernel share 8 + 128 + 16 f_ins); achieved_no_bloom_model prices the same kernel at the "
-                              "no-bloom share of 24 B/instance",
-                     "achieved_no_bloom_model": (dom["bytes_no_bloom_model"] / (dom["ms"] * 1e-3) / 1e9) if dom.get("bytes_no_bloom_model") else None,
+        # the roofline line is the WHOLE protocol step: SURVEY 8(d)'s algorithmic bytes of every instance both passes consumed / the step's
+        # wall-clock time (every kernel and every host gap in the denominator).  The dominant kernel keeps its own entry for the rocprof cross-check
+        "roofline": {"bound": "hbm", "kernel": "whole protocol step (init, pass 1 incl. exact layout, clear, pass 2, shrink)",
+                     "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (step_gbs / HBM_PEAK_GBS) if step_gbs else None,
+                     "traffic": step_traffic,
+                     "hbm_util": (step_traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
+                     "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summed over the kernels of one step; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)") if step_traffic else None,
+                     "algorithmic_bytes_per_step": b_step,
+                     "model": "SURVEY 8(d): bloom mode pass 1 = 16 + 128 + 16 f_ins bytes per instance (the reference touches a 64-byte bloom block per instance; "
+                              "this design stages every bloom range once in LDS instead, so the 128 is a credit, not traffic), pass 2 = 16 + 8 + 8 f_hit; "
+                              "no_bloom_step_frac prices the one-pass unfiltered protocol on the same reads at 32 B per instance",
                      "f_ins": f_ins, "f_hit": f_hit,
-                     "pass1_frac": frac(b_pass1, ms_p1), "pass1_extract_insert_frac": frac(b_pass1, ms_p1_core),
+                     "pass1_frac": frac(b_pass1, ms_p1),
                      "pass2_frac": frac(b_pass2, w.get("pass2", 0.0)) if s2 else None,
-                     "step_frac": frac(b_pass1 + b_pass2, ms_step if world == 1 else 0.0),
+                     "step_frac": frac(b_step, ms_step if world == 1 else 0.0),
+                     "no_bloom_step_frac": nb_probe["step_frac"] if nb_probe else None,
+                     "no_bloom_step": nb_probe,
                      "pass_bytes": {"pass1": b_pass1, "pass2": b_pass2, "per_instance_pass1": b_pass1 / max(1, n1), "per_instance_pass2": (b_pass2 / n2) if n2 else None},
-                     "pass_ms": {"pass1": ms_p1, "pass1_extract_insert": ms_p1_core, "pass2": w.get("pass2"), "step": ms_step},
+                     "pass_ms": {"pass1": ms_p1, "pass2": w.get("pass2"), "step": ms_step},
+                     "pass2_input": "level-1 records retained by pass 1 (same input: main.c:57)" if (s2 and not p2_extracted) else "extracted again",
+                     "dominant_kernel": {"kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
+                                         "algorithmic_bytes_per_launch": dom["bytes"] / launches, "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),
+                                         "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                                         "achieved_no_bloom_model": (dom["bytes_no_bloom_model"] / (dom["ms"] * 1e-3) / 1e9) if dom.get("bytes_no_bloom_model") else None,
+                                         "traffic": (dom["traffic_bytes"] / launches) if dom.get("traffic_bytes") else None,
+                                         "hbm_util": dom.get("hbm_util")},
                      "all_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kern]},
         "verify": verify,
         "job_yak_md5": job_md5,

@@ -1309,37 +1309,55 @@ void k_select_scatter(AccTab tab, int bloom_mode, const u64 *seg_off, u32 *seg_c
  * eight ballots (peers with an equal digit), per-wave digit counters live in LDS.
  * ------------------------------------------------------------------------------------------ */
 #define SS_E 8
+/* exclusive scan of n_bins (a multiple of 256) LDS counters by 256 threads; `carry` is a one-word LDS scratch */
+__device__ __forceinline__ void ss_scan(u32 *h, const int n_bins, u32 *s_w /* [5] */)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = n_bins / 256;
+	u32 t = 0;
+	for (int q = 0; q < per; ++q) t += h[per * tid + q];
+	u32 incl = t;
+	for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	u32 e = incl - t;
+	for (int w = 0; w < wave; ++w) e += s_w[w];
+	for (int q = 0; q < per; ++q) { const u32 c = h[per * tid + q]; h[per * tid + q] = e; e += c; }
+	__syncthreads();
+}
+
+template <int BITS>   /* digit width: 8 (general path) or 11 (two passes cover the 22-bit ranks of the exclusive-ownership path) */
 __global__ __launch_bounds__(256)
 void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ seg_len, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
                      u64 *__restrict__ dst_kc, u64 *__restrict__ dst_t, int shift)
 {
-	__shared__ u32 s_hist[256];
-	__shared__ u32 s_wc[4][256];
+	constexpr int NBIN = 1 << BITS, PERB = NBIN / 256;
+	__shared__ u32 s_hist[NBIN];
+	__shared__ u32 s_wc[4][NBIN];
+	__shared__ u32 s_w[5];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const u64 a = seg_off[blockIdx.x], len = seg_len ? (u64)seg_len[blockIdx.x] : seg_off[blockIdx.x + 1] - a;
 	if (len == 0) return;
 	if (len == 1) { if (tid == 0) { dst_kc[a] = src_kc[a]; dst_t[a] = src_t[a]; } return; }
-	s_hist[tid] = 0;
+	for (int q = tid; q < NBIN; q += 256) s_hist[q] = 0;
 	__syncthreads();
-	for (u64 i = tid; i < len; i += 256) atomicAdd(&s_hist[(src_t[a + i] >> shift) & 255], 1u);
+	for (u64 i = tid; i < len; i += 256) atomicAdd(&s_hist[(src_t[a + i] >> shift) & (NBIN - 1)], 1u);
 	__syncthreads();
-	if (tid == 0) { u32 acc = 0; for (int d = 0; d < 256; ++d) { const u32 c = s_hist[d]; s_hist[d] = acc; acc += c; } }
-	__syncthreads();
+	ss_scan(s_hist, NBIN, s_w);
 	for (u64 tile = 0; tile < len; tile += 256 * SS_E) {
-		for (int w = 0; w < 4; ++w) s_wc[w][tid] = 0;
+		for (int w = 0; w < 4; ++w) for (int q = tid; q < NBIN; q += 256) s_wc[w][q] = 0;
 		__syncthreads();
 		u64 et[SS_E], ek[SS_E];
-		u32 erk[SS_E];
+		u32 erk[SS_E]; unsigned short edg[SS_E];
 #pragma unroll
 		for (int r = 0; r < SS_E; ++r) {
 			const u64 idx = tile + (u64)wave * (64 * SS_E) + r * 64 + lane;
 			const bool valid = idx < len;
 			u64 t = 0, kc = 0;
 			if (valid) { t = src_t[a + idx]; kc = src_kc[a + idx]; }
-			const u32 d = (u32)(t >> shift) & 255;
+			const u32 d = (u32)(t >> shift) & (NBIN - 1);
 			u64 peers = __ballot(valid);
 #pragma unroll
-			for (int b = 0; b < 8; ++b) {
+			for (int b = 0; b < BITS; ++b) {
 				const u64 vb = __ballot(valid && (d >> b & 1));
 				peers &= (d >> b & 1) ? vb : ~vb;
 			}
@@ -1347,20 +1365,21 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
 			const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
 			if (valid && lane == leader) { old = s_wc[wave][d]; s_wc[wave][d] = old + __popcll(peers); }
 			old = __shfl(old, leader);
-			et[r] = t; ek[r] = kc;
-			erk[r] = valid ? (d << 24 | (old + __popcll(peers & lanemask_lt()))) : 0xffffffffu;
+			et[r] = t; ek[r] = kc; edg[r] = (unsigned short)d;
+			erk[r] = valid ? old + __popcll(peers & lanemask_lt()) : 0xffffffffu;
 		}
 		__syncthreads();
-		{	/* digit `tid`: turn per-wave counts into start offsets, advance the running offset */
-			u32 run = s_hist[tid];
-			for (int w = 0; w < 4; ++w) { const u32 c = s_wc[w][tid]; s_wc[w][tid] = run; run += c; }
-			s_hist[tid] = run;
+		for (int q = 0; q < PERB; ++q) {	/* digits tid, tid + 256, ...: turn per-wave counts into start offsets, advance the running offset */
+			const int dg = tid + 256 * q;
+			u32 run = s_hist[dg];
+			for (int w = 0; w < 4; ++w) { const u32 c = s_wc[w][dg]; s_wc[w][dg] = run; run += c; }
+			s_hist[dg] = run;
 		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < SS_E; ++r) {
 			if (erk[r] != 0xffffffffu) {
-				const u64 d = a + s_wc[wave][erk[r] >> 24] + (erk[r] & 0xffffff);
+				const u64 d = a + s_wc[wave][edg[r]] + erk[r];
 				dst_kc[d] = ek[r]; dst_t[d] = et[r];
 			}
 		}
@@ -2285,7 +2304,7 @@ __device__ u32 r2_small_rounds(u64 *S, u64 *D, u32 *TG, u32 F, const u32 n, cons
 
 /* the prefix by the literal rule, then the rounds below R2_SMALL_F; one workgroup per sub-table */
 __global__ __launch_bounds__(256)
-void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, u32 small_f)
+void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, u32 small_f, int defer)
 {
 	__shared__ R2Wave s_wave[1];
 	__shared__ u64 s_S[R2_WS], s_D[R2_WD];                              /* 31 KB in all: the 1024 workgroups of a launch are resident at once */
@@ -2302,13 +2321,17 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 	u32 *TG = TAG + (off >> 1);
 	u32 *OC = OCC + (off >> 4);
 	if (tid == 0) {
-		/* the literal rule (khashl.h:171-189) for the scan positions below F0, every chain followed to its end
-		 * wherever it goes: all keys with a processing time (c, d), c < F0, are then in place, in the reference's
-		 * order -- including the keys the run that wraps around the end of the table shares with its beginning.
-		 * A kicked-out key leaves a tombstone: its slot still belongs to its run */
+		/* the literal rule (khashl.h:171-189) for the scan positions below F0.  A kicked-out key leaves a tombstone: its slot still
+		 * belongs to its run.  A chain is followed while it stays inside the prefix (whose slots feed each other) and wherever it
+		 * meets the run that may touch the end of the table (that run shares its region with the table's first run: its kicked keys
+		 * must be in place, in the reference's order, before the first run's later keys).  Anywhere else the key that lands on an
+		 * unmoved key of another run just leaves its tag, exactly as in the rounds (r2_chain): that run takes its kicked keys first, in
+		 * (c, d) order, when its round comes -- the chain's remaining steps (one dependent global access each, ~log2 n of them) are
+		 * not walked by this one lane.  defer == 0: every chain to its end, wherever it goes */
 		u32 F0 = n < 8 ? n : 8;
 		while (F0 < n && S[F0 - 1] != YK_EMPTY) ++F0;               /* slot F0 - 1 unused (or F0 == n) */
 		if (F0 > R2_BASE_MAX && F0 < n) *fail = 1;
+		const u32 tail0 = n > R2_LMAX + 2 ? n - (R2_LMAX + 2) : 0;     /* a run reaching slot n - 1 starts behind this slot (longer runs are refused) */
 		for (u32 j = 0; j < F0; ++j) {
 			u64 key = S[j];
 			if (key == YK_EMPTY || key == R2_MOVED) continue;
@@ -2321,6 +2344,7 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 				OC[q >> 5] |= 1u << (q & 31);
 				if (q >= n) break;
 				TG[q] = j << 6 | (d < 63 ? d : 63);
+				if (defer && q >= F0 && q < tail0) break;                /* the run of slot q reads the tag in its round */
 				const u64 v = S[q];
 				if (v == YK_EMPTY || v == R2_MOVED) break;
 				key = v; S[q] = R2_MOVED; ++d;                          /* an unmoved key sits there: kick it out */
@@ -2528,7 +2552,7 @@ void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG,
 #define F2_LST 24u
 struct R2Chunk {
 	union {
-		struct { u64 key[F2_NA]; u64 win[F2_WN]; u32 tag[F2_NA]; short le[F2_NA + 1], ne[F2_NA + 1]; u32 oc[F2_NOC]; } c;
+		struct { u64 key[F2_NA + 1]; u64 win[F2_WN]; u32 oc[F2_NOC]; } c;
 		R2WaveM m;                                                             /* the same memory while a medium run is placed */
 	} u;
 	u32 lst[F2_LST]; u32 nlst, pad;                                            /* runs of this chunk left to the wave routine */
@@ -2549,12 +2573,22 @@ __device__ __forceinline__ u32 r2_boundary_wave(const u64 *S, u32 F, u32 x, u32 
 	}
 }
 
-/* the chunks c0 = F + F2_CH (wave + n_waves i) of the round [F, G) that belong to this wave */
+/* LDS traffic of ONE wave is served in issue order: a compiler barrier is all that lies between a phase's writes and the next phase's
+ * reads -- no s_waitcnt, so the global loads requested for the next chunk stay in flight (a fence or __syncthreads() here waits vmcnt(0):
+ * gfx950 counts loads and stores on one counter) */
+__device__ __forceinline__ void r2_lds_phase() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+
+/* the chunks c0 = F + F2_CH (wave + n_waves i) of the round [F, G) that belong to this wave.  Window index x <-> old slot c0 - 1 + x; lane l
+ * holds the entries x = l + 64 j.  The runs of the window come from ballots (a 64-bit "unused" mask per j), not from LDS scans; a lane keeps
+ * its own keys and tags in registers, LDS holds the keys (looked up by window index at write-back) and the window of the new table */
+template <bool PROF>
 __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, u32 *TG, const u32 *OC, const u32 F, const u32 G, const u32 n, const u32 nb,
-                              const u32 wave, const u32 n_waves, u32 *s_big, u32 *s_nbig, u32 *fail)
+                                              const u32 wave, const u32 n_waves, u32 *s_big, u32 *s_nbig, u32 *fail, u64 *pf, u64 &tq)
 {
 	const u32 lane = threadIdx.x & 63;
+#define R2W_LAP(i) if (PROF) { const u64 t_ = wall_clock64(); pf[i] += t_ - tq; tq = t_; }
 	constexpr u32 PER = (F2_NA + 63) / 64;
+	static_assert(PER == 4, "four 64-bit masks cover the window");
 	u64 rk[PER]; u32 rt[PER], roc = 0;
 	auto fetch = [&](const u32 c0) {
 #pragma unroll
@@ -2569,43 +2603,55 @@ __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, 
 	if (c0 < G) fetch(c0);
 	while (c0 < G) {
 		const u32 w0 = 2 * c0;
+		u64 kc[PER], E[PER]; u32 tc[PER];
 #pragma unroll
 		for (u32 j = 0; j < PER; ++j) {
 			const u32 x = lane + 64 * j, sl = c0 - 1 + x;
-			if (x < F2_NA) { C.u.c.key[x] = sl < n ? rk[j] : YK_EMPTY; C.u.c.tag[x] = sl < n ? rt[j] : R2_NONE; }
+			kc[j] = (x < F2_NA && sl < n) ? rk[j] : YK_EMPTY; tc[j] = rt[j];
+			if (x >= F2_NA) kc[j] = R2_MOVED;                                   /* behind the window: neither a key nor a gap */
+			if (x < F2_NA) C.u.c.key[x] = kc[j];
+			E[j] = __ballot(kc[j] == YK_EMPTY);
 		}
-		if (lane < F2_NOC) C.u.c.oc[lane] = roc;
+		const u32 oc_cur = roc;
+		const bool any_oc = __ballot(lane < F2_NOC && oc_cur != 0) != 0;      /* slots a chain of the prefix took: only near the two ends of the table */
+		if (any_oc && lane < F2_NOC) C.u.c.oc[lane] = oc_cur;
 		if (lane == 0) C.nlst = 0;
 		const u32 c1 = c0 + n_waves * F2_CH;
 		if (c1 < G) fetch(c1);
-		r2_wave_sync();
+		r2_lds_phase();
+		R2W_LAP(0)
 		for (u32 i = lane; i < F2_WN; i += 64) {
-			const u32 q = w0 + i, b = (w0 & 31) + i;
-			C.u.c.win[i] = (q < 2 * n && (C.u.c.oc[b >> 5] >> (b & 31) & 1)) ? 0ull : ~0ull;
+			u64 v = ~0ull;
+			if (any_oc) { const u32 q = w0 + i, b = (w0 & 31) + i; if (q < 2 * n && (C.u.c.oc[b >> 5] >> (b & 31) & 1)) v = 0ull; }
+			C.u.c.win[i] = v;
 		}
-		{	/* last / next unused slot: every lane owns PER consecutive entries, the lanes are linked by a shuffle scan */
-			const u32 x0 = lane * PER;
-			int le = -1, ne = (int)F2_NA;
-			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x < F2_NA && C.u.c.key[x] == YK_EMPTY) le = (int)x; }
-			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x < F2_NA && C.u.c.key[x] == YK_EMPTY) ne = (int)x; }
-			int lei = le, nei = ne;
-			for (int o = 1; o < 64; o <<= 1) {
-				const int t = __shfl_up(lei, o), u = __shfl_down(nei, o);
-				if ((int)lane >= o && t > lei) lei = t;
-				if ((int)lane + o < 64 && u < nei) nei = u;
-			}
-			int run_le = __shfl_up(lei, 1), run_ne = __shfl_down(nei, 1);
-			if (lane == 0) run_le = -1;
-			if (lane == 63) run_ne = (int)F2_NA;
-			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x >= F2_NA) break; if (C.u.c.key[x] == YK_EMPTY) run_le = (int)x; C.u.c.le[x] = (short)run_le; }
-			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x >= F2_NA) continue; if (C.u.c.key[x] == YK_EMPTY) run_ne = (int)x; C.u.c.ne[x] = (short)run_ne; }
-		}
-		r2_wave_sync();
+		r2_lds_phase();
+		R2W_LAP(1)
 		const u32 lim = (G < c0 + F2_CH ? G : c0 + F2_CH) - c0;              /* runs start in [c0, c0 + lim) */
-		for (u32 x = lane + 1; x < F2_NA; x += 64) {
-			const u64 key = C.u.c.key[x];
-			if (key == YK_EMPTY) continue;
-			const int le = C.u.c.le[x], ne = C.u.c.ne[x];
+#pragma unroll
+		for (u32 j = 0; j < PER; ++j) {
+			const u32 x = lane + 64 * j;
+			const u64 key = kc[j];
+			if (x == 0 || x >= F2_NA || key == YK_EMPTY) continue;
+			/* last unused slot before x, next unused slot behind x (window indices; -1 / F2_NA: none) */
+			int le = -1, ne = (int)F2_NA;
+			{
+				const u64 below = lane == 63 ? ~0ull : (2ull << lane) - 1;      /* bits 0 .. lane */
+				bool got = false;
+#pragma unroll
+				for (int jj = (int)PER - 1; jj >= 0; --jj) {
+					if (jj > (int)j || got) continue;
+					const u64 m = jj == (int)j ? E[jj] & below : E[jj];
+					if (m) { le = 64 * jj + 63 - __clzll((long long)m); got = true; }
+				}
+				got = false;
+#pragma unroll
+				for (int jj = 0; jj < (int)PER; ++jj) {
+					if (jj < (int)j || got) continue;
+					const u64 m = jj == (int)j ? E[jj] & ~below : E[jj];
+					if (m) { ne = 64 * jj + (__ffsll((long long)m) - 1); got = true; }
+				}
+			}
 			if (le < 0 || (u32)le >= lim) continue;                             /* its run starts before / behind this chunk */
 			const u32 L = (u32)(ne - le - 1), a = c0 + (u32)le;
 			if (ne >= (int)F2_NA || L > F2_CHL || a + L >= n) {                 /* too long for the window, or it reaches the end of the table: the wave routine */
@@ -2616,7 +2662,7 @@ __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, 
 				continue;
 			}
 			if (key == R2_MOVED) continue;
-			const u32 sl = c0 - 1 + x, t = C.u.c.tag[x];
+			const u32 sl = c0 - 1 + x, t = tc[j];
 			const u32 sig = (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
 			u64 e = (u64)(sig + 1) << 32 | x;
 			u32 q = r2_home(key, nb) - w0;
@@ -2628,7 +2674,8 @@ __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, 
 				++q;
 			}
 		}
-		r2_wave_sync();
+		r2_lds_phase();
+		R2W_LAP(2)
 		for (u32 i = lane; i < F2_WN; i += 64) {
 			const u64 e = C.u.c.win[i];
 			if (e == ~0ull || (e >> 32) == 0) continue;
@@ -2636,7 +2683,8 @@ __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, 
 			D[q] = C.u.c.key[(u32)e];
 			if (q < n) TG[q] = (u32)(e >> 32) - 1;
 		}
-		r2_wave_sync();
+		r2_lds_phase();
+		R2W_LAP(3)
 		/* the runs this chunk left out: every run of a round is independent of the others, so they are placed now, in the chunk's own LDS */
 		const u32 nl = C.nlst < F2_LST ? C.nlst : F2_LST;
 		for (u32 j = 0; j < nl; ++j) {
@@ -2653,17 +2701,20 @@ __device__ __forceinline__ void r2_round_wave(R2Chunk &C, const u64 *S, u64 *D, 
 			else if (lane == 0) { const u32 at = atomicAdd(s_nbig, 1u); if (at < 64) s_big[at] = a; else *fail = 8; }
 			r2_wave_sync();
 		}
+		R2W_LAP(4)
 		c0 = c1;
 	}
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5)))      /* <= 96 VGPRs: four 5-wave workgroups per CU */
-void k_r2_double(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail)
+template <int NW, bool PROF>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 6 && !PROF ? 6 : 4)))      /* NW = 6: <= 80 VGPRs, four workgroups per CU = 24 waves */
+void k_r2_double(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail, u64 *prof)
 {
+	u64 pf[PROF ? 8 : 1] = { 0 }, tq = PROF ? wall_clock64() : 0;              /* PROF (YAKAMD_VERBOSE > 1): 100 MHz ticks per phase, lane 0 of every wave */
+#define R2F_LAP(i) if (PROF) { const u64 t_ = wall_clock64(); pf[i] += t_ - tq; tq = t_; }
 	__shared__ union { R2Chunk ch[NW]; R2Wave big; } U;
 	__shared__ u32 s_big[64];
-	__shared__ u32 s_G, s_nbig;
+	__shared__ u32 s_G, s_F, s_nbig;
 	const u32 p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const R2Act A = acts[p];
 	if (A.kind != 2) return;
@@ -2679,24 +2730,47 @@ void k_r2_double(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 	__syncthreads();
 	while (F < n) {
 		const u32 G = s_G;
-		if (G == 0) { if (tid == 0) *fail = 3; break; }                       /* a run covers [F, 2F] beyond small_f: not handled here (uniform) */
+		if (G == 0) {
+			/* (uniform) no unused slot in (F, 2F]: one run covers [F, 2F] and feeds its own slots.  It is placed alone, by the literal rule in
+			 * sigma order on LDS copies (r2_wave_run<.., true>, as in k_r2_dsmall's rounds), up to its own end */
+			__syncthreads();
+			if (wave == 0) {
+				u32 g = 2 * F;
+				for (;;) {                                                         /* first unused slot from 2F on */
+					const u32 idx = g + lane;
+					const u64 m = __ballot(idx >= n || S[idx] == YK_EMPTY);
+					if (m) { g += (u32)__ffsll((long long)m) - 1; break; }
+					g += 64;
+				}
+				const u32 G2 = g < n ? g + 1 : n;
+				r2_wave_run<true, true>(U.big, S, D, TG, F, n, nb, fail);
+				r2_wave_sync();
+				const u32 gn = G2 < n ? r2_boundary_wave(S, G2, 2 * G2 < n ? 2 * G2 : n, n) : n;
+				if (lane == 0) { s_F = G2; s_G = gn; }
+			}
+			__syncthreads();
+			F = s_F;
+			continue;
+		}
 		__syncthreads();                                                       /* everybody has read s_G */
 		if (wave == 0 && G < n) { const u32 g = r2_boundary_wave(S, G, 2 * G < n ? 2 * G : n, n); if (lane == 0) s_G = g; }   /* used slots stay used: the next boundary can be looked up now */
-		r2_round_wave(U.ch[wave], S, D, TG, OC, F, G, n, nb, wave, NW, s_big, &s_nbig, fail);
-		__threadfence();
-		__syncthreads();
+		r2_round_wave<PROF>(U.ch[wave], S, D, TG, OC, F, G, n, nb, wave, NW, s_big, &s_nbig, fail, pf, tq);
+		R2F_LAP(5)
+		__syncthreads();                                                       /* workgroup scope is all it takes: the sub-table never leaves this workgroup (an agent-scope fence here writes the L2 back, once per round and workgroup) */
+		R2F_LAP(6)
 		if (s_nbig) {                                                          /* (uniform) runs beyond R2_MMAX slots: wave 0, one after the other */
 			if (wave == 0) {
 				const u32 nbg = s_nbig < 64 ? s_nbig : 64;
 				for (u32 j = 0; j < nbg; ++j) { r2_wave_run<true, false>(U.big, S, D, TG, s_big[j], n, nb, fail); r2_wave_sync(); }
 				if (lane == 0) s_nbig = 0;
 			}
-			__threadfence();
 			__syncthreads();
+			R2F_LAP(7)
 		}
 		F = G;
 	}
 	if (tid == 0) Fout[p] = F;
+	if (PROF && lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)pf[i]); atomicAdd((unsigned long long*)&prof[8], 1ull); }
 }
 
 /* keys of a stage grouped by the segment of their home slot: pk/pr[rec_off + i0 + ...], seg_start[seg0 + s] relative to the stage's first key */
@@ -3825,6 +3899,62 @@ void k_lc_compact(LcOut O, const u64 *__restrict__ sbstart, int s2_bits, int plo
 	if (tid == 0 && s_red[0]) { const u64 v = t_pass0 + (u64)s_red[0]; if (v > lastput[p]) lastput[p] = v; }
 }
 
+/* The same gather fused with the FIRST pass of the sort by insertion time: the keys go straight to their place by the low LS1_BITS bits of T.
+ * The first pass of an LSD radix sort has no earlier order to keep, so it need not be stable: a histogram sweep over the fragments, a scan, and
+ * a second sweep that hands out places with LDS atomics.  A batch of 256 sub-buckets is flattened (element e -> its fragment by a search in the
+ * batch's prefix sums), so every lane has a load in flight whatever the fragment sizes are.  One stable pass per further LS1_BITS bits follows
+ * (k_seg_sort_pass<11>): two data movements in all for ranks below 2^22, where the separate gather + three 8-bit passes made four */
+#define LS1_BITS 11
+__global__ __launch_bounds__(256)
+void k_lc_sort1(LcOut O, const u64 *__restrict__ sbstart, int s2_bits, int plo, u64 t_pass0, const u64 *__restrict__ seg_base,
+                u64 *__restrict__ out_kc, u64 *__restrict__ out_T, u64 *lastput, u32 *ndist_p)
+{
+	constexpr u32 NBIN = 1u << LS1_BITS;
+	__shared__ u32 s_hist[NBIN];
+	__shared__ u32 s_off[257];
+	__shared__ u64 s_src[256];
+	__shared__ u32 s_w[5], s_red[1];
+	const u32 p = (u32)plo + blockIdx.x, S2 = 1u << s2_bits, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const size_t b0 = (size_t)p * S2;
+	const u64 base = seg_base[p];
+	for (u32 q = tid; q < NBIN; q += 256) s_hist[q] = 0;
+	if (tid == 0) s_red[0] = 0;
+	u32 lpm = 0, nds = 0;
+	for (int sweep = 0; sweep < 2; ++sweep) {
+		for (u32 j0 = 0; j0 < S2; j0 += 256) {
+			__syncthreads();
+			const u32 j = j0 + tid, n = j < S2 ? O.nsel[b0 + j] : 0;
+			if (sweep == 0 && j < S2) { const u32 l = O.lp[b0 + j]; lpm = l > lpm ? l : lpm; nds += O.nd[b0 + j]; }
+			s_src[tid] = j < S2 ? sbstart[b0 + j] : 0;
+			u32 incl = n;                                               /* exclusive scan of the batch's 256 counts */
+			for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= (u32)o) incl += x; }
+			if (lane == 63) s_w[wave] = incl;
+			__syncthreads();
+			u32 e0 = incl - n;
+			for (u32 w = 0; w < wave; ++w) e0 += s_w[w];
+			s_off[tid] = e0;
+			if (tid == 255) s_off[256] = e0 + n;
+			__syncthreads();
+			const u32 tot = s_off[256];
+			for (u32 e = tid; e < tot; e += 256) {
+				u32 lo = 0, hi = 256;                                    /* the fragment of element e: largest q with s_off[q] <= e */
+				while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid; }
+				const u64 src = s_src[lo] + (e - s_off[lo]);
+				const u64 T = O.T[src];
+				const u32 d = (u32)T & (NBIN - 1);
+				if (sweep == 0) atomicAdd(&s_hist[d], 1u);
+				else { const u64 dst = base + atomicAdd(&s_hist[d], 1u); out_kc[dst] = O.kc[src]; out_T[dst] = T; }
+			}
+		}
+		__syncthreads();
+		if (sweep == 0) ss_scan(s_hist, (int)NBIN, s_w);
+	}
+	for (int o = 32; o; o >>= 1) { const u32 x = __shfl_down(lpm, o); lpm = x > lpm ? x : lpm; nds += __shfl_down(nds, o); }
+	if (lane == 0) { atomicMax(&s_red[0], lpm); atomicAdd(&ndist_p[p], nds); }
+	__syncthreads();
+	if (tid == 0 && s_red[0]) { const u64 v = t_pass0 + (u64)s_red[0]; if (v > lastput[p]) lastput[p] = v; }
+}
+
 /* ------------------------------------------------------------------------------------------
  * launch wrappers
  * ------------------------------------------------------------------------------------------ */
@@ -4373,7 +4503,7 @@ void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_
 void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
+	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
 }
 
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
@@ -4516,12 +4646,13 @@ void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0,
 }
 void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Gcur, fail, (u32)yk_r2_small_f());
+	static const int defer = getenv("YAKAMD_R2_DEFER") ? atoi(getenv("YAKAMD_R2_DEFER")) : 1;   /* 0: the prefix lane follows every chain to its end */
+	hipLaunchKernelGGL(k_r2_dsmall, dim3(P), dim3(256), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Gcur, fail, (u32)yk_r2_small_f(), defer);
 }
 int yk_r2_small_f(void)                                            /* YAKAMD_R2_SMALL_F: test / tuning knob, a power of two in [16, 4096] */
 {
 	const char *e = getenv("YAKAMD_R2_SMALL_F");
-	int v = e ? atoi(e) : (int)R2_SMALL_F;
+	int v = e ? atoi(e) : yk_r2_fused() ? 16 : (int)R2_SMALL_F;   /* the fused rounds (k_r2_double) take over right behind the literal prefix: their chunk routine places a round's runs side by side where k_r2_dsmall walks them lane by lane */
 	if (v < 16) v = 16;
 	if (v > 4096) v = 4096;
 	while (v & (v - 1)) v &= v - 1;
@@ -4538,17 +4669,31 @@ void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0
 	hipLaunchKernelGGL(k_r2_dround, dim3((unsigned)std::min<u64>(tasks, resident)), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, Gcur, Gnext, fail, long_list, long_n, long_cap, blocks, P);
 	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_n_next, long_cap, fail);
 }
+int yk_r2_fused(void) { static const int on = getenv("YAKAMD_R2_FUSED") ? atoi(getenv("YAKAMD_R2_FUSED")) : 1; return on; }
 /* the rounds of a doubling step from k_r2_dsmall's end (Fin) on in one launch (k_r2_double): n_dbl = sub-tables that double in this step.  0 = launched, 1 = switched off (YAKAMD_R2_FUSED=0) */
 int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail, hipStream_t st)
 {
-	static const int on = getenv("YAKAMD_R2_FUSED") ? atoi(getenv("YAKAMD_R2_FUSED")) : 1;
-	if (!on) return 1;
+	if (!yk_r2_fused()) return 1;
 	static const int force_nw = getenv("YAKAMD_R2_NW") ? atoi(getenv("YAKAMD_R2_NW")) : 0;
-	/* many sub-tables: 5 waves each, four workgroups per CU (all 1024 sub-tables of a default table resident at once); few, large ones (a shard of
+	/* many sub-tables: 6 waves each, four workgroups per CU (all 1024 sub-tables of a default table resident at once); few, large ones (a shard of
 	 * a multi-GPU job): 16 waves each */
-	const int nw = force_nw ? force_nw : n_dbl <= 256 ? 16 : 5;
-	if (nw >= 16) hipLaunchKernelGGL(k_r2_double<16>, dim3(P), dim3(64 * 16), 0, st, tabs, acts, K0, K1, TAG, (const u32*)OCC, (const u32*)Fin, Fout, fail);
-	else hipLaunchKernelGGL(k_r2_double<5>, dim3(P), dim3(64 * 5), 0, st, tabs, acts, K0, K1, TAG, (const u32*)OCC, (const u32*)Fin, Fout, fail);
+	const int nw = force_nw ? force_nw : n_dbl <= 256 ? 16 : 6;
+	static u64 *d_prof = 0;
+	static const bool prof = getenv("YAKAMD_VERBOSE") && atoi(getenv("YAKAMD_VERBOSE")) > 1;
+	if (prof && !d_prof) { hipMalloc((void**)&d_prof, 16 * 8); }
+	if (prof) hipMemsetAsync(d_prof, 0, 16 * 8, st);
+#define YK_DBL(NWv, PRv) hipLaunchKernelGGL((k_r2_double<NWv, PRv>), dim3(P), dim3(64 * NWv), 0, st, tabs, acts, K0, K1, TAG, (const u32*)OCC, (const u32*)Fin, Fout, fail, d_prof)
+	if (nw >= 16) { if (prof) YK_DBL(16, true); else YK_DBL(16, false); }
+	else { if (prof) YK_DBL(6, true); else YK_DBL(6, false); }
+#undef YK_DBL
+	if (prof) {
+		u64 h[16];
+		hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, st);
+		hipStreamSynchronize(st);
+		if (h[8]) fprintf(stderr, "[yak_amd] k_r2_double<%d> 100 MHz ticks per wave (%llu waves): stage %llu, window+scans %llu, probing %llu, write-back %llu, medium runs %llu, round total %llu, barrier %llu, big runs %llu\n",
+		                  nw, (unsigned long long)h[8], (unsigned long long)(h[0] / h[8]), (unsigned long long)(h[1] / h[8]), (unsigned long long)(h[2] / h[8]), (unsigned long long)(h[3] / h[8]),
+		                  (unsigned long long)(h[4] / h[8]), (unsigned long long)(h[5] / h[8]), (unsigned long long)(h[6] / h[8]), (unsigned long long)(h[7] / h[8]));
+	}
 	return 0;
 }
 #ifdef R2_PROF
@@ -4634,7 +4779,19 @@ void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_seg_sort_pass, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
+	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
+}
+/* the passes behind k_lc_sort1: LS1_BITS bits each */
+int yk_sort1_bits(void) { return LS1_BITS; }
+void yk_launch_seg_sort_pass11(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
+                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_seg_sort_pass<LS1_BITS>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
+}
+void yk_launch_lc_sort1(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
+                        u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_lc_sort1, dim3(phi - plo), dim3(256), 0, st, O, sbstart, s2_bits, plo, t_pass0, seg_base, out_kc, out_T, lastput, ndist_p);
 }
 
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st)
