@@ -1621,11 +1621,9 @@ static int fast_finish(yakamd_ctx *c)
 	const u64 n_sel = ro[P];
 	if (dmalloc(&kc[0], n_sel) || dmalloc(&tt[0], n_sel) || dmalloc(&kc[1], n_sel) || dmalloc(&tt[1], n_sel) || dmalloc(&d_segbase, P + 1)) return -1;
 	HIPCK(hipMemcpyAsync(d_segbase, ro.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	const bool sort1 = env_i64("YAKAMD_SORT1", 1) != 0;          /* the gather is the first pass of the sort by insertion time (k_lc_sort1) */
 	{
 		EvTimer tm(c->st);
-		if (sort1) yk_launch_lc_sort1(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
-		else yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
+		yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
 		c->st_cur.ms_select += tm.stop();
 	}
 	{
@@ -1640,12 +1638,7 @@ static int fast_finish(yakamd_ctx *c)
 	{
 		EvTimer tm(c->st);
 		const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
-		if (sort1) {
-			for (int shift = yk_sort1_bits(); shift < tbits; shift += yk_sort1_bits()) {   /* stable passes over the digits above the one k_lc_sort1 placed by */
-				yk_launch_seg_sort_pass11(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
-				cur ^= 1;
-			}
-		} else for (int shift = 0; shift < tbits; shift += 8) {
+		for (int shift = 0; shift < tbits; shift += 8) {
 			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
 			cur ^= 1;
 		}

@@ -1325,7 +1325,8 @@ __device__ __forceinline__ void ss_scan(u32 *h, const int n_bins, u32 *s_w /* [5
 	__syncthreads();
 }
 
-template <int BITS>   /* digit width: 8 (general path) or 11 (two passes cover the 22-bit ranks of the exclusive-ownership path) */
+template <int BITS>   /* digit width.  8: a tile of 2048 keys leaves ~8 neighbours per digit, i.e. 64-byte runs in the output; 11-bit digits (two passes for 22-bit ranks, the first one fused
+                       * with the gather of the fragments) were measured and lost: one key per digit and tile means lone 8-byte stores, and the saved pass does not pay for them */
 __global__ __launch_bounds__(256)
 void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ seg_len, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
                      u64 *__restrict__ dst_kc, u64 *__restrict__ dst_t, int shift)
@@ -3899,62 +3900,6 @@ void k_lc_compact(LcOut O, const u64 *__restrict__ sbstart, int s2_bits, int plo
 	if (tid == 0 && s_red[0]) { const u64 v = t_pass0 + (u64)s_red[0]; if (v > lastput[p]) lastput[p] = v; }
 }
 
-/* The same gather fused with the FIRST pass of the sort by insertion time: the keys go straight to their place by the low LS1_BITS bits of T.
- * The first pass of an LSD radix sort has no earlier order to keep, so it need not be stable: a histogram sweep over the fragments, a scan, and
- * a second sweep that hands out places with LDS atomics.  A batch of 256 sub-buckets is flattened (element e -> its fragment by a search in the
- * batch's prefix sums), so every lane has a load in flight whatever the fragment sizes are.  One stable pass per further LS1_BITS bits follows
- * (k_seg_sort_pass<11>): two data movements in all for ranks below 2^22, where the separate gather + three 8-bit passes made four */
-#define LS1_BITS 11
-__global__ __launch_bounds__(256)
-void k_lc_sort1(LcOut O, const u64 *__restrict__ sbstart, int s2_bits, int plo, u64 t_pass0, const u64 *__restrict__ seg_base,
-                u64 *__restrict__ out_kc, u64 *__restrict__ out_T, u64 *lastput, u32 *ndist_p)
-{
-	constexpr u32 NBIN = 1u << LS1_BITS;
-	__shared__ u32 s_hist[NBIN];
-	__shared__ u32 s_off[257];
-	__shared__ u64 s_src[256];
-	__shared__ u32 s_w[5], s_red[1];
-	const u32 p = (u32)plo + blockIdx.x, S2 = 1u << s2_bits, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const size_t b0 = (size_t)p * S2;
-	const u64 base = seg_base[p];
-	for (u32 q = tid; q < NBIN; q += 256) s_hist[q] = 0;
-	if (tid == 0) s_red[0] = 0;
-	u32 lpm = 0, nds = 0;
-	for (int sweep = 0; sweep < 2; ++sweep) {
-		for (u32 j0 = 0; j0 < S2; j0 += 256) {
-			__syncthreads();
-			const u32 j = j0 + tid, n = j < S2 ? O.nsel[b0 + j] : 0;
-			if (sweep == 0 && j < S2) { const u32 l = O.lp[b0 + j]; lpm = l > lpm ? l : lpm; nds += O.nd[b0 + j]; }
-			s_src[tid] = j < S2 ? sbstart[b0 + j] : 0;
-			u32 incl = n;                                               /* exclusive scan of the batch's 256 counts */
-			for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= (u32)o) incl += x; }
-			if (lane == 63) s_w[wave] = incl;
-			__syncthreads();
-			u32 e0 = incl - n;
-			for (u32 w = 0; w < wave; ++w) e0 += s_w[w];
-			s_off[tid] = e0;
-			if (tid == 255) s_off[256] = e0 + n;
-			__syncthreads();
-			const u32 tot = s_off[256];
-			for (u32 e = tid; e < tot; e += 256) {
-				u32 lo = 0, hi = 256;                                    /* the fragment of element e: largest q with s_off[q] <= e */
-				while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid; }
-				const u64 src = s_src[lo] + (e - s_off[lo]);
-				const u64 T = O.T[src];
-				const u32 d = (u32)T & (NBIN - 1);
-				if (sweep == 0) atomicAdd(&s_hist[d], 1u);
-				else { const u64 dst = base + atomicAdd(&s_hist[d], 1u); out_kc[dst] = O.kc[src]; out_T[dst] = T; }
-			}
-		}
-		__syncthreads();
-		if (sweep == 0) ss_scan(s_hist, (int)NBIN, s_w);
-	}
-	for (int o = 32; o; o >>= 1) { const u32 x = __shfl_down(lpm, o); lpm = x > lpm ? x : lpm; nds += __shfl_down(nds, o); }
-	if (lane == 0) { atomicMax(&s_red[0], lpm); atomicAdd(&ndist_p[p], nds); }
-	__syncthreads();
-	if (tid == 0 && s_red[0]) { const u64 v = t_pass0 + (u64)s_red[0]; if (v > lastput[p]) lastput[p] = v; }
-}
-
 /* ------------------------------------------------------------------------------------------
  * launch wrappers
  * ------------------------------------------------------------------------------------------ */
@@ -4781,19 +4726,6 @@ void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, co
 {
 	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
 }
-/* the passes behind k_lc_sort1: LS1_BITS bits each */
-int yk_sort1_bits(void) { return LS1_BITS; }
-void yk_launch_seg_sort_pass11(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
-                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
-{
-	hipLaunchKernelGGL(k_seg_sort_pass<LS1_BITS>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
-}
-void yk_launch_lc_sort1(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
-                        u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st)
-{
-	hipLaunchKernelGGL(k_lc_sort1, dim3(phi - plo), dim3(256), 0, st, O, sbstart, s2_bits, plo, t_pass0, seg_base, out_kc, out_T, lastput, ndist_p);
-}
-
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st)
 {
 	if (n) hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
