@@ -1028,15 +1028,18 @@ static bool rccl_open(RcclApi *R)
 	return R->CommInitAll && R->CommDestroy && R->GroupStart && R->GroupEnd && R->Send && R->Recv;
 }
 
+/* Ranks own prefix ranges; chunks of the input live in SLOTS, one per distinct device (ranks that share a device -- the sweeps of one device
+ * posing as several -- share its chunk, its partition and its buffers: the owner's slice of a chunk on its own device is fed where it lies).
+ * Two sets of slot buffers: set x is being partitioned, exchanged and fed by a worker thread while the reader fills set 1 - x. */
 struct MultiJob {
-	int N, P;
-	std::vector<int> dev;
-	std::vector<hipStream_t> st;
+	int N, P, S;                                               /* ranks, sub-tables, slots */
+	std::vector<int> dev, sdev, slot_of;                       /* device of rank r; device of slot s; slot of rank r */
+	std::vector<hipStream_t> st, cp;                           /* per slot: exchange stream; copy stream of the reader (non-blocking: the fill of the next set must not wait for the kernels of this one) */
 	bool use_rccl;
 	RcclApi R;
-	std::vector<ncclComm_t> comm;
-	std::vector<uint8_t*> d_base;                              /* chunk of sequence on each GPU */
-	std::vector<uint64_t*> d_send, d_recv;                     /* records grouped by prefix / by source then prefix */
+	std::vector<ncclComm_t> comm;                              /* per slot */
+	std::vector<uint8_t*> d_base[2];                           /* [set][slot]: chunk of sequence */
+	std::vector<uint64_t*> d_send[2], d_recv[2];               /* [set][slot]: records grouped by prefix / slices received from the other slots */
 	int64_t chunk, send_words, recv_words;
 };
 
@@ -1091,27 +1094,41 @@ static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *
 static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
 {
 	J->N = N; J->P = P; J->dev = dev;
-	J->st.assign(N, 0); J->d_base.assign(N, 0); J->d_send.assign(N, 0); J->d_recv.assign(N, 0);
+	J->sdev.clear(); J->slot_of.assign(N, 0);
+	for (int r = 0; r < N; ++r) {
+		int s = -1;
+		for (size_t q = 0; q < J->sdev.size(); ++q) if (J->sdev[q] == dev[r]) s = (int)q;
+		if (s < 0) { s = (int)J->sdev.size(); J->sdev.push_back(dev[r]); }
+		J->slot_of[r] = s;
+	}
+	const int S = J->S = (int)J->sdev.size();
+	J->st.assign(S, 0); J->cp.assign(S, 0);
+	for (int x = 0; x < 2; ++x) { J->d_base[x].assign(S, 0); J->d_send[x].assign(S, 0); J->d_recv[x].assign(S, 0); }
 	const char *c = getenv("YAKAMD_MGPU_CHUNK");
 	J->chunk = c && atoll(c) > 0 ? atoll(c) : (int64_t)1 << 28;
 	J->chunk = (J->chunk + 4095) & ~(int64_t)4095;
-	J->send_words = 2 * J->chunk;                             /* one 16-byte record per position at most */
-	J->recv_words = J->send_words + J->send_words / 2 + 4096 * N;   /* the owner's share of N chunks: 1 / N each on average; refused beyond 1.5 chunks */
-	bool distinct = true;
-	for (int a = 0; a < N; ++a) for (int b = a + 1; b < N; ++b) if (dev[a] == dev[b]) distinct = false;
-	J->use_rccl = distinct && !(getenv("YAKAMD_MGPU_NO_RCCL") && atoi(getenv("YAKAMD_MGPU_NO_RCCL")));
+	J->send_words = 2 * J->chunk;                             /* one 16-byte record per position at most (8-byte tagged records use half of it) */
+	/* a slot receives, for the ranks it hosts, their share of the S - 1 other chunks: (ranks here / N) each on average; refused beyond 1.5 x that */
+	int most = 0;
+	for (int s = 0; s < S; ++s) { int n_here = 0; for (int r = 0; r < N; ++r) n_here += J->slot_of[r] == s; most = std::max(most, n_here); }
+	J->recv_words = S > 1 ? (int64_t)((double)J->send_words * (S - 1) * most / N * 1.5) + 4096 * N : 0;
+	J->use_rccl = S > 1 && !(getenv("YAKAMD_MGPU_NO_RCCL") && atoi(getenv("YAKAMD_MGPU_NO_RCCL")));
+	if (S < N) fprintf(stderr, "[M::yak_count] %d ranks on %d device%s: ranks that share a device share its chunks and take turns (their slices are fed where they lie)%s\n",
+	                   N, S, S > 1 ? "s" : "", S == 1 ? "; nothing is exchanged" : "");
 	if (J->use_rccl) {
-		J->comm.assign(N, 0);
+		J->comm.assign(S, 0);
 		if (!rccl_open(&J->R)) { fprintf(stderr, "[W::yak_count] librccl.so not found: exchanging with peer copies\n"); J->use_rccl = false; }
-		else { const ncclResult_t r = J->R.CommInitAll(J->comm.data(), N, dev.data()); if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; } }
+		else { const ncclResult_t r = J->R.CommInitAll(J->comm.data(), S, J->sdev.data()); if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; } }
 	}
-	for (int r = 0; r < N; ++r) {
-		if (hipSetDevice(dev[r]) != hipSuccess || hipStreamCreate(&J->st[r]) != hipSuccess) return false;
-		if (!J->use_rccl) for (int q = 0; q < N; ++q) if (dev[q] != dev[r]) (void)hipDeviceEnablePeerAccess(dev[q], 0);
-		J->d_base[r] = (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
-		J->d_send[r] = (uint64_t*)yakamd_dev_alloc((size_t)J->send_words * 8);
-		J->d_recv[r] = (uint64_t*)yakamd_dev_alloc((size_t)J->recv_words * 8);
-		if (!J->d_base[r] || !J->d_send[r] || !J->d_recv[r]) return false;
+	for (int s = 0; s < S; ++s) {
+		if (hipSetDevice(J->sdev[s]) != hipSuccess || hipStreamCreate(&J->st[s]) != hipSuccess || hipStreamCreateWithFlags(&J->cp[s], hipStreamNonBlocking) != hipSuccess) return false;
+		if (!J->use_rccl) for (int q = 0; q < S; ++q) if (q != s) (void)hipDeviceEnablePeerAccess(J->sdev[q], 0);
+		for (int x = 0; x < 2; ++x) {
+			J->d_base[x][s] = (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
+			J->d_send[x][s] = (uint64_t*)yakamd_dev_alloc((size_t)J->send_words * 8);
+			J->d_recv[x][s] = J->recv_words ? (uint64_t*)yakamd_dev_alloc((size_t)J->recv_words * 8) : 0;
+			if (!J->d_base[x][s] || !J->d_send[x][s] || (J->recv_words && !J->d_recv[x][s])) return false;
+		}
 	}
 	(void)hipGetLastError();
 	return true;
@@ -1119,78 +1136,82 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
 
 static void multi_close(MultiJob *J)
 {
-	for (int r = 0; r < J->N; ++r) {
-		hipSetDevice(J->dev[r]);
-		yakamd_dev_free(J->d_base[r]); yakamd_dev_free(J->d_send[r]); yakamd_dev_free(J->d_recv[r]);
-		if (J->st[r]) hipStreamDestroy(J->st[r]);
-		if (J->use_rccl && J->comm[r]) J->R.CommDestroy(J->comm[r]);
+	for (int s = 0; s < J->S; ++s) {
+		hipSetDevice(J->sdev[s]);
+		for (int x = 0; x < 2; ++x) { yakamd_dev_free(J->d_base[x][s]); yakamd_dev_free(J->d_send[x][s]); yakamd_dev_free(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
+		if (J->st[s]) { hipStreamDestroy(J->st[s]); J->st[s] = 0; }
+		if (J->cp[s]) { hipStreamDestroy(J->cp[s]); J->cp[s] = 0; }
+		if (J->use_rccl && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
 	}
 }
 
-/* one round: chunk r (fill[r] bytes, stream offset t0[r]) sits on GPU r.  Partition, exchange, feed. */
-static bool multi_round(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
+/* one round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Partition, exchange, feed. */
+static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
 {
 	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
 	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
-	const int N = J->N, P = J->P, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
-	std::vector<std::vector<uint64_t> > bst(N, std::vector<uint64_t>(P + 1, 0));
-	std::vector<int64_t> n_rec(N, 0);
-	std::vector<char> ok(N, 1);
-	{	/* every GPU groups the k-mers of its chunk by prefix */
+	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
+	std::vector<std::vector<uint64_t> > bst(S, std::vector<uint64_t>(P + 1, 0));
+	std::vector<int64_t> n_rec(S, 0);
+	std::vector<char> ok(std::max(N, S), 1);
+	{	/* every slot groups the k-mers of its chunk by prefix */
 		std::vector<std::thread> th;
-		for (int r = 0; r < N; ++r) th.emplace_back([&, r]() {
-			if (fill[r] <= 0) return;
-			hipSetDevice(J->dev[r]);
-			n_rec[r] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
-			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data())
-			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[r], fill[r], J->d_send[r], bst[r].data());
-			if (n_rec[r] < 0) ok[r] = 0;
+		for (int s = 0; s < S; ++s) th.emplace_back([&, s]() {
+			if (fill[s] <= 0) return;
+			hipSetDevice(J->sdev[s]);
+			n_rec[s] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
+			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
+			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data());
+			if (n_rec[s] < 0) ok[s] = 0;
 		});
 		for (auto &t : th) t.join();
 	}
-	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
-	/* receive layout of owner d: the slices of source 0, 1, ... one after the other */
-	std::vector<std::vector<uint64_t> > roff(N, std::vector<uint64_t>(N + 1, 0));
+	for (int s = 0; s < S; ++s) if (!ok[s]) return false;
+	/* receive layout of a slot: for each rank it hosts (rank order), the slices of the other slots' chunks (slot order) */
+	std::vector<std::vector<uint64_t> > roff(N, std::vector<uint64_t>(S, 0));   /* roff[d][s]: where owner d's slice of chunk s lies in its slot's receive buffer (records) */
+	std::vector<uint64_t> used(S, 0);
 	for (int d = 0; d < N; ++d) {
-		const int lo = d * (P / N), hi = (d + 1) * (P / N);
-		for (int r = 0; r < N; ++r) roff[d][r + 1] = roff[d][r] + (bst[r][hi] - bst[r][lo]);
-		if ((int64_t)(roff[d][N] * W) > J->recv_words) { fprintf(stderr, "[E::yak_count] GPU %d would receive %llu records in one round: prefixes too unevenly filled for YAKAMD_MGPU_CHUNK\n", d, (unsigned long long)roff[d][N]); return false; }
+		const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
+		for (int s = 0; s < S; ++s) { if (s == sd) continue; roff[d][s] = used[sd]; used[sd] += bst[s][hi] - bst[s][lo]; }
 	}
-	if (J->use_rccl) J->R.GroupStart();
-	for (int r = 0; r < N; ++r)
-		for (int d = 0; d < N; ++d) {
-			const int lo = d * (P / N), hi = (d + 1) * (P / N);
-			const uint64_t cnt = (bst[r][hi] - bst[r][lo]) * W;
-			if (cnt == 0) continue;
-			const uint64_t *src = J->d_send[r] + bst[r][lo] * W;
-			uint64_t *dst = J->d_recv[d] + roff[d][r] * W;
-			if (J->use_rccl && r != d) {
-				if (J->R.Send(src, cnt, ncclUint64, d, J->comm[r], J->st[r]) != ncclSuccess || J->R.Recv(dst, cnt, ncclUint64, r, J->comm[d], J->st[d]) != ncclSuccess) ok[0] = 0;
-			} else {
-				hipSetDevice(J->dev[d]);
-				if (hipMemcpyPeerAsync(dst, J->dev[d], src, J->dev[r], cnt * 8, J->st[d]) != hipSuccess) ok[0] = 0;
+	for (int s = 0; s < S; ++s) if ((int64_t)(used[s] * W) > J->recv_words) { fprintf(stderr, "[E::yak_count] device %d would receive %llu records in one round: prefixes too unevenly filled for YAKAMD_MGPU_CHUNK\n", J->sdev[s], (unsigned long long)used[s]); return false; }
+	if (S > 1) {
+		if (J->use_rccl) J->R.GroupStart();
+		for (int s = 0; s < S; ++s)
+			for (int d = 0; d < N; ++d) {
+				const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
+				const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
+				if (cnt == 0 || s == sd) continue;
+				const uint64_t *src = J->d_send[x][s] + bst[s][lo] * W;
+				uint64_t *dst = J->d_recv[x][sd] + roff[d][s] * W;
+				if (J->use_rccl) {
+					if (J->R.Send(src, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess || J->R.Recv(dst, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok[0] = 0;
+				} else {
+					hipSetDevice(J->sdev[sd]);
+					if (hipMemcpyPeerAsync(dst, J->sdev[sd], src, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
+				}
 			}
-		}
-	if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
-	for (int r = 0; r < N; ++r) { hipSetDevice(J->dev[r]); if (hipStreamSynchronize(J->st[r]) != hipSuccess) ok[0] = 0; }
-	if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
-	{	/* every owner takes its slices, in chunk order = stream order */
+		if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
+		for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
+		if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
+	}
+	{	/* every owner takes its slices, in chunk order = stream order; owners that share a device take turns (a feed may count a whole slice of the pass) */
 		std::vector<std::thread> th;
-		std::vector<int> devs(J->dev); std::sort(devs.begin(), devs.end()); devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
-		for (int dv : devs) th.emplace_back([&, dv]() { for (int d = 0; d < N; ++d) if (J->dev[d] == dv) {   /* owners that share a device take turns: a feed may count a whole slice of the pass */
+		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int d = 0; d < N; ++d) if (J->slot_of[d] == sd) {
 			hipSetDevice(J->dev[d]);
 			const int lo = d * (P / N), hi = (d + 1) * (P / N);
 			std::vector<uint64_t> ob(P + 1);
-			for (int r = 0; r < N; ++r) {
-				const uint64_t cnt = roff[d][r + 1] - roff[d][r];
+			for (int s = 0; s < S; ++s) {
+				const uint64_t cnt = bst[s][hi] - bst[s][lo];
 				if (cnt == 0) continue;
-				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[r][q] - bst[r][lo]; }
-				const uint64_t *rec = J->d_recv[d] + roff[d][r] * W;
-				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r], 0)
-				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[r], (uint64_t)fill[r])
+				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[s][q] - bst[s][lo]; }
+				const uint64_t *rec = s == sd ? J->d_send[x][s] + bst[s][lo] * W : J->d_recv[x][sd] + roff[d][s] * W;   /* the slice of the device's own chunk is fed where the partition left it */
+				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s], 0)
+				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s])
 				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
 				if (rc != 0) ok[d] = 0;
 			}
+			if (hipStreamSynchronize(yk_ctx_stream(((yak_ch_ext*)e->sub[d])->ctx)) != hipSuccess) ok[d] = 0;   /* the copies out of this set's buffers are done before the set is filled again */
 		} });
 		for (auto &t : th) t.join();
 	}
@@ -1205,7 +1226,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	const int P = 1 << opt->pre;
 	yak_ch_t *h = h0;
 	const int create_new = h0 ? 0 : 1;
-	if (h0 == 0) {                                             /* N tables, one per GPU, each owning its prefix range */
+	if (h0 == 0) {                                             /* N tables, one per rank, each owning its prefix range */
 		yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
 		e->magic = EXT_MAGIC; e->n_sub = N; e->sub = (yak_ch_t**)calloc(N, sizeof(yak_ch_t*));
 		h = &e->pub;
@@ -1225,28 +1246,39 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	yak_ch_ext *e = (yak_ch_ext*)h;
 	MultiJob J;
 	bool ok = multi_open(&J, N, P, dev);
+	const int S = J.S;
 	yk_realtime();
 	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
-	std::vector<int64_t> fill(N, 0);
-	std::vector<uint64_t> t0(N, 0);
+	/* the reader fills the chunks of set `cur` while a worker thread partitions, exchanges and feeds the set before it */
+	std::vector<int64_t> fill[2] = { std::vector<int64_t>(S, 0), std::vector<int64_t>(S, 0) };
+	std::vector<uint64_t> t0[2] = { std::vector<uint64_t>(S, 0), std::vector<uint64_t>(S, 0) };
+	std::thread worker;
+	bool worker_ok = true;
+	int cur = 0;
 	uint64_t t_stream = 0;
 	int64_t n_seq_tot = 0;
-	int g = 0;                                                 /* the GPU whose chunk is being filled */
+	int g = 0;                                                 /* the slot whose chunk is being filled */
+	auto wait_worker = [&]() { if (worker.joinable()) worker.join(); if (!worker_ok) ok = false; };
 	auto round = [&]() {
-		if (ok) ok = multi_round(&J, e, opt->k, opt->pre, create_new, fill, t0);
-		std::fill(fill.begin(), fill.end(), 0); g = 0;
+		wait_worker();                                          /* at most one round in flight: its set becomes the one to fill next */
+		if (ok) {
+			const int x = cur;
+			worker = std::thread([&, x]() { worker_ok = multi_round(&J, x, e, opt->k, opt->pre, create_new, fill[x], t0[x]); });
+		}
+		cur ^= 1;
+		std::fill(fill[cur].begin(), fill[cur].end(), 0); g = 0;
 	};
 	/* a piece (whole sequences, each followed by '\n') goes to the chunk being filled; a chunk is closed between two
-	 * sequences only, so no k-mer spans two GPUs */
+	 * sequences, or inside one that is longer than a whole chunk */
 	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool {
 		n_seq_tot += ns;
 		while (n > 0 && ok) {
-			const size_t room = (size_t)(J.chunk - fill[g]);
+			const size_t room = (size_t)(J.chunk - fill[cur][g]);
 			size_t m = n, back = 0;
 			if (n > room) {
 				const void *nl = room ? memrchr(img, '\n', room) : 0;
 				if (nl) m = (size_t)((const char*)nl - img) + 1;
-				else if (fill[g] > 0) { if (++g == N) round(); continue; }
+				else if (fill[cur][g] > 0) { if (++g == S) round(); continue; }
 				else {
 					/* one sequence longer than a whole chunk (a chromosome beyond YAKAMD_MGPU_CHUNK bases): the chunk ends inside it and the
 					 * next one starts k - 1 bases earlier -- the k-mers that end in this chunk are counted here, those that end behind it
@@ -1254,19 +1286,19 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 					m = room; back = (size_t)opt->k - 1;
 				}
 			}
-			if (fill[g] == 0) t0[g] = t_stream;
-			hipSetDevice(J.dev[g]);
-			ok = hipMemcpyAsync(J.d_base[g] + fill[g], img, m, hipMemcpyHostToDevice, J.st[g]) == hipSuccess && hipStreamSynchronize(J.st[g]) == hipSuccess;
-			fill[g] += (int64_t)m;
+			if (fill[cur][g] == 0) t0[cur][g] = t_stream;
+			hipSetDevice(J.sdev[g]);
+			ok = hipMemcpyAsync(J.d_base[cur][g] + fill[cur][g], img, m, hipMemcpyHostToDevice, J.cp[g]) == hipSuccess && hipStreamSynchronize(J.cp[g]) == hipSuccess;
+			fill[cur][g] += (int64_t)m;
 			t_stream += m - back; img += m - back; n -= m - back;
-			if (fill[g] == J.chunk || n > 0) { if (++g == N) round(); }
+			if (fill[cur][g] == J.chunk || n > 0) { if (++g == S) round(); }
 		}
 		return ok;
 	};
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
 	const bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
-	if (ok && par) ok = parse_parallel(&psrc, opt->k, n_thr, take_piece);
+	if (ok && par) ok = parse_parallel(&psrc, opt->k, n_thr, take_piece) && ok;
 	else if (ok) {
 		std::vector<char> piece;
 		int64_t l, ns = 0;
@@ -1280,23 +1312,23 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		}
 		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns);
 	}
-	if (ok) { bool any = false; for (int r = 0; r < N; ++r) any = any || fill[r] > 0; if (any) round(); }
-	{	/* every GPU finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
+	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
+	wait_worker();
+	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
+	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
 		 * scratch of only one of them is alive at a time (one device posing as N = the pass in N sweeps over prefix ranges: what lets a
 		 * 5 Gb assembly through 288 GB) */
 		std::vector<int64_t> n_ins(N, 0);
 		std::vector<std::thread> th;
-		std::vector<int> devs(dev); std::sort(devs.begin(), devs.end()); devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
 		std::vector<std::string> why(N);                       /* the error text is per thread: bring it back */
-		for (int d : devs) th.emplace_back([&, d]() { for (int r = 0; r < N; ++r) if (dev[r] == d) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) why[r] = yakamd_last_error(); } });
+		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int r = 0; r < N; ++r) if (J.slot_of[r] == sd) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) why[r] = yakamd_last_error(); } });
 		for (auto &t : th) t.join();
 		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) fprintf(stderr, "[E::yak_count] rank %d of %d (device %d): %s\n", r, N, dev[r], why[r].c_str());
 		for (int r = 0; r < N; ++r) { if (n_ins[r] < 0) ok = false; else e->sub[r]->tot += (uint64_t)n_ins[r]; }
 	}
-	multi_close(&J);
 	multi_tot(h);
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
-	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, J.use_rccl ? "RCCL exchange" : "peer copies");
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? "RCCL exchange" : "peer copies");
 	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
