@@ -133,9 +133,10 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--batch-reads", type=int, default=10_000_000, help="N > 1: reads per exchange round and rank (the job's input is dealt to the ranks in chunks of this size)")
     ap.add_argument("--bf-shift", type=int, default=37)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "nofilter", "cfg4", "cfg5"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "nofilter", "cfg3shard", "cfg4", "cfg5"],
                     help="BASELINE.json configuration: cfg2 = configs[1] (default, the metric's workload); nofilter = same reads, no bloom filter, one pass; "
                          "cfg4 = configs[3], yak count -k21 on a synthetic assembly (long contigs, singletons kept); cfg5 = configs[4], lookup-only path of yak qv")
+    ap.add_argument("--of", type=int, default=8, help="cfg3shard: GPUs of the job whose rank 0 is measured on this one GPU (BASELINE configs[2]: 8)")
     ap.add_argument("--contigs", type=int, default=50, help="cfg4: number of contigs")
     ap.add_argument("--contig-len", type=int, default=100_000_000, help="cfg4: bases per contig")
     ap.add_argument("--sweeps", type=int, default=1, help="cfg4: > 1 = count through yak_count() in that many sweeps over prefix ranges (sizes beyond one pass: --contigs 50 --sweeps 8 = 5 Gb)")
@@ -155,10 +156,12 @@ def main():
     ap.add_argument("--no-retain", action="store_true", help="pass 2 extracts and hashes the input again instead of counting the records pass 1 retained")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
+    a.reads_given = any(x == "--reads" or x.startswith("--reads=") for x in sys.argv[1:])
+    a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
     if a.config == "nofilter":
         a.bf_shift = 0
-    if a.config in ("cfg4", "cfg5"):
+    if a.config in ("cfg3shard", "cfg4", "cfg5"):
         import bench_configs
         return bench_configs.run(a)
     if a.scaling == "strong":

@@ -223,13 +223,141 @@ def run_cfg5(a, torch, yak_amd):
             "verify": verify}
 
 
+def run_cfg3shard(a, torch, yak_amd):
+    """ONE rank's share of BASELINE configs[2] (600 M x 150 bp over `of` = 8 GPUs, prefix-sharded) on one GPU: the rank owns P / of sub-tables and
+    receives, round after round, the records of its prefixes from `of` sources.  Every source's chunk of reads is generated on the host (the job's
+    own read numbering: chunk c = round * of + source), partitioned on THIS device as its source would do it, and the owned slice is fed in source
+    order -- exactly what the exchange delivers (yakamd_feed_partitioned_tagged_dev).  Timed per rank: the partition of the rank's OWN chunks
+    (source 0), every feed, and the end of the pass; the other sources' partitions stand in for the peers' GPUs and are not this rank's time.
+    The 8-GPU rate printed is a PREDICTION from these per-rank times and the exchange volume, not a measurement."""
+    import bench
+    K, N_HASH, P = 31, 4, 1 << PRE
+    L = yak_amd.lib()
+    of = a.of
+    bf = a.bf_shift if a.bf_shift_given else 0                   # configs[2] is written without a filter; --bf-shift 37 runs the two-pass protocol
+    per_src = a.reads if a.reads_given else 75_000_000
+    batch = min(a.batch_reads, per_src)
+    n_rounds = -(-per_src // batch)
+    genome = 5 * per_src * of
+    ERR = 0.001                                                # SURVEY 8(d): e = 0.1 % for configs[2] (at 0.5 % an unfiltered count of 600 M reads holds ~15 G distinct k-mers: ~200 GB of slots)
+    threads = min(os.cpu_count() or 8, 64)
+    lo, hi = 0, P // of
+    rec_len = bench.READ_LEN + 1
+    B = batch * rec_len
+    h_buf = torch.empty(B, dtype=torch.uint8, pin_memory=True)
+    d_reads = torch.empty(B, dtype=torch.uint8, device="cuda:0")
+    d_rec = torch.empty(B, dtype=torch.int64, device="cuda:0")
+    h_bst = (C.c_uint64 * (P + 1))()
+    syn = bench.synth_lib()
+    if L.yakamd_tagged_ok(K, PRE) == 0:
+        raise SystemExit("tagged records not available")
+    tot_mem = torch.cuda.mem_get_info()[1]
+    min_free = [torch.cuda.mem_get_info()[0]]
+    T = {"own_partition": 0.0, "feed": 0.0, "finish": 0.0, "peer_partitions_not_counted": 0.0, "host_generation_not_counted": 0.0}
+    fed = [0]
+
+    def chunk(b, s, hashes):
+        """source s's chunk of round b on the device, partitioned; returns (records, offsets of the owned slice, stream offset)"""
+        n_reads = min(batch, per_src - b * batch)
+        tg = time.perf_counter()
+        syn.yaksynth_reads(h_buf.data_ptr(), n_reads, bench.READ_LEN, genome, 42, ERR, 0.0005, (b * of + s) * batch, threads)
+        d_reads[:n_reads * rec_len].copy_(h_buf[:n_reads * rec_len])
+        torch.cuda.synchronize()
+        T["host_generation_not_counted"] += time.perf_counter() - tg
+        tp = time.perf_counter()
+        n = (L.yakamd_partition_hashes_dev if hashes else L.yakamd_partition_tagged_dev)(K, PRE, d_reads.data_ptr(), n_reads * rec_len, d_rec.data_ptr(), h_bst)
+        torch.cuda.synchronize()
+        T["own_partition" if s == 0 else "peer_partitions_not_counted"] += time.perf_counter() - tp
+        if n < 0:
+            raise RuntimeError("partition: " + yak_amd._err())
+        bst = list(h_bst)
+        cnt = bst[hi] - bst[lo]
+        ob = (C.c_uint64 * (P + 1))(*[bst[min(max(p_, lo), hi)] - bst[lo] for p_ in range(P + 1)])
+        return d_rec.data_ptr() + 8 * bst[lo], cnt, ob, (b * of + s) * B, n_reads * rec_len
+
+    def one_pass(t, create_new):
+        if L.yakamd_pass_begin(t.h, create_new) != 0:
+            raise RuntimeError(yak_amd._err())
+        reuse = 1
+        if not create_new:
+            tf = time.perf_counter()
+            reuse = L.yakamd_count_retained(t.h)                 # 0: the records of pass 1 were kept (YAKAMD_RETAIN_GB) and are counted now
+            torch.cuda.synchronize()
+            T["feed"] += time.perf_counter() - tf
+            if reuse < 0:
+                raise RuntimeError(yak_amd._err())
+        for b in range(n_rounds if reuse else 0):
+            for s in range(of):
+                ptr, cnt, ob, t0, span = chunk(b, s, hashes=not create_new)
+                tf = time.perf_counter()
+                rc = (L.yakamd_feed_partitioned_tagged_dev(t.h, ptr, cnt, ob, t0, span, 0) if create_new else L.yakamd_count_partitioned_dev(t.h, ptr, cnt, ob)) if cnt else 0
+                torch.cuda.synchronize()
+                T["feed"] += time.perf_counter() - tf
+                if rc != 0:
+                    raise RuntimeError("feed: " + yak_amd._err())
+                fed[0] += cnt
+            min_free[0] = min(min_free[0], torch.cuda.mem_get_info()[0])
+        tf = time.perf_counter()
+        n_ins = L.yakamd_pass_end(t.h)
+        torch.cuda.synchronize()
+        T["finish"] += time.perf_counter() - tf
+        min_free[0] = min(min_free[0], torch.cuda.mem_get_info()[0])
+        if n_ins < 0:
+            raise RuntimeError("pass_end: " + yak_amd._err())
+        t.h.contents.tot += n_ins
+        return reuse == 0
+
+    t = yak_amd.Table(K, PRE, N_HASH, bf)
+    L.yakamd_set_shard(t.h, lo, hi)
+    if bf > 0:
+        L.yakamd_retain_input(t.h, 1)
+    one_pass(t, 1)
+    inst1 = fed[0]
+    pass1 = dict(T)
+    reused = None
+    if bf > 0:
+        t.destroy_bf(); t.clear()
+        reused = one_pass(t, 0)
+        tf = time.perf_counter()
+        t.shrink(2, 1023)
+        torch.cuda.synchronize()
+        T["finish"] += time.perf_counter() - tf
+    hist = (C.c_int64 * 1024)()
+    L.yak_ch_hist(t.h, hist, 1)
+    tot = t.tot
+    caps = [t.subtable(p_) for p_ in range(lo, hi)]
+    t.close()
+    rank_s = T["own_partition"] + T["feed"] + T["finish"]
+    # what the rank receives over xGMI per pass: (of - 1) / of of its records, 8 bytes each, over of - 1 point-to-point links (MI355X_MICROARCH.md: ~153 GB/s each way per link)
+    exch_s = inst1 * 8.0 * (of - 1) / of / ((of - 1) * 153e9 * 0.8) * (2 if (bf > 0 and not reused) else 1)
+    verify = {"count_mass_equals_instances": (sum(c * hist[c] for c in range(1024)) == inst1 and hist[1023] == 0) if bf == 0 else None,
+              "sum_hist_equals_tot": sum(hist) == tot, "largest_subtable_slots": max(c_ for c_, _ in caps), "distinct": tot}
+    if verify["count_mass_equals_instances"] is False or not verify["sum_hist_equals_tot"]:
+        raise SystemExit(f"FAILED: {verify}")
+    by = (32.0 if bf == 0 else (16.0 + 128.0 + 16.0 + 16.0 + 8.0 + 8.0)) * inst1
+    return {"metric": f"distinct k-mers counted/sec (k=31): ONE rank's share of a {of}-GPU prefix-sharded job, measured on one GPU", "value": tot / rank_s, "unit": "distinct k-mers/s (this rank)",
+            "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": rank_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"rank 0 of {of}: owns sub-tables [{lo}, {hi}); receives the records of its prefixes from {of} sources x {per_src} x {bench.READ_LEN} bp reads "
+                                   f"(G = {genome}, e = 0.1 %) in {n_rounds} rounds of {batch} reads per source; yak count -k{K}" + (f" -b{bf}, both passes + shrink" if bf else ", no filter"),
+                       "k": K, "pre": PRE, "bf_shift": bf, "of": of, "reads_per_source": per_src, "batch_reads": batch},
+            "rank_seconds": {k_: round(v, 3) for k_, v in T.items()}, "pass1_seconds": {k_: round(v, 3) for k_, v in pass1.items()},
+            "instances_received_per_pass": inst1, "final_distinct_this_rank": tot,
+            "peak_hbm_bytes": tot_mem - min_free[0], "pass2_counted_retained_records": reused,
+            "prediction": {"label": "PREDICTED, not measured: all ranks take this rank's time; the exchange (8-byte records over of-1 xGMI links at 80 % of 153 GB/s) is added in full, not overlapped",
+                           "exchange_seconds": exch_s, "job_seconds": rank_s + exch_s, "job_distinct_kmers_per_s": tot * of / (rank_s + exch_s),
+                           "job_reads": per_src * of},
+            "roofline": {"bound": "hbm", "kernel": "this rank's passes (own partition + feeds + finish)", "achieved": by / rank_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": by / rank_s / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "verify": verify}
+
+
 def run(a):
     import torch
     import yak_amd
     if a.gpus != 1:
-        raise SystemExit("--config cfg4 / cfg5 are single-GPU configurations")
+        raise SystemExit("--config cfg3shard / cfg4 / cfg5 are single-GPU configurations")
     if yak_amd.lib().yakamd_device_count() < 1:
         raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")
     torch.cuda.set_device(0)
-    out = run_cfg4(a, torch, yak_amd) if a.config == "cfg4" else run_cfg5(a, torch, yak_amd)
+    out = run_cfg4(a, torch, yak_amd) if a.config == "cfg4" else run_cfg3shard(a, torch, yak_amd) if a.config == "cfg3shard" else run_cfg5(a, torch, yak_amd)
     print(json.dumps(out))
