@@ -141,13 +141,17 @@ def test_cli_drop_in(ya, oracle, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BATCH="65536"), dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_COUNT_OWN="0")],
-                         ids=["one_batch", "many_batches", "budget_refuses", "count_kernel_not_applicable"])
+@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BATCH="65536"), dict(YAKAMD_CNT2_WGS="3"), dict(YAKAMD_RETAIN2="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_BATCH="65536"),
+                                 dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_COUNT_OWN="0")],
+                         ids=["subbucket_records", "subbucket_records_many_batches", "subbucket_records_3_workgroups", "prefix_records", "prefix_records_many_batches",
+                              "budget_refuses", "count_kernel_not_applicable"])
 @pytest.mark.parametrize("opt", [dict(k=31, bf_shift=24), dict(k=21, bf_shift=20), dict(k=31, bf_shift=22, n_hash=7)], ids=["k31b24", "k21b20", "k31b22H7"])
 def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch):
     """main.c:53-57: both passes read the same input.  With yakamd_retain_input the create_new pass keeps its hashed k-mers on the
-    device and the count pass counts those (yakamd_count_retained) -- or reports that nothing usable was kept and takes the input
-    again; either way the bytes are the oracle's, and the retained path must really have been taken where it applies"""
+    device -- grouped by sub-bucket together with the keys every sub-bucket put into the table (k_cnt2) when the pass was one slice into
+    an empty table, else grouped by prefix (k_img_count_own) -- and the count pass counts those (yakamd_count_retained), or reports
+    that nothing usable was kept and takes the input again; either way the bytes are the oracle's, and the retained path must really
+    have been taken where it applies"""
     L = ya.lib()
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)

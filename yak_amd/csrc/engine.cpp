@@ -219,6 +219,10 @@ struct yakamd_ctx {
 	 * the second pass of the bloom protocol (reference main.c:53-57) then neither reads nor hashes the input again */
 	struct Retained { u64 *d_rec; u64 n; std::vector<u64> bstart; };
 	std::vector<Retained> retained; bool retain_on, retain_broken; u64 retained_bytes;
+	/* ... or, when the whole pass was one slice into an empty table, its level-2 records (grouped by sub-bucket) + the keys every sub-bucket put
+	 * into the table: the count pass then owns each key's counter in LDS (k_cnt2) */
+	struct Ret2 { Rec *d_r2; u64 *d_sbstart, *d_koff, *d_kkc; FastParams fp; u64 n_total; bool valid; } ret2;
+	int n_slices;                      /* slices of the running pass counted so far (fast_flush_slice) */
 	u64 src_id[5]; bool src_set;       /* identity of the file the retained records came from + its sequence count (yak_count) */
 
 	std::mutex api_mu;                 /* serialises whole-table entry points that callers may reach from several threads (yak_ch_insert_list) */
@@ -300,6 +304,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->fast = false; c->kept_bytes = 0; c->fast_budget = 0; c->t_pass0 = 0; c->t_pass0_set = false;
 	c->host_valid = false; c->hm_keys = 0; c->hm_used = 0; c->hm_slots = 0; c->hts = 0;
 	c->retain_on = false; c->retain_broken = false; c->retained_bytes = 0; c->src_set = false;
+	memset(&c->ret2, 0, sizeof(c->ret2)); c->n_slices = 0;
 	c->dev = (int)env_i64("YAKAMD_DEVICE", 0);
 	{
 		const char *lr = getenv("LOCAL_RANK");
@@ -332,6 +337,8 @@ static void retained_drop(yakamd_ctx *c)
 {
 	for (auto &r : c->retained) dfree(r.d_rec);
 	c->retained.clear(); c->retained_bytes = 0; c->src_set = false;
+	dfree(c->ret2.d_r2); dfree(c->ret2.d_sbstart); dfree(c->ret2.d_koff); dfree(c->ret2.d_kkc);
+	c->ret2.valid = false; c->ret2.n_total = 0;
 }
 
 static void pass_free(yakamd_ctx *c)
@@ -419,6 +426,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	(void)hipGetLastError();                                   /* whatever other users of the runtime left behind is not this pass's (see yakamd_pass_end) */
 	c->create_new = create_new;
 	if (create_new) { retained_drop(c); c->retain_broken = false; }
+	c->n_slices = 0;
 	c->bloom_mode = create_new && c->has_bloom && !c->gate_off;
 	c->in_pass = true;
 	c->t_end = 0;
@@ -750,10 +758,11 @@ static int fast_abandon(yakamd_ctx *c)
 	return r;
 }
 
-static int fast_finish(yakamd_ctx *c);
+static int fast_finish(yakamd_ctx *c, bool last = false);
 static int fast_flush_slice(yakamd_ctx *c)
 {
 	if (fast_finish(c)) return -1;
+	++c->n_slices;
 	HIPCK(hipMemsetAsync(c->d_lastput, 0, c->P * 8, c->st));      /* the put-calls of the slice are accounted for */
 	HIPCK(hipMemsetAsync(c->d_counters, 0, YKC_N * 8, c->st));
 	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] slice of the pass counted early (budget / 2^32-position limit): %llu keys in the table\n", (unsigned long long)c->img_keys_total);
@@ -1017,7 +1026,7 @@ extern "C" int64_t yakamd_retained_instances(yak_ch_t *h)
 {
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || c->retain_broken) return 0;
-	u64 n = 0;
+	u64 n = c->ret2.valid ? c->ret2.n_total : 0;
 	for (auto &r : c->retained) n += r.n;
 	return (int64_t)n;
 }
@@ -1029,6 +1038,16 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass || c->create_new) return fail("yakamd_count_retained needs an open create_new = 0 pass");
 	HIPCK(hipSetDevice(c->dev));
+	if (c->ret2.valid && !c->retain_broken && env_i64("YAKAMD_RETAIN", 1) != 0) {
+		EvTimer tm(c->st);
+		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, img_view(c), c->st);
+		const double ms = tm.stop();
+		const bool bad = hipGetLastError() != hipSuccess;
+		c->st_cur.n_instances += (int64_t)c->ret2.n_total;
+		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
+		retained_drop(c);
+		return bad ? fail("the count over the retained sub-bucket records failed") : 0;
+	}
 	if (c->retained.empty() || c->retain_broken || env_i64("YAKAMD_RETAIN", 1) == 0) { retained_drop(c); return 1; }
 	{
 		int rl, rb; u32 km;
@@ -1054,7 +1073,7 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 void yk_ctx_set_source(yakamd_ctx *c, const uint64_t id[4], int64_t n_seq) { memcpy(c->src_id, id, 32); c->src_id[4] = (u64)n_seq; c->src_set = true; }
 bool yk_ctx_same_source(yakamd_ctx *c, const uint64_t id[4], int64_t *n_seq)
 {
-	if (!c->src_set || c->retained.empty() || c->retain_broken || memcmp(c->src_id, id, 32) != 0) return false;
+	if (!c->src_set || (c->retained.empty() && !c->ret2.valid) || c->retain_broken || memcmp(c->src_id, id, 32) != 0) return false;
 	*n_seq = (int64_t)c->src_id[4];
 	return true;
 }
@@ -1461,7 +1480,7 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 
 /* pass_end of the fast path: level-2 partition -> exclusive LDS counting (+ bloom gate) ->
  * per sub-table sort by insertion time -> exact layout replay */
-static int fast_finish(yakamd_ctx *c)
+static int fast_finish(yakamd_ctx *c, bool last)
 {
 	const int P = c->P;
 	u64 n_total = 0;
@@ -1547,6 +1566,7 @@ static int fast_finish(yakamd_ctx *c)
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 += c->ms_part2;
 	}
+	bool keep2 = false;
 	{
 		/* the level-1 records stay for the count pass over the same input when the caller asked for that and they fit the budget
 		 * (an eighth of the device memory unless YAKAMD_RETAIN_GB says otherwise): all of the pass's records, or none */
@@ -1556,7 +1576,10 @@ static int fast_finish(yakamd_ctx *c)
 		if (cap_gb < 0 && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = tot / 8;
 		bool keep = c->retain_on && !c->retain_broken && fmt_in == 1 && c->bloom_mode && !c->or_mode && c->retained_bytes + n_total * 8 <= budget;
 		for (auto &k : c->kept) keep = keep && k.owned;
-		if (c->retain_on && !keep && !c->kept.empty()) { c->retain_broken = true; retained_drop(c); }
+		/* the whole pass in this one slice, into an empty table: the level-2 records and the sub-buckets' key lists serve the count pass better (k_cnt2) */
+		keep2 = keep && last && c->n_slices == 0 && c->img_keys_total == 0 && fp.rec8_out && c->retained.empty() && env_i64("YAKAMD_RETAIN2", 1) != 0;
+		if (keep2) keep = false;
+		if (c->retain_on && !keep && !keep2 && !c->kept.empty()) { c->retain_broken = true; retained_drop(c); }
 		for (auto &k : c->kept) {
 			if (keep && k.n) { yakamd_ctx::Retained r; r.d_rec = (u64*)k.d_rec; r.n = k.n; r.bstart.swap(k.bstart); c->retained.push_back(std::move(r)); c->retained_bytes += k.n * 8; }
 			else if (k.owned) dfree(k.d_rec);
@@ -1610,6 +1633,7 @@ static int fast_finish(yakamd_ctx *c)
 		HIPCK(hipStreamSynchronize(c->st));
 		dfree(d_scr); dfree(d_scroff);
 	}
+	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; }
 	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
 	/* gather the fragments: keys per sub-table, then one contiguous list each */
 	std::vector<u32> m(P, 0);
@@ -1632,6 +1656,16 @@ static int fast_finish(yakamd_ctx *c)
 		u64 tot_d = 0;
 		for (int p = 0; p < P; ++p) tot_d += nd[p];
 		c->st_cur.n_distinct_seen += (int64_t)tot_d;
+	}
+	if (keep2) {
+		/* the gathered list is grouped by sub-bucket (k_lc_compact walks them in order): a copy of it + the first key of every sub-bucket */
+		if (dmalloc(&c->ret2.d_koff, n_sb + 1) || dmalloc(&c->ret2.d_kkc, n_sel)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
+		else {
+			yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
+			HIPCK(hipMemcpyAsync(c->ret2.d_kkc, kc[0], n_sel * 8, hipMemcpyDeviceToDevice, c->st));
+			c->ret2.d_sbstart = d_sbstart; d_sbstart = 0;
+			c->ret2.valid = true;
+		}
 	}
 	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist);
 	int cur = 0;
@@ -1683,7 +1717,7 @@ static int64_t pass_end_body(yakamd_ctx *c)
 		pass_free(c);
 		return fail("flag-mode loads need the exclusive-ownership path (prefix length <= 13, input within the device budget)");
 	} else if (c->fast && !c->acc.s) {
-		if (fast_finish(c)) return -1;
+		if (fast_finish(c, true)) return -1;
 		n_ins = (int64_t)(c->img_keys_total - c->keys_at_begin);   /* earlier slices of the pass included */
 		c->st_cur.n_new_keys = n_ins;
 	} else {

@@ -3841,6 +3841,123 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 	if ((fp.dbg & 128) && tid == 0) for (int i = 0; i < 7; ++i) atomicAdd(&d_lc2_prof[i], pf[i]);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * k_cnt2: the count pass (create_new = 0, reference htab.c:71-75) over the SAME input as the pass before, on the records that pass left
+ * grouped by sub-bucket (the level-2 partition) and on the list of keys every sub-bucket put into the table.  All instances of a k-mer sit
+ * in one sub-bucket, so a workgroup owns the counters of its sub-bucket's keys outright: the keys go into a small LDS set, the records are
+ * streamed once (one LDS lookup, one LDS increment per hit), and every key then adds its count to its slot of the table image (one table
+ * probe per KEY instead of one per instance; exclusive owner: a plain read-modify-write).  Persistent workgroups with the next sub-bucket's
+ * first records in flight, as in k_lc2.  A sub-bucket with more keys than the LDS set takes (other tiers of the insert kernel) looks every
+ * instance up in the image with device atomics.  k_img_fold saturates the counts afterwards.
+ * ------------------------------------------------------------------------------------------ */
+#define C2_CAP 2048
+#define C2_FULL 1280
+__global__ __launch_bounds__(256)
+void k_cnt2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict__ rec, const u64 *__restrict__ key_off, const u64 *__restrict__ key_kc,
+            ImgView img, u32 n_sb)
+{
+	__shared__ u64 s_K[C2_CAP];
+	__shared__ u32 s_C[C2_CAP];
+	__shared__ unsigned short s_slot[C2_FULL];
+	const u32 tid = threadIdx.x;
+	const u32 sb0 = (u32)fp.plo << fp.s2_bits;
+	for (u32 i = tid; i < C2_CAP; i += 256) { s_K[i] = YK_EMPTY; s_C[i] = 0; }
+	auto home = [&](u64 x) -> u32 { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 40) & (C2_CAP - 1); };
+	u32 it = blockIdx.x;
+	u64 lo = 0, hi = 0;
+	Rec r0 = make_ulonglong2(0, 0), r1 = r0, r2 = r0;
+	if (it < n_sb) {
+		lo = sbstart[sb0 + it]; hi = sbstart[sb0 + it + 1];
+		if (lo + tid < hi) r0 = lc_raw(fp, rec, lo + tid);
+		if (lo + 256 + tid < hi) r1 = lc_raw(fp, rec, lo + 256 + tid);
+		if (lo + 512 + tid < hi) r2 = lc_raw(fp, rec, lo + 512 + tid);
+	}
+	__syncthreads();
+	while (it < n_sb) {
+		const u32 sb = sb0 + it, itn = it + gridDim.x, p = sb >> fp.s2_bits;
+		const u64 ko = key_off[sb];
+		const u32 nk = (u32)(key_off[sb + 1] - ko);
+		u64 lon = 0, hin = 0;
+		if (itn < n_sb) { lon = sbstart[sb0 + itn]; hin = sbstart[sb0 + itn + 1]; }
+		const bool in_lds = nk <= C2_FULL;
+		if (in_lds) {
+			for (u32 i = tid; i < nk; i += 256) {                            /* the keys this sub-bucket put into the table */
+				const u64 x = key_kc[ko + i] >> 10;
+				u32 s = home(x);
+				for (;;) {
+					const u64 cur = atomicCAS(&s_K[s], YK_EMPTY, x);
+					if (cur == YK_EMPTY || cur == x) break;
+					s = (s + 1) & (C2_CAP - 1);
+				}
+				s_slot[i] = (unsigned short)s;
+			}
+			__syncthreads();
+		}
+		auto take = [&](const Rec rc) {
+			if (in_lds) {
+				const u64 x = rc.x >> fp.pre;
+				u32 s = home(x);
+				for (;;) {
+					const u64 cur = s_K[s];
+					if (cur == x) { atomicAdd(&s_C[s], 1u); break; }
+					if (cur == YK_EMPTY) break;
+					s = (s + 1) & (C2_CAP - 1);
+				}
+			} else {
+				const int64_t idx = img_find(img, rc.x);
+				if (idx >= 0) atomicAdd(&img.delta[idx], 1u);
+			}
+		};
+		if (lo + tid < hi) take(lc_dec(fp, r0, sb));
+		if (lo + 256 + tid < hi) take(lc_dec(fp, r1, sb));
+		if (lo + 512 + tid < hi) take(lc_dec(fp, r2, sb));
+		for (u64 i = lo + 768 + tid; i < hi; i += 256) take(lc_rec(fp, rec, i, sb));
+		/* the next sub-bucket's records travel while this one's counts go to the table */
+		if (lon + tid < hin) r0 = lc_raw(fp, rec, lon + tid);
+		if (lon + 256 + tid < hin) r1 = lc_raw(fp, rec, lon + 256 + tid);
+		if (lon + 512 + tid < hin) r2 = lc_raw(fp, rec, lon + 512 + tid);
+		__syncthreads();
+		if (in_lds) {
+			for (u32 i = tid; i < nk; i += 256) {
+				const u32 s = s_slot[i];
+				const u32 c = s_C[s];
+				if (c) {
+					const int64_t idx = img_find(img, (s_K[s] << fp.pre) | p);
+					if (idx >= 0) img.delta[idx] += c;                        /* exclusive owner of this key's instances */
+				}
+			}
+			__syncthreads();
+			for (u32 i = tid; i < nk; i += 256) { const u32 s = s_slot[i]; s_K[s] = YK_EMPTY; s_C[s] = 0; }
+		}
+		it = itn; lo = lon; hi = hin;
+		__syncthreads();
+	}
+}
+
+/* first key of every sub-bucket in the gathered (unsorted) key list: seg_base[p] + exclusive scan of nsel inside sub-table p; key_off[n_sb] = all keys */
+__global__ __launch_bounds__(256)
+void k_nsel_scan(const u32 *__restrict__ nsel, int s2_bits, int plo, int phi, int P, const u64 *__restrict__ seg_base, u64 *__restrict__ key_off)
+{
+	__shared__ u32 s_w[5];
+	const u32 p = blockIdx.x, S2 = 1u << s2_bits, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const size_t b0 = (size_t)p * S2;
+	const bool mine = (int)p >= plo && (int)p < phi;
+	u64 run = seg_base[p];
+	for (u32 j0 = 0; j0 < S2; j0 += 256) {
+		__syncthreads();
+		const u32 j = j0 + tid, n = (mine && j < S2) ? nsel[b0 + j] : 0;
+		u32 incl = n;
+		for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= (u32)o) incl += x; }
+		if (lane == 63) s_w[wave] = incl;
+		__syncthreads();
+		u32 e = incl - n, tot = 0;
+		for (u32 w = 0; w < 4; ++w) { if (w < wave) e += s_w[w]; tot += s_w[w]; }
+		if (j < S2) key_off[b0 + j] = run + e;
+		run += tot;
+	}
+	if ((int)p == P - 1 && tid == 0) key_off[(size_t)P * S2] = run;
+}
+
 /* keys selected per sub-table = sum over its sub-buckets */
 __global__ __launch_bounds__(256)
 void k_lc_sum(const u32 *__restrict__ nsel, int s2_bits, int plo, u32 *seg_cnt)
@@ -4726,6 +4843,17 @@ void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, co
 {
 	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
 }
+void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, ImgView img, hipStream_t st)
+{
+	const u32 n_sb = (u32)(fp.phi - fp.plo) << fp.s2_bits;
+	static const int wgs = getenv("YAKAMD_CNT2_WGS") ? atoi(getenv("YAKAMD_CNT2_WGS")) : 256 * 8;   /* 28 KB of LDS, 256 threads: five workgroups per CU and then some waiting */
+	hipLaunchKernelGGL(k_cnt2, dim3(std::min<u32>(n_sb, (u32)std::max(1, wgs))), dim3(256), 0, st, fp, sbstart, rec, key_off, key_kc, img, n_sb);
+}
+void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_nsel_scan, dim3(P), dim3(256), 0, st, nsel, s2_bits, plo, phi, P, seg_base, key_off);
+}
+
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st)
 {
 	if (n) hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
