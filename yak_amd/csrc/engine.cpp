@@ -221,7 +221,7 @@ struct yakamd_ctx {
 	std::vector<Retained> retained; bool retain_on, retain_broken; u64 retained_bytes;
 	/* ... or, when the whole pass was one slice into an empty table, its level-2 records (grouped by sub-bucket) + the keys every sub-bucket put
 	 * into the table: the count pass then owns each key's counter in LDS (k_cnt2) */
-	struct Ret2 { Rec *d_r2; u64 *d_sbstart, *d_koff, *d_kkc; FastParams fp; u64 n_total; bool valid; } ret2;
+	struct Ret2 { Rec *d_r2; u64 *d_sbstart, *d_koff, *d_kkc, *d_segbase; FastParams fp; u64 n_total, n_keys; bool valid; } ret2;
 	int n_slices;                      /* slices of the running pass counted so far (fast_flush_slice) */
 	u64 src_id[5]; bool src_set;       /* identity of the file the retained records came from + its sequence count (yak_count) */
 
@@ -337,7 +337,7 @@ static void retained_drop(yakamd_ctx *c)
 {
 	for (auto &r : c->retained) dfree(r.d_rec);
 	c->retained.clear(); c->retained_bytes = 0; c->src_set = false;
-	dfree(c->ret2.d_r2); dfree(c->ret2.d_sbstart); dfree(c->ret2.d_koff); dfree(c->ret2.d_kkc);
+	dfree(c->ret2.d_r2); dfree(c->ret2.d_sbstart); dfree(c->ret2.d_koff); dfree(c->ret2.d_kkc); dfree(c->ret2.d_segbase);
 	c->ret2.valid = false; c->ret2.n_total = 0;
 }
 
@@ -775,9 +775,12 @@ static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
 	const u64 cost = borrowed ? 0 : n_cap * (fmt ? 8 : 16);      /* a borrowed buffer is the caller's memory */
-	bool fits = t >= c->t_pass0 && t + n_pos - c->t_pass0 < 0xfffffff0ull && c->kept_bytes + cost <= c->fast_budget;
+	/* {hash, position} records hold 32-bit positions relative to the slice; tagged records hold no position at all (their times are ranks inside a
+	 * sub-table's stream, checked when the slice is counted), so a slice of them may span more than 2^32 stream positions */
+	const bool span_ok = fmt != 0 || t + n_pos - c->t_pass0 < 0xfffffff0ull;
+	bool fits = t >= c->t_pass0 && span_ok && c->kept_bytes + cost <= c->fast_budget;
 	if (!c->kept.empty() && c->kept.back().fmt != fmt) fits = false;   /* tagged records carry ranks, Rec records stream positions: never in one slice */
-	if (!fits && !c->kept.empty() && t >= c->t_end && n_pos < 0xfffffff0ull && cost <= c->fast_budget && !c->acc.s) {
+	if (!fits && !c->kept.empty() && t >= c->t_end && (fmt != 0 || n_pos < 0xfffffff0ull) && cost <= c->fast_budget && !c->acc.s) {
 		/* the kept batches are a complete prefix of the stream: count them now, exactly as if the pass
 		 * ended here (table, filter and counts carry over; the next slice meets them as existing state --
 		 * what the reference does chunk after chunk), and start a new slice with times relative to t */
@@ -1039,9 +1042,12 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 	if (!c || !c->in_pass || c->create_new) return fail("yakamd_count_retained needs an open create_new = 0 pass");
 	HIPCK(hipSetDevice(c->dev));
 	if (c->ret2.valid && !c->retain_broken && env_i64("YAKAMD_RETAIN", 1) != 0) {
+		u32 *d_kcnt = 0;
+		if (dmalloc(&d_kcnt, c->ret2.n_keys)) return -1;
 		EvTimer tm(c->st);
-		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, img_view(c), c->st);
+		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, c->ret2.d_segbase, d_kcnt, img_view(c), c->st);
 		const double ms = tm.stop();
+		dfree(d_kcnt);
 		const bool bad = hipGetLastError() != hipSuccess;
 		c->st_cur.n_instances += (int64_t)c->ret2.n_total;
 		c->st_cur.ms_insert += ms; c->st_cur.ms_dominant_kernel += ms; c->st_cur.n_dominant_launches += 1;
@@ -1659,11 +1665,13 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	}
 	if (keep2) {
 		/* the gathered list is grouped by sub-bucket (k_lc_compact walks them in order): a copy of it + the first key of every sub-bucket */
-		if (dmalloc(&c->ret2.d_koff, n_sb + 1) || dmalloc(&c->ret2.d_kkc, n_sel)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
+		if (dmalloc(&c->ret2.d_koff, n_sb + 1) || dmalloc(&c->ret2.d_kkc, n_sel) || dmalloc(&c->ret2.d_segbase, P + 1)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
 		else {
 			yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
 			HIPCK(hipMemcpyAsync(c->ret2.d_kkc, kc[0], n_sel * 8, hipMemcpyDeviceToDevice, c->st));
 			c->ret2.d_sbstart = d_sbstart; d_sbstart = 0;
+			HIPCK(hipMemcpyAsync(c->ret2.d_segbase, d_segbase, (P + 1) * 8, hipMemcpyDeviceToDevice, c->st));
+			c->ret2.n_keys = n_sel;
 			c->ret2.valid = true;
 		}
 	}

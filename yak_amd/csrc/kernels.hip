@@ -2321,50 +2321,95 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 	u64 *D = (A.src ? K0 : K1) + off;
 	u32 *TG = TAG + (off >> 1);
 	u32 *OC = OCC + (off >> 4);
-	if (tid == 0) {
-		/* the literal rule (khashl.h:171-189) for the scan positions below F0.  A kicked-out key leaves a tombstone: its slot still
-		 * belongs to its run.  A chain is followed while it stays inside the prefix (whose slots feed each other) and wherever it
-		 * meets the run that may touch the end of the table (that run shares its region with the table's first run: its kicked keys
-		 * must be in place, in the reference's order, before the first run's later keys).  Anywhere else the key that lands on an
-		 * unmoved key of another run just leaves its tag, exactly as in the rounds (r2_chain): that run takes its kicked keys first, in
-		 * (c, d) order, when its round comes -- the chain's remaining steps (one dependent global access each, ~log2 n of them) are
-		 * not walked by this one lane.  defer == 0: every chain to its end, wherever it goes */
-		u32 F0 = n < 8 ? n : 8;
-		while (F0 < n && S[F0 - 1] != YK_EMPTY) ++F0;               /* slot F0 - 1 unused (or F0 == n) */
-		if (F0 > R2_BASE_MAX && F0 < n) *fail = 1;
-		const u32 tail0 = n > R2_LMAX + 2 ? n - (R2_LMAX + 2) : 0;     /* a run reaching slot n - 1 starts behind this slot (longer runs are refused) */
-		for (u32 j = 0; j < F0; ++j) {
-			u64 key = S[j];
-			if (key == YK_EMPTY || key == R2_MOVED) continue;
-			u32 d = 0;
-			S[j] = R2_MOVED;
-			for (;;) {
-				u32 q = r2_home(key, nb);
-				while (D[q] != YK_EMPTY) q = (q + 1) & Nmask;
-				D[q] = key;
-				OC[q >> 5] |= 1u << (q & 31);
-				if (q >= n) break;
-				TG[q] = j << 6 | (d < 63 ? d : 63);
-				if (defer && q >= F0 && q < tail0) break;                /* the run of slot q reads the tag in its round */
-				const u64 v = S[q];
-				if (v == YK_EMPTY || v == R2_MOVED) break;
-				key = v; S[q] = R2_MOVED; ++d;                          /* an unmoved key sits there: kick it out */
+	const u32 ns = n < R2_WS ? n : R2_WS, nd = 2 * n < R2_WD ? 2 * n : R2_WD, nt = n < R2_WD ? n : R2_WD;
+	__shared__ u32 s_bail;
+	/* The literal rule (khashl.h:171-189) for the scan positions below F0.  A kicked-out key leaves a tombstone: its slot still belongs to
+	 * its run.  A chain is followed while it stays inside the prefix (whose slots feed each other) and wherever it meets the run that may
+	 * touch the end of the table (that run shares its region with the table's first run: its kicked keys must be in place, in the
+	 * reference's order, before the first run's later keys).  Anywhere else the key that lands on an unmoved key of another run just leaves
+	 * its tag, exactly as in the rounds (r2_chain): that run takes its kicked keys first, in (c, d) order, when its round comes -- the chain's
+	 * remaining steps (one dependent global access each, ~log2 n of them) are not walked by this one lane.  defer == 0: every chain to its end.
+	 * With deferred chains on a table of >= 2048 slots everything the prefix touches lies in the first few hundred slots of both tables: the
+	 * lane walks LDS copies (the new table and its tags are fresh from k_r2_dinit: no load), the OCC marks are applied afterwards.  An access
+	 * that leaves the windows after all (a long first run) drops the copies, nothing global having been written, and the lane starts over
+	 * on the arrays */
+	bool have_win = false;
+	if (defer && n >= 2048) {
+		for (u32 i = tid; i < ns; i += 256) s_S[i] = __hip_atomic_load(&S[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (u32 i = tid; i < nd; i += 256) s_D[i] = YK_EMPTY;
+		for (u32 i = tid; i < nt; i += 256) s_T[i] = R2_NONE;
+		if (tid == 0) { s_bail = 0; s_nlong = 0; }
+		__syncthreads();
+		if (tid == 0) {
+			u32 F0 = 8, nl = 0;
+			bool bail = false;
+			while (F0 < ns && s_S[F0 - 1] != YK_EMPTY) ++F0;
+			if (F0 >= ns) bail = true;
+			for (u32 j = 0; j < F0 && !bail; ++j) {
+				u64 key = s_S[j];
+				if (key == YK_EMPTY || key == R2_MOVED) continue;
+				u32 d = 0;
+				s_S[j] = R2_MOVED;
+				for (;;) {
+					u32 q = r2_home(key, nb);
+					while (q < nd && s_D[q] != YK_EMPTY) ++q;                 /* (no wrap-around this far from the end of the table) */
+					if (q >= nd || q >= nt || nl >= 256) { bail = true; break; }
+					s_D[q] = key;
+					s_long[nl++] = q;
+					s_T[q] = j << 6 | (d < 63 ? d : 63);
+					if (q >= F0) break;                                         /* the run of slot q reads the tag in its round (q is far below the table's last run) */
+					const u64 v = s_S[q];
+					if (v == YK_EMPTY || v == R2_MOVED) break;
+					key = v; s_S[q] = R2_MOVED; ++d;                           /* an unmoved key of the prefix sits there: kick it out */
+				}
 			}
+			if (bail) s_bail = 1;
+			else { for (u32 i = 0; i < nl; ++i) { const u32 q = s_long[i]; OC[q >> 5] |= 1u << (q & 31); } s_F = F0; }
 		}
-		s_F = F0;
+		__syncthreads();
+		have_win = s_bail == 0;
 	}
-	__threadfence();
-	__syncthreads();
+	if (!have_win) {
+		if (tid == 0) {
+			u32 F0 = n < 8 ? n : 8;
+			while (F0 < n && S[F0 - 1] != YK_EMPTY) ++F0;               /* slot F0 - 1 unused (or F0 == n) */
+			if (F0 > R2_BASE_MAX && F0 < n) *fail = 1;
+			const u32 tail0 = n > R2_LMAX + 2 ? n - (R2_LMAX + 2) : 0;     /* a run reaching slot n - 1 starts behind this slot (longer runs are refused) */
+			for (u32 j = 0; j < F0; ++j) {
+				u64 key = S[j];
+				if (key == YK_EMPTY || key == R2_MOVED) continue;
+				u32 d = 0;
+				S[j] = R2_MOVED;
+				for (;;) {
+					u32 q = r2_home(key, nb);
+					while (D[q] != YK_EMPTY) q = (q + 1) & Nmask;
+					D[q] = key;
+					OC[q >> 5] |= 1u << (q & 31);
+					if (q >= n) break;
+					TG[q] = j << 6 | (d < 63 ? d : 63);
+					if (defer && q >= F0 && q < tail0) break;                /* the run of slot q reads the tag in its round */
+					const u64 v = S[q];
+					if (v == YK_EMPTY || v == R2_MOVED) break;
+					key = v; S[q] = R2_MOVED; ++d;                          /* an unmoved key sits there: kick it out */
+				}
+			}
+			s_F = F0;
+		}
+		__threadfence();
+		__syncthreads();
+	}
 	u32 F = s_F;
-	if (small_f <= R2_WS / 2 && F < small_f && F < n) {
+	const bool do_small = small_f <= R2_WS / 2 && F < small_f && F < n;
+	if (have_win || do_small) {
 		/* the rounds below small_f touch old slots < 2 small_f and new slots < 4 small_f + 2 only: they run on LDS copies (a dependent
 		 * access costs ~100 cycles there instead of a trip to L2), the windows go back to the arrays afterwards */
-		const u32 ns = n < R2_WS ? n : R2_WS, nd = 2 * n < R2_WD ? 2 * n : R2_WD, nt = n < R2_WD ? n : R2_WD;
-		for (u32 i = tid; i < ns; i += 256) s_S[i] = __hip_atomic_load(&S[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		for (u32 i = tid; i < nd; i += 256) s_D[i] = __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		for (u32 i = tid; i < nt; i += 256) s_T[i] = __hip_atomic_load(&TG[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (!have_win) {
+			for (u32 i = tid; i < ns; i += 256) s_S[i] = __hip_atomic_load(&S[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (u32 i = tid; i < nd; i += 256) s_D[i] = __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (u32 i = tid; i < nt; i += 256) s_T[i] = __hip_atomic_load(&TG[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 		__syncthreads();
-		F = r2_small_rounds<false>(s_S, s_D, s_T, F, n, nb, small_f, R2_WS, s_wave, 1, s_long, &s_F, &s_dyn, &s_nlong, fail);
+		if (do_small) F = r2_small_rounds<false>(s_S, s_D, s_T, F, n, nb, small_f, R2_WS, s_wave, 1, s_long, &s_F, &s_dyn, &s_nlong, fail);
 		__syncthreads();
 		for (u32 i = tid; i < ns; i += 256) S[i] = s_S[i];
 		for (u32 i = tid; i < nd; i += 256) D[i] = s_D[i];
@@ -3854,7 +3899,7 @@ void k_lc2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict
 #define C2_FULL 1280
 __global__ __launch_bounds__(256)
 void k_cnt2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restrict__ rec, const u64 *__restrict__ key_off, const u64 *__restrict__ key_kc,
-            ImgView img, u32 n_sb)
+            ImgView img, u32 n_sb, u32 *__restrict__ key_cnt)
 {
 	__shared__ u64 s_K[C2_CAP];
 	__shared__ u32 s_C[C2_CAP];
@@ -3918,19 +3963,27 @@ void k_cnt2(FastParams fp, const u64 *__restrict__ sbstart, const Rec *__restric
 		if (lon + 512 + tid < hin) r2 = lc_raw(fp, rec, lon + 512 + tid);
 		__syncthreads();
 		if (in_lds) {
-			for (u32 i = tid; i < nk; i += 256) {
-				const u32 s = s_slot[i];
-				const u32 c = s_C[s];
-				if (c) {
-					const int64_t idx = img_find(img, (s_K[s] << fp.pre) | p);
-					if (idx >= 0) img.delta[idx] += c;                        /* exclusive owner of this key's instances */
-				}
-			}
-			__syncthreads();
-			for (u32 i = tid; i < nk; i += 256) { const u32 s = s_slot[i]; s_K[s] = YK_EMPTY; s_C[s] = 0; }
-		}
+			/* the counts go out next to the keys (coalesced); k_cnt2_apply adds them to the table image, one lane per key: the table probe is a chain
+			 * of dependent global reads that a couple of dozen lanes of this workgroup would wait for at every sub-bucket */
+			for (u32 i = tid; i < nk; i += 256) { const u32 s = s_slot[i]; key_cnt[ko + i] = s_C[s]; s_K[s] = YK_EMPTY; s_C[s] = 0; }
+		} else for (u32 i = tid; i < nk; i += 256) key_cnt[ko + i] = 0;    /* counted straight into the image */
+		(void)p;
 		it = itn; lo = lon; hi = hin;
 		__syncthreads();
+	}
+}
+
+/* counts of k_cnt2 -> table image: key i of sub-table p (the list is grouped by sub-table: seg_base) */
+__global__ __launch_bounds__(256)
+void k_cnt2_apply(const u64 *__restrict__ key_kc, const u32 *__restrict__ key_cnt, const u64 *__restrict__ seg_base, int plo, int pre, ImgView img)
+{
+	const u32 p = (u32)plo + blockIdx.y;
+	const u64 a = seg_base[p], b = seg_base[p + 1];
+	for (u64 i = a + (u64)blockIdx.x * 256 + threadIdx.x; i < b; i += (u64)gridDim.x * 256) {
+		const u32 c = key_cnt[i];
+		if (!c) continue;
+		const int64_t idx = img_find(img, (key_kc[i] >> 10) << pre | p);
+		if (idx >= 0) img.delta[idx] += c;                                /* a key occurs once in the list: nobody else touches its slot */
 	}
 }
 
@@ -4843,11 +4896,14 @@ void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, co
 {
 	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
 }
-void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, ImgView img, hipStream_t st)
+void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, hipStream_t st)
 {
 	const u32 n_sb = (u32)(fp.phi - fp.plo) << fp.s2_bits;
 	static const int wgs = getenv("YAKAMD_CNT2_WGS") ? atoi(getenv("YAKAMD_CNT2_WGS")) : 256 * 8;   /* 28 KB of LDS, 256 threads: five workgroups per CU and then some waiting */
-	hipLaunchKernelGGL(k_cnt2, dim3(std::min<u32>(n_sb, (u32)std::max(1, wgs))), dim3(256), 0, st, fp, sbstart, rec, key_off, key_kc, img, n_sb);
+	hipLaunchKernelGGL(k_cnt2, dim3(std::min<u32>(n_sb, (u32)std::max(1, wgs))), dim3(256), 0, st, fp, sbstart, rec, key_off, key_kc, img, n_sb, key_cnt);
+	const int n_p = fp.phi - fp.plo;
+	const int per = std::max(1, 8192 / std::max(1, n_p));                  /* ~8 K workgroups in all */
+	hipLaunchKernelGGL(k_cnt2_apply, dim3(per, n_p), dim3(256), 0, st, key_kc, (const u32*)key_cnt, seg_base, fp.plo, fp.pre, img);
 }
 void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st)
 {
