@@ -1498,8 +1498,14 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
 	fp.dbg = (int)env_i64("YAKAMD_DBG", 0);
 	fp.or_mode = c->or_mode;
-	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them */
-	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + 599) / 600) : 0;
+	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them.  With a filter the input is reads with
+	 * coverage (a filtered count of all-distinct k-mers keeps nothing): three times as many instances per sub-bucket still leave the distinct
+	 * k-mers far below the table's 624 (30 x coverage: ~100 distinct per 560 instances), and 2048 sub-buckets per sub-table are what the
+	 * level-2 scatter takes in one sweep -- 30 M reads: 13 -> 11 bits, its partition 124 -> ~40 ms.  A sub-bucket that does overflow goes to
+	 * the tiers behind k_lc2, as always */
+	const u64 per_sb = (u64)env_i64("YAKAMD_SB_INST", c->bloom_mode ? 1800 : 600);
+	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
+	if (c->bloom_mode && s2 < c->nb - 9 - 7 && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - 7;   /* k_lc2 stages at most 128 bloom blocks per sub-bucket */
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
 	if (s2 > 13) s2 = 13;
 	if (s2 < 0) s2 = 0;
@@ -1680,8 +1686,9 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	{
 		EvTimer tm(c->st);
 		const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
+		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= (u64)env_i64("YAKAMD_SORT_BIG", 100000);
 		for (int shift = 0; shift < tbits; shift += 8) {
-			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st);
+			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st, sort_big);
 			cur ^= 1;
 		}
 		c->st_cur.ms_sort += tm.stop();

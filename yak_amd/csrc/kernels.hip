@@ -1309,46 +1309,40 @@ void k_select_scatter(AccTab tab, int bloom_mode, const u64 *seg_off, u32 *seg_c
  * eight ballots (peers with an equal digit), per-wave digit counters live in LDS.
  * ------------------------------------------------------------------------------------------ */
 #define SS_E 8
-/* exclusive scan of n_bins (a multiple of 256) LDS counters by 256 threads; `carry` is a one-word LDS scratch */
-__device__ __forceinline__ void ss_scan(u32 *h, const int n_bins, u32 *s_w /* [5] */)
-{
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = n_bins / 256;
-	u32 t = 0;
-	for (int q = 0; q < per; ++q) t += h[per * tid + q];
-	u32 incl = t;
-	for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-	if (lane == 63) s_w[wave] = incl;
-	__syncthreads();
-	u32 e = incl - t;
-	for (int w = 0; w < wave; ++w) e += s_w[w];
-	for (int q = 0; q < per; ++q) { const u32 c = h[per * tid + q]; h[per * tid + q] = e; e += c; }
-	__syncthreads();
-}
-
-template <int BITS>   /* digit width.  8: a tile of 2048 keys leaves ~8 neighbours per digit, i.e. 64-byte runs in the output; 11-bit digits (two passes for 22-bit ranks, the first one fused
-                       * with the gather of the fragments) were measured and lost: one key per digit and tile means lone 8-byte stores, and the saved pass does not pay for them */
-__global__ __launch_bounds__(256)
+template <int BITS, int NT>   /* digit width; threads per workgroup (256, or 1024 for long segments: four times the loads in flight per sub-table).
+                               * 8 bits: a tile of NT x 8 keys leaves >= 8 neighbours per digit, i.e. 64-byte runs in the output; 11-bit digits (two passes for 22-bit
+                               * ranks, the first one fused with the gather of the fragments) were measured and lost: one key per digit and tile means lone 8-byte
+                               * stores, and the saved pass does not pay for them */
+__global__ __launch_bounds__(NT)
 void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ seg_len, const u64 *__restrict__ src_kc, const u64 *__restrict__ src_t,
                      u64 *__restrict__ dst_kc, u64 *__restrict__ dst_t, int shift)
 {
-	constexpr int NBIN = 1 << BITS, PERB = NBIN / 256;
+	constexpr int NBIN = 1 << BITS, NWV = NT / 64;
+	static_assert(NBIN == 256, "the scans below give four digits to each lane of one wave");
 	__shared__ u32 s_hist[NBIN];
-	__shared__ u32 s_wc[4][NBIN];
-	__shared__ u32 s_w[5];
+	__shared__ u32 s_wc[NWV][NBIN];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const u64 a = seg_off[blockIdx.x], len = seg_len ? (u64)seg_len[blockIdx.x] : seg_off[blockIdx.x + 1] - a;
 	if (len == 0) return;
 	if (len == 1) { if (tid == 0) { dst_kc[a] = src_kc[a]; dst_t[a] = src_t[a]; } return; }
-	for (int q = tid; q < NBIN; q += 256) s_hist[q] = 0;
+	for (int q = tid; q < NBIN; q += NT) s_hist[q] = 0;
 	__syncthreads();
-	for (u64 i = tid; i < len; i += 256) atomicAdd(&s_hist[(src_t[a + i] >> shift) & (NBIN - 1)], 1u);
+	for (u64 i = tid; i < len; i += NT) atomicAdd(&s_hist[(src_t[a + i] >> shift) & (NBIN - 1)], 1u);
 	__syncthreads();
-	ss_scan(s_hist, NBIN, s_w);
-	for (u64 tile = 0; tile < len; tile += 256 * SS_E) {
-		for (int w = 0; w < 4; ++w) for (int q = tid; q < NBIN; q += 256) s_wc[w][q] = 0;
+	if (tid < 64) {                                              /* exclusive scan of the 256 digit counts by one wave */
+		u32 v[4], t = 0;
+		for (int q = 0; q < 4; ++q) { v[q] = s_hist[4 * tid + q]; t += v[q]; }
+		u32 incl = t;
+		for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+		u32 e = incl - t;
+		for (int q = 0; q < 4; ++q) { s_hist[4 * tid + q] = e; e += v[q]; }
+	}
+	__syncthreads();
+	for (u64 tile = 0; tile < len; tile += (u64)NT * SS_E) {
+		for (int w = 0; w < NWV; ++w) for (int q = tid; q < NBIN; q += NT) s_wc[w][q] = 0;
 		__syncthreads();
 		u64 et[SS_E], ek[SS_E];
-		u32 erk[SS_E]; unsigned short edg[SS_E];
+		u32 erk[SS_E];
 #pragma unroll
 		for (int r = 0; r < SS_E; ++r) {
 			const u64 idx = tile + (u64)wave * (64 * SS_E) + r * 64 + lane;
@@ -1366,21 +1360,20 @@ void k_seg_sort_pass(const u64 *__restrict__ seg_off, const u32 *__restrict__ se
 			const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
 			if (valid && lane == leader) { old = s_wc[wave][d]; s_wc[wave][d] = old + __popcll(peers); }
 			old = __shfl(old, leader);
-			et[r] = t; ek[r] = kc; edg[r] = (unsigned short)d;
-			erk[r] = valid ? old + __popcll(peers & lanemask_lt()) : 0xffffffffu;
+			et[r] = t; ek[r] = kc;
+			erk[r] = valid ? (d << 24 | (old + __popcll(peers & lanemask_lt()))) : 0xffffffffu;
 		}
 		__syncthreads();
-		for (int q = 0; q < PERB; ++q) {	/* digits tid, tid + 256, ...: turn per-wave counts into start offsets, advance the running offset */
-			const int dg = tid + 256 * q;
-			u32 run = s_hist[dg];
-			for (int w = 0; w < 4; ++w) { const u32 c = s_wc[w][dg]; s_wc[w][dg] = run; run += c; }
-			s_hist[dg] = run;
+		if (tid < NBIN) {	/* digit `tid`: turn per-wave counts into start offsets, advance the running offset */
+			u32 run = s_hist[tid];
+			for (int w = 0; w < NWV; ++w) { const u32 c = s_wc[w][tid]; s_wc[w][tid] = run; run += c; }
+			s_hist[tid] = run;
 		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < SS_E; ++r) {
 			if (erk[r] != 0xffffffffu) {
-				const u64 d = a + s_wc[wave][edg[r]] + erk[r];
+				const u64 d = a + s_wc[wave][erk[r] >> 24] + (erk[r] & 0xffffff);
 				dst_kc[d] = ek[r]; dst_t[d] = et[r];
 			}
 		}
@@ -4618,7 +4611,7 @@ void yk_launch_select_scatter(AccTab tab, int bloom_mode, int P, const u64 *seg_
 void yk_launch_seg_sort_pass(const u64 *seg_off, int P, const u64 *src_kc, const u64 *src_t,
                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
+	hipLaunchKernelGGL((k_seg_sort_pass<8, 256>), dim3(P), dim3(256), 0, st, seg_off, (const u32*)0, src_kc, src_t, dst_kc, dst_t, shift);
 }
 
 void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const u64 *old_keys, const u32 *old_used,
@@ -4892,9 +4885,11 @@ void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int
 }
 
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
-                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st)
+                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st, int big)
 {
-	hipLaunchKernelGGL(k_seg_sort_pass<8>, dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
+	/* long segments (an assembly: ~1 M keys per sub-table): 1024 threads per sub-table */
+	if (big) hipLaunchKernelGGL((k_seg_sort_pass<8, 1024>), dim3(P), dim3(1024), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
+	else hipLaunchKernelGGL((k_seg_sort_pass<8, 256>), dim3(P), dim3(256), 0, st, seg_base, seg_cnt, src_kc, src_t, dst_kc, dst_t, shift);
 }
 void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, hipStream_t st)
 {

@@ -219,7 +219,7 @@ void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int
 void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, hipStream_t st);
 void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
-                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st);
+                              u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st, int big);
 #ifdef __cplusplus
 }
 #endif
