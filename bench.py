@@ -253,7 +253,7 @@ def main():
     def one_pass(t, create_new):
         if not sharded:
             if packed[0] is not None:
-                t.count_pass_packed(create_new, [(packed[0][0].data_ptr(), packed[0][1].data_ptr(), n_bytes, 0)])
+                t.count_pass_packed(create_new, [(packed[0][0].data_ptr(), packed[0][1].data_ptr(), n_bytes, 0)], same_input=not a.no_retain)
             else:
                 t.count_pass(create_new, [(d_reads.data_ptr(), n_bytes, 0)], same_input=not a.no_retain)
             return
@@ -480,8 +480,13 @@ def main():
     if not a.no_pcie and not sharded:
         def host_protocol():
             t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
+            if a.bf_shift > 0 and not a.no_retain:
+                L.yakamd_retain_input(t.h, 1)                       # what yak_count() does for a filtered count of one file: pass 2 crosses the bus only if nothing was kept
             for create_new in ((1, 0) if a.bf_shift > 0 else (1,)):
-                if L.yakamd_pass_begin(t.h, create_new) != 0 or L.yakamd_feed_bases_host(t.h, h_reads.data_ptr(), n_bytes, 0) != 0:
+                if L.yakamd_pass_begin(t.h, create_new) != 0:
+                    raise RuntimeError(yak_amd._err())
+                kept = L.yakamd_count_retained(t.h) if (not create_new and not a.no_retain) else 1
+                if kept < 0 or (kept and L.yakamd_feed_bases_host(t.h, h_reads.data_ptr(), n_bytes, 0) != 0):
                     raise RuntimeError(yak_amd._err())
                 n_ins = L.yakamd_pass_end(t.h)
                 t.h.contents.tot += n_ins
@@ -638,7 +643,7 @@ def main():
                      "no_bloom_step": nb_probe,
                      "pass_bytes": {"pass1": b_pass1, "pass2": b_pass2, "per_instance_pass1": b_pass1 / max(1, n1), "per_instance_pass2": (b_pass2 / n2) if n2 else None},
                      "pass_ms": {"pass1": ms_p1, "pass2": w.get("pass2"), "step": ms_step},
-                     "pass2_input": "level-1 records retained by pass 1 (same input: main.c:57)" if (s2 and not p2_extracted) else "extracted again",
+                     "pass2_input": "records retained by pass 1 (same input: main.c:57; sub-bucket records + key lists when pass 1 was one slice, else prefix-grouped records)" if (s2 and not p2_extracted) else "extracted again",
                      "dominant_kernel": {"kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
                                          "algorithmic_bytes_per_launch": dom["bytes"] / launches, "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),
                                          "achieved": ach, "frac": ach / HBM_PEAK_GBS,

@@ -26,7 +26,7 @@ def bench_line(*args):
     import yak_amd
     if yak_amd.lib().yakamd_device_count() < 1:
         pytest.skip("no MI355X visible")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-qv", "--no-pcie"] + list(args),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-qv", "--no-pcie", "--no-packed", "--no-nofilter"] + list(args),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
@@ -38,8 +38,20 @@ def test_no_filter_10m_reads_equals_reference():
     assert d["final_distinct"] > 200e6
 
 
-def test_30m_reads_sliced_pass_equals_reference():
+def test_30m_reads_equal_reference():
+    """4.5 G stream positions: one slice of tagged records (their times are ranks, not positions), pass 2 on the records pass 1 retained"""
     d = bench_line("--reads", "30000000")
+    assert d["verify"]["equals_reference"] is True
+    assert d["roofline"]["pass2_input"].startswith("records retained")
+
+
+def test_30m_reads_sliced_pass_equals_reference():
+    """the same with {hash, position} records, whose 32-bit positions force two slices: state carries over exactly as between the reference's chunks"""
+    os.environ["YAKAMD_REC8"] = "0"
+    try:
+        d = bench_line("--reads", "30000000")
+    finally:
+        del os.environ["YAKAMD_REC8"]
     assert d["verify"]["equals_reference"] is True
 
 
@@ -63,3 +75,14 @@ def test_cfg4_1gb_in_sweeps_over_prefix_ranges():
     v = d["verify"]
     assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
     assert v["distinct"] == 999771658 and v["yak_size_bytes"] == 7998181472
+
+
+def test_cfg4_5gb_assembly_in_sweeps():
+    """BASELINE configs[3] at its full size (50 contigs x 100 Mb, k = 21, 5 G distinct k-mers: a 40 GB .yak): yak_count() in 8 sweeps over prefix
+    ranges on the one device.  No reference golden exists at this size (the reference needs more host memory than the build container has):
+    the size-independent properties -- every count adds up to the instances consumed, the histogram adds up to tot, two chunkings of the
+    stream give the same counts -- and the distinct count both earlier rounds' runs agreed on"""
+    d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", "8")
+    v = d["verify"]
+    assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
+    assert v["distinct"] == 4994315360 and v["yak_size_bytes"] == 16 + 8 * 1024 + 8 * 4994315360

@@ -195,11 +195,14 @@ class Table:
         self.h.contents.tot += n_ins
         return n_ins
 
-    def count_pass_packed(self, create_new, feeds):
+    def count_pass_packed(self, create_new, feeds, same_input=False):
         """one pass over packed images: feeds = iterable of (codes_ptr, valid_ptr, n_bases, t0) (yakamd_feed_packed_dev)"""
         if self.L.yakamd_pass_begin(self.h, create_new) != 0:
             raise RuntimeError(_err())
-        for codes, valid, n, t0 in feeds:
+        r = self.L.yakamd_count_retained(self.h) if (same_input and not create_new) else 1
+        if r < 0:
+            raise RuntimeError(_err())
+        for codes, valid, n, t0 in (feeds if r else ()):
             if self.L.yakamd_feed_packed_dev(self.h, codes, valid, n, t0) != 0:
                 raise RuntimeError(_err())
         n_ins = self.L.yakamd_pass_end(self.h)

@@ -26,9 +26,6 @@
 
 static thread_local char g_err[512] = "";
 
-#ifdef R2_PROF
-extern "C" void yk_r2_prof_print(void);
-#endif
 static int fail(const char *fmt, ...)
 {
 	va_list ap;
@@ -1349,38 +1346,12 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			lap("dinit", k, bd, &tl);
 			int n_dbl = 0;
 			for (int p = 0; p < P; ++p) n_dbl += acts[k * P + p].kind == 2;
-			int cur = 0;
 			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, Fc + 2 * P, d_fail, c->st);
 			lap("dsmall", k, bd, &tl);
-			/* the rounds from there on: one launch (k_r2_double: a workgroup per sub-table walks its rounds behind workgroup barriers) ... */
-			const bool fused = yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st) == 0;
-			if (fused) { cur = 1; lap("double (fused rounds)", k, bd, &tl); }
-			else {                                                   /* ... or a launch per round (YAKAMD_R2_FUSED=0) */
-			const u64 n = 1ull << bd, SF = (u64)yk_r2_small_f();
-			HIPCK(hipMemsetAsync(misc + 2, 0, 8, c->st));           /* the two long-run counters the rounds alternate between */
-			for (u64 reach = SF; reach < 2 * n; reach <<= 1) {       /* F at least doubles... it cannot: G <= 2F; so one round per factor of two, plus slack for short rounds */
-				const u64 span = std::min<u64>(n, 2 * reach);
-				yk_r2_dround(d_tabs, da, P, (u32)span, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, Fc + (2 + cur) * P, Fc + (2 + (cur ^ 1)) * P, d_fail, spill, misc + 2 + cur, misc + 2 + (cur ^ 1), spill_cap, c->st);
-				cur ^= 1;
-			}
-			/* rounds can be shorter than a factor of two (the boundary is the last unused slot before 2F): finish whatever is left */
-			for (int extra = 0; extra < 2; ++extra) {
-				yk_r2_dround(d_tabs, da, P, (u32)n, K0, K1, TAG, OCC, Fc + cur * P, Fc + (cur ^ 1) * P, Fc + (2 + cur) * P, Fc + (2 + (cur ^ 1)) * P, d_fail, spill, misc + 2 + cur, misc + 2 + (cur ^ 1), spill_cap, c->st);
-				cur ^= 1;
-			}
-			lap("drounds", k, bd, &tl);
-#ifdef R2_PROF
-			if (prof) yk_r2_prof_print();
-#endif
-			}
-			/* every doubling sub-table must have reached its end */
-			std::vector<u32> Fh(P);
-			HIPCK(hipMemcpyAsync(Fh.data(), Fc + cur * P, P * 4, hipMemcpyDeviceToHost, c->st));
-			HIPCK(hipStreamSynchronize(c->st));
-			for (int p = 0; p < P; ++p) if (acts[k * P + p].kind == 2 && Fh[p] < (1u << acts[k * P + p].bits)) {   /* did not converge: the caller replays with k_replay */
-				if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] streaming replay: doubling of sub-table %d (2^%u slots) stopped at slot %u (step %zu, %s): falling back to k_replay\n", p, acts[k * P + p].bits, Fh[p], k, hipGetErrorString(hipGetLastError()));
-				++g_r2_refused; return 1;
-			}
+			/* the rounds from there on in one launch: a workgroup per sub-table walks its rounds behind workgroup barriers.  A sub-table that does
+			 * not reach its end raises `fail` (read once, after the last step: whatever the later steps then do is thrown away with the buffers) */
+			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st);
+			lap("double (fused rounds)", k, bd, &tl);
 		}
 		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, c->st); lap("place", k, bp, &tl); }
 	}

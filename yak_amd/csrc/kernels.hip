@@ -2411,166 +2411,8 @@ void k_r2_dsmall(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 		__syncthreads();
 	}
 	F = r2_small_rounds<true>(S, D, TG, F, n, nb, small_f, 0, s_wave, 1, s_long, &s_F, &s_dyn, &s_nlong, fail);   /* whatever is left (a run that left the window; small_f beyond the window) */
-	if (tid == 0) { Fcur[p] = F; Gcur[p] = F < n ? r2_boundary(S, F, 2 * F < n ? 2 * F : n, n) : n; }   /* the first round of k_r2_dround */
-}
-
-/* One round [F, G) of every sub-table still doubling.  A wave takes R2_CH consecutive old slots: keys and tags come
- * into LDS with coalesced loads; every key of a run that STARTS in the chunk gets its processing time from its tag and
- * goes into an LDS window of the new table by ordered probing (smallest time wins a slot, the displaced key walks
- * on): in a round no chain continues inside a run, so first come first served in sigma order IS ordered probing, and
- * the runs keep to their own regions by themselves.  A lane per key, uniform work, no dependent global access; the
- * window goes back with coalesced stores.  Slots a chain of the prefix took are marked from the OCC bits.  Runs longer
- * than R2_CHL, or touching the end of the table, are listed for k_r2_long. */
-#ifndef R2_CH
-#define R2_CH  128u
-#endif
-#define R2_CHL 32u
-#define R2_CHX (R2_CHL + 8)
-#define R2_NA  (R2_CH + R2_CHX + 1)
-#define R2_WN  (2 * (R2_CH + R2_CHX) + 2)
-#ifdef R2_PROF
-__device__ u64 d_r2_prof[8];
-#endif
-__global__ __launch_bounds__(64)
-void k_r2_dround(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail, u64 *long_list, u32 *long_n, u32 long_cap,
-                 u32 nbx, int n_tab)
-{
-	__shared__ u64 s_key[R2_NA];                                             /* s_key[x] = old slot c0 - 1 + x */
-	__shared__ u32 s_tag[R2_NA];
-	__shared__ short s_le[R2_NA], s_ne[R2_NA];                               /* last unused slot at or before x (-1: none), next unused slot at or after x (R2_NA: none) */
-	__shared__ u64 s_win[R2_WN];                                             /* (time + 1) << 32 | x; 0 = taken before this round; ~0 = free */
-	__shared__ u32 s_oc[R2_WN / 32 + 2];
-	const u32 lane = threadIdx.x;
-	/* the launch is PERSISTENT: a few thousand one-wave workgroups walk the nbx x P (chunk group, sub-table) tasks of the round.  One workgroup per
-	 * task made the big rounds (65536 workgroups living ~10 us each) wait for the dispatcher: 11 % of the wave slots busy */
-	for (u32 vt = blockIdx.x; vt < nbx * (u32)n_tab; vt += gridDim.x) {
-	const u32 p = vt / nbx, bx = vt - p * nbx;
-	const R2Act A = acts[p];
-	if (A.kind != 2) continue;
-	const u32 n = 1u << A.bits, nb = A.bits + 1, F = Fcur[p], G = Gcur[p];   /* the round's end was found by the round before (or k_r2_dsmall) */
-	if (F >= n) { if (bx == 0 && lane == 0) { Fnext[p] = F; Gnext[p] = n; } continue; }
-	const u64 off = tabs[p].off;
-	u64 *S = (A.src ? K1 : K0) + off, *D = (A.src ? K0 : K1) + off;
-	u32 *TG = TAG + (off >> 1);
-	const u32 *OC = OCC + (off >> 4);
-	if (G == 0) { if (bx == 0 && lane == 0) { *fail = 3; Fnext[p] = n; Gnext[p] = n; } continue; }
-	if (bx == 0 && lane == 0) { Fnext[p] = G; Gnext[p] = G < n ? r2_boundary(S, G, 2 * G < n ? 2 * G : n, n) : n; }   /* used slots stay used (R2_MOVED): the next boundary can be looked up now */
-	constexpr u32 PER = (R2_NA + 63) / 64, NOC = R2_WN / 32 + 2;
-	/* a workgroup (one wave) walks several chunks; the next chunk's keys, tags and OCC words travel while this one is placed */
-	u64 rk[PER]; u32 rt[PER], roc = 0;
-	auto fetch = [&](const u32 c0) {
-#pragma unroll
-		for (u32 j = 0; j < PER; ++j) {
-			const u32 sl = c0 - 1 + lane + 64 * j;                              /* c0 >= F >= 8 */
-			const u32 cl = sl < n ? sl : n - 1;
-			rk[j] = S[cl]; rt[j] = TG[cl];
-		}
-		roc = OC[((2 * c0) >> 5) + (lane < NOC ? lane : 0)];
-	};
-	u32 c0 = F + bx * R2_CH;
-#ifdef R2_PROF
-	u64 pf[6] = { 0, 0, 0, 0, 0, 0 }, tq = __builtin_readcyclecounter(), tq0 = tq;
-#define R2_LAP(i) { const u64 t_ = __builtin_readcyclecounter(); pf[i] += t_ - tq; tq = t_; }
-#else
-#define R2_LAP(i)
-#endif
-	if (c0 < G) fetch(c0);
-	while (c0 < G) {
-		const u32 w0 = 2 * c0;
-#pragma unroll
-		for (u32 j = 0; j < PER; ++j) {
-			const u32 x = lane + 64 * j, sl = c0 - 1 + x;
-			if (x < R2_NA) { s_key[x] = sl < n ? rk[j] : YK_EMPTY; s_tag[x] = sl < n ? rt[j] : R2_NONE; }
-		}
-		if (lane < NOC) s_oc[lane] = roc;
-		const u32 c1 = c0 + nbx * R2_CH;
-		if (c1 < G) fetch(c1);
-		__syncthreads();
-		R2_LAP(0)
-		for (u32 i = lane; i < R2_WN; i += 64) {
-			const u32 q = w0 + i, b = (w0 & 31) + i;
-			s_win[i] = (q < 2 * n && (s_oc[b >> 5] >> (b & 31) & 1)) ? 0ull : ~0ull;
-		}
-		__syncthreads();
-		{	/* last / next unused slot: every lane owns PER consecutive entries, the lanes are linked by a shuffle scan */
-			const u32 x0 = lane * PER;
-			int le = -1, ne = (int)R2_NA;
-			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x < R2_NA && s_key[x] == YK_EMPTY) le = (int)x; }
-			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x < R2_NA && s_key[x] == YK_EMPTY) ne = (int)x; }
-			int lei = le, nei = ne;
-			for (int o = 1; o < 64; o <<= 1) {
-				const int t = __shfl_up(lei, o), u = __shfl_down(nei, o);
-				if ((int)lane >= o && t > lei) lei = t;
-				if ((int)lane + o < 64 && u < nei) nei = u;
-			}
-			int run_le = __shfl_up(lei, 1), run_ne = __shfl_down(nei, 1);
-			if (lane == 0) run_le = -1;
-			if (lane == 63) run_ne = (int)R2_NA;
-			for (u32 j = 0; j < PER; ++j) { const u32 x = x0 + j; if (x >= R2_NA) break; if (s_key[x] == YK_EMPTY) run_le = (int)x; s_le[x] = (short)run_le; }
-			for (u32 j = PER; j-- > 0;) { const u32 x = x0 + j; if (x >= R2_NA) continue; if (s_key[x] == YK_EMPTY) run_ne = (int)x; s_ne[x] = (short)run_ne; }
-		}
-		__syncthreads();
-		R2_LAP(1)
-		const u32 lim = (G < c0 + R2_CH ? G : c0 + R2_CH) - c0;              /* runs start in [c0, c0 + lim) */
-		for (u32 x = lane + 1; x < R2_NA; x += 64) {
-			const u64 key = s_key[x];
-			if (key == YK_EMPTY) continue;
-			const int le = s_le[x], ne = s_ne[x];
-			if (le < 0 || (u32)le >= lim) continue;                             /* its run starts before / behind this chunk */
-			const u32 L = (u32)(ne - le - 1), a = c0 + (u32)le;
-			if (ne >= (int)R2_NA || L > R2_CHL || a + L >= n) {                 /* too long for the window, or it reaches the end of the table: a wave does it */
-				if ((int)x == le + 1) {
-					const u32 at = atomicAdd(long_n, 1u);
-					if (at < long_cap) long_list[at] = (u64)p << 32 | a; else *fail = 8;
-				}
-				continue;
-			}
-			if (key == R2_MOVED) continue;
-			const u32 sl = c0 - 1 + x, t = s_tag[x];
-			const u32 sig = (t != R2_NONE && (t >> 6) < sl) ? ((t & ~63u) | ((t & 63u) < 62 ? (t & 63u) + 1 : 63u)) : sl << 6;
-			u64 e = (u64)(sig + 1) << 32 | x;
-			u32 q = r2_home(key, nb) - w0;
-			for (;;) {
-				if (q >= R2_WN) { *fail = 9; break; }
-				const u64 old = atomicMin((unsigned long long*)&s_win[q], (unsigned long long)e);
-				if (old == ~0ull) break;
-				if (old > e) e = old;                                           /* we took the slot; carry the displaced later key on */
-				++q;
-			}
-		}
-		__syncthreads();
-		R2_LAP(2)
-		for (u32 i = lane; i < R2_WN; i += 64) {
-			const u64 e = s_win[i];
-			if (e == ~0ull || (e >> 32) == 0) continue;
-			const u32 q = w0 + i;
-			D[q] = s_key[(u32)e];
-			if (q < n) TG[q] = (u32)(e >> 32) - 1;
-		}
-		__syncthreads();
-		R2_LAP(3)
-		c0 = c1;
-	}
-#ifdef R2_PROF
-	if (lane == 0) { pf[4] = __builtin_readcyclecounter() - tq0; for (int i = 0; i < 5; ++i) atomicAdd(&d_r2_prof[i], pf[i]); atomicAdd(&d_r2_prof[5], 1ull); }
-#endif
-	}
-}
-
-/* the long runs of the round just launched, a wave each */
-__global__ __launch_bounds__(64)
-void k_r2_long(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TAG, const u64 *long_list, const u32 *long_n, u32 *long_n_next, u32 long_cap, u32 *fail)
-{
-	__shared__ R2Wave W;
-	const u32 nl = *long_n < long_cap ? *long_n : long_cap;
-	if (blockIdx.x == 0 && threadIdx.x == 0) *long_n_next = 0;           /* the next round counts into the other counter: no fill kernel between the rounds */
-	for (u32 j = blockIdx.x; j < nl; j += gridDim.x) {
-		const u32 p = (u32)(long_list[j] >> 32), a = (u32)long_list[j];
-		const R2Act A = acts[p];
-		const u64 off = tabs[p].off;
-		r2_wave_run<false, false>(W, (A.src ? K1 : K0) + off, (A.src ? K0 : K1) + off, TAG + (off >> 1), a, 1u << A.bits, A.bits + 1, fail);
-		__syncthreads();
-	}
+	if (tid == 0) Fcur[p] = F;                                                /* k_r2_double goes on from here */
+	(void)Gcur;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2808,7 +2650,7 @@ void k_r2_double(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, u32 *TA
 		}
 		F = G;
 	}
-	if (tid == 0) Fout[p] = F;
+	if (tid == 0) { Fout[p] = F; if (F < n) *fail = 10; }                     /* did not reach the end of the table: the host replays with k_replay */
 	if (PROF && lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&prof[i], (unsigned long long)pf[i]); atomicAdd((unsigned long long*)&prof[8], 1ull); }
 }
 
@@ -2860,10 +2702,10 @@ void k_r2_place(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, const u6
 	const u32 L = nseg > 1 ? 1u << SEGLOG : n, start = seg * L;
 	u64 *keys = (A.src ? K1 : K0) + tabs[p].off;
 	const u64 base = tabs[p].rec_off + A.i0;
-	for (u32 i = tid; i < L; i += 1024) s_own[i] = keys[start + i] != YK_EMPTY ? 0u : 0xffffffffu;
+	for (u32 i = tid; i < L; i += blockDim.x) s_own[i] = keys[start + i] != YK_EMPTY ? 0u : 0xffffffffu;
 	__syncthreads();
 	const u32 q0 = nseg > 1 ? seg_start[A.seg0 + seg] : 0, q1 = nseg > 1 ? seg_start[A.seg0 + seg + 1] : A.batch;
-	for (u32 q = q0 + tid; q < q1; q += 1024) {
+	for (u32 q = q0 + tid; q < q1; q += blockDim.x) {
 		u32 r, li;
 		if (nseg > 1) { r = pr[base + q]; li = r2_home(pk[base + q], A.bits) - start; }
 		else { r = q + 1; li = r2_home(kc[base + q], A.bits); }
@@ -2884,7 +2726,7 @@ void k_r2_place(const R2Tab *tabs, const R2Act *acts, u64 *K0, u64 *K1, const u6
 	const u64 *src = kc + base;
 	const u32 h0 = nseg > 1 ? HEAD : 0;
 	u32 *hd = head + (size_t)(A.seg0 + seg) * HEAD;
-	for (u32 i = tid; i < L; i += 1024) {
+	for (u32 i = tid; i < L; i += blockDim.x) {
 		const u32 o = s_own[i];
 		if (i < h0) hd[i] = o;                                          /* finished by k_r2_spill / k_r2_headfill */
 		else if (o != 0 && o != 0xffffffffu) keys[start + i] = src[o - 1];
@@ -4760,28 +4602,15 @@ void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1,
 int yk_r2_small_f(void)                                            /* YAKAMD_R2_SMALL_F: test / tuning knob, a power of two in [16, 4096] */
 {
 	const char *e = getenv("YAKAMD_R2_SMALL_F");
-	int v = e ? atoi(e) : yk_r2_fused() ? 16 : (int)R2_SMALL_F;   /* the fused rounds (k_r2_double) take over right behind the literal prefix: their chunk routine places a round's runs side by side where k_r2_dsmall walks them lane by lane */
+	int v = e ? atoi(e) : 16;   /* the fused rounds (k_r2_double) take over right behind the literal prefix: their chunk routine places a round's runs side by side where k_r2_dsmall walks them lane by lane */
 	if (v < 16) v = 16;
 	if (v > 4096) v = 4096;
 	while (v & (v - 1)) v &= v - 1;
 	return v;
 }
-void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail,
-                  u64 *long_list, u32 *long_n, u32 *long_n_next, u32 long_cap, hipStream_t st)
-{
-	static const u32 cpw = getenv("YAKAMD_R2_CPW") ? (u32)std::max(1, atoi(getenv("YAKAMD_R2_CPW"))) : 4;   /* chunks per wave */
-	const u32 chunks = (span + R2_CH - 1) / R2_CH;                      /* `span` old slots per sub-table at most in this round */
-	const u32 blocks = (chunks + cpw - 1) / cpw;
-	static const u32 resident = getenv("YAKAMD_R2_WGS") ? (u32)std::max(1, atoi(getenv("YAKAMD_R2_WGS"))) : 256u * 24u;   /* one-wave workgroups that fit the device at once (5.5 KB of LDS, 64 VGPRs each) */
-	const u64 tasks = (u64)blocks * (u64)P;
-	hipLaunchKernelGGL(k_r2_dround, dim3((unsigned)std::min<u64>(tasks, resident)), dim3(64), 0, st, tabs, acts, K0, K1, TAG, OCC, Fcur, Fnext, Gcur, Gnext, fail, long_list, long_n, long_cap, blocks, P);
-	hipLaunchKernelGGL(k_r2_long, dim3(256 * 16), dim3(64), 0, st, tabs, acts, K0, K1, TAG, (const u64*)long_list, (const u32*)long_n, long_n_next, long_cap, fail);
-}
-int yk_r2_fused(void) { static const int on = getenv("YAKAMD_R2_FUSED") ? atoi(getenv("YAKAMD_R2_FUSED")) : 1; return on; }
-/* the rounds of a doubling step from k_r2_dsmall's end (Fin) on in one launch (k_r2_double): n_dbl = sub-tables that double in this step.  0 = launched, 1 = switched off (YAKAMD_R2_FUSED=0) */
+/* the rounds of a doubling step from k_r2_dsmall's end (Fin) on in one launch (k_r2_double): n_dbl = sub-tables that double in this step */
 int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail, hipStream_t st)
 {
-	if (!yk_r2_fused()) return 1;
 	static const int force_nw = getenv("YAKAMD_R2_NW") ? atoi(getenv("YAKAMD_R2_NW")) : 0;
 	/* many sub-tables: 6 waves each, four workgroups per CU (all 1024 sub-tables of a default table resident at once); few, large ones (a shard of
 	 * a multi-GPU job): 16 waves each */
@@ -4804,18 +4633,6 @@ int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0
 	}
 	return 0;
 }
-#ifdef R2_PROF
-void yk_r2_prof_print(void)
-{
-	u64 h[8];
-	hipDeviceSynchronize();
-	hipMemcpyFromSymbol(h, HIP_SYMBOL(d_r2_prof), sizeof(h));
-	if (h[5]) fprintf(stderr, "[yak_amd] k_r2_dround clocks (lane 0 sums / %llu waves): load+stage %llu, window+scans %llu, probing %llu, write-back %llu, whole wave %llu\n", (unsigned long long)h[5],
-	                  (unsigned long long)(h[0] / h[5]), (unsigned long long)(h[1] / h[5]), (unsigned long long)(h[2] / h[5]), (unsigned long long)(h[3] / h[5]), (unsigned long long)(h[4] / h[5]));
-	for (int i = 0; i < 8; ++i) h[i] = 0;
-	hipMemcpyToSymbol(HIP_SYMBOL(d_r2_prof), h, sizeof(h));
-}
-#endif
 int yk_r2_seg_log(void) { const int v = getenv("YAKAMD_R2_SEG_LOG") ? atoi(getenv("YAKAMD_R2_SEG_LOG")) : R2_SEG_LOG; return v < 10 ? 10 : v > R2_SEG_LOG ? R2_SEG_LOG : v; }   /* the knob lets tests split small tables */
 int yk_r2_head(void) { const u32 seg = 1u << yk_r2_seg_log(); return (int)(seg / 2 < R2_HEAD ? seg / 2 : R2_HEAD); }
 void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
@@ -4827,7 +4644,8 @@ void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0,
 	const u32 nseg = bmax > SL ? 1u << (bmax - SL) : 1, L = bmax > SL ? 1u << SL : 1u << bmax;
 	hipMemsetAsync(spill_n, 0, 4, st);
 	if (nseg > 1) hipLaunchKernelGGL(k_r2_ppart, dim3(P), dim3(1024), 0, st, tabs, acts, kc, pk, pr, seg_start, SL);
-	hipLaunchKernelGGL(k_r2_place, dim3(nseg, P), dim3(1024), (size_t)L * 4, st, tabs, acts, K0, K1, kc, (const u64*)pk, (const u32*)pr, (const u32*)seg_start, head, spill, spill_n, spill_cap, fail, SL, HD);
+	static const int pt = getenv("YAKAMD_R2_PLACE_THREADS") ? std::min(1024, std::max(64, atoi(getenv("YAKAMD_R2_PLACE_THREADS")) & ~63)) : 1024;
+	hipLaunchKernelGGL(k_r2_place, dim3(nseg, P), dim3(pt), (size_t)L * 4, st, tabs, acts, K0, K1, kc, (const u64*)pk, (const u32*)pr, (const u32*)seg_start, head, spill, spill_n, spill_cap, fail, SL, HD);
 	if (nseg > 1) {
 		hipLaunchKernelGGL(k_r2_spill, dim3(64), dim3(256), 0, st, acts, (const u64*)spill, (const u32*)spill_n, spill_cap, head, fail, HD);
 		hipLaunchKernelGGL(k_r2_headfill, dim3(nseg, P), dim3(256), 0, st, tabs, acts, K0, K1, kc, (const u32*)head, SL, HD);

@@ -196,10 +196,7 @@ struct R2Load { u64 src_off; u32 bits, from_src, dst, pad; };
 struct R2Pub { u64 new_off; u32 bits, src; };
 void yk_r2_dinit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, hipStream_t st);
 void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *Fcur, u32 *Gcur, u32 *fail, hipStream_t st);
-void yk_r2_dround(const R2Tab *tabs, const R2Act *acts, int P, u32 span, u64 *K0, u64 *K1, u32 *TAG, const u32 *OCC, const u32 *Fcur, u32 *Fnext, const u32 *Gcur, u32 *Gnext, u32 *fail,
-                  u64 *long_list, u32 *long_n, u32 *long_n_next, u32 long_cap, hipStream_t st);
 int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, const u32 *Fin, u32 *Fout, u32 *fail, hipStream_t st);
-int yk_r2_fused(void);
 void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
                  u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, hipStream_t st);
 void yk_r2_load(const R2Tab *tabs, const R2Load *ld, int P, u32 bmax, const u64 *src1, const u64 *src2, u64 *K0, u64 *K1, hipStream_t st);
