@@ -12,7 +12,7 @@ all: lib cli tools oracle
 lib: yak_amd/libyak_amd.so
 cli: yak_amd/yak-amd
 
-yak_amd/kernels.o: $(CSRC)/kernels.hip $(CSRC)/yk_device.h
+yak_amd/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/kern_*.inc) $(CSRC)/yk_device.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 yak_amd/engine.o: $(CSRC)/engine.cpp $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
