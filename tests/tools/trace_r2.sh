@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2trace; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/raw -o t -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-qv --no-pcie > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/raw -o t -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-qv --no-pcie --no-packed --no-nofilter > /dev/null 2>&1
 python3 - $O <<'PY'
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "raw", "**", "*kernel_trace.csv"), recursive=True)[0]
@@ -12,7 +12,7 @@ out = []
 prev_end = None
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    if n.startswith(("k_r2_", "k_replay", "k_seg_sort", "k_shrink", "k_lc_", "__amd_rocclr_fill")):
+    if n.startswith(("k_r2_", "k_replay", "k_seg_sort", "k_shrink", "k_lc_", "k_cnt2", "k_nsel", "__amd_rocclr_fill")):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - prev_end) / 1e3 if prev_end else 0
         out.append("%-18s %8.1f us  gap %6.1f us  grid %s" % (n[:18], (e - s) / 1e3, gap, r.get("Grid_Size_X", "") + "x" + r.get("Grid_Size_Y", "")))
