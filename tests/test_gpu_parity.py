@@ -310,7 +310,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_REC8="0"), dict(YAKAMD_REC8_OUT="0"), dict(YAKAMD_REC8_OUT="0", YAKAMD_BATCH="16384"), dict(YAKAMD_BATCH="8192", YAKAMD_S2_BITS="3"),
                                  dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
-                                 dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576")],
+                                 dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576"),
+                                 dict(YAKAMD_S2_BITS="0", YAKAMD_OVF_SCRATCH_WORDS="200000"), dict(YAKAMD_SLICE_SB="1", YAKAMD_BATCH="65536")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
                               "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
@@ -318,7 +319,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
                               "lc2_three_persistent_workgroups", "pass2_plain_hashes", "pass2_plain_hashes_cross_sweep", "replay_prefix_16", "replay_prefix_1024",
                               "rec16_records", "tagged_in_rec16_out", "tagged_in_rec16_out_multibatch", "tagged_multibatch_s2_3",
-                              "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices"])
+                              "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices",
+                              "lds_overflow_to_global_in_groups", "slices_cut_by_sub_bucket_load"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""

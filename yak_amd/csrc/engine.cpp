@@ -771,11 +771,24 @@ static int fast_flush_slice(yakamd_ctx *c)
 static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec *borrowed = 0, int fmt = 0)
 {
 	if (!c->t_pass0_set) { c->t_pass0 = t; c->t_pass0_set = true; }
-	const u64 cost = borrowed ? 0 : n_cap * (fmt ? 8 : 16);      /* a borrowed buffer is the caller's memory */
+	/* what a kept record costs against the budget (a quarter of the free memory): its 16 bytes, or for an 8-byte tagged record 12 -- the count of
+	 * the slice holds 24-32 bytes per record at its peak (level-2 records, 8 or 16 bytes when the ranks outgrow their field, + 16 of key / time
+	 * output), so that a slice admitted by records x 12 <= free / 4 peaks at two thirds of the free memory.  (Tagged slices used to be cut by the
+	 * 2^32-position limit long before memory mattered; a rank of an 8-GPU job feeds 9 G records.)  A borrowed buffer is the caller's memory */
+	const u64 cost = borrowed ? 0 : n_cap * (fmt ? 12 : 16);
 	/* {hash, position} records hold 32-bit positions relative to the slice; tagged records hold no position at all (their times are ranks inside a
 	 * sub-table's stream, checked when the slice is counted), so a slice of them may span more than 2^32 stream positions */
 	const bool span_ok = fmt != 0 || t + n_pos - c->t_pass0 < 0xfffffff0ull;
 	bool fits = t >= c->t_pass0 && span_ok && c->kept_bytes + cost <= c->fast_budget;
+	if (fits && !c->kept.empty()) {
+		/* the count of a slice cuts a sub-table into at most 2^13 sub-buckets, each meant to hold what one workgroup's LDS table takes (fast_finish):
+		 * a slice stops growing where its sub-tables would outgrow that.  Unsharded that is > 5 G records; an 8-GPU rank (an eighth of the
+		 * sub-tables, 9 G records of 600 M reads) reaches it every ~700 M records -- the 2^32-position limit used to cut there by accident */
+		u64 kept_n = 0;
+		for (auto &k : c->kept) kept_n += k.n;
+		const u64 per_sb = (u64)env_i64("YAKAMD_SB_INST", c->bloom_mode ? 1800 : 600);
+		if (kept_n + n_cap > (u64)(c->phi - c->plo) * (u64)env_i64("YAKAMD_SLICE_SB", 8192) * per_sb) fits = false;
+	}
 	if (!c->kept.empty() && c->kept.back().fmt != fmt) fits = false;   /* tagged records carry ranks, Rec records stream positions: never in one slice */
 	if (!fits && !c->kept.empty() && t >= c->t_end && (fmt != 0 || n_pos < 0xfffffff0ull) && cost <= c->fast_budget && !c->acc.s) {
 		/* the kept batches are a complete prefix of the stream: count them now, exactly as if the pass
@@ -1602,19 +1615,30 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		std::vector<u64> sbs(n_sb + 1), off(n_ovf);
 		HIPCK(hipMemcpy(ovf.data(), d_ovf2, n_ovf * 4, hipMemcpyDeviceToHost));
 		HIPCK(hipMemcpy(sbs.data(), d_sbstart, (n_sb + 1) * 8, hipMemcpyDeviceToHost));
-		u64 words = 0;
-		for (u32 i = 0; i < n_ovf; ++i) {
-			const u64 n = sbs[ovf[i] + 1] - sbs[ovf[i]];
-			u64 cap = 4096; while (cap < 2 * n) cap <<= 1;
-			off[i] = words; words += 5 * cap;               /* 40 B per slot = 5 u64 */
+		/* scratch tables of 40 B per slot (5 u64), in groups of sub-buckets that stay within a quarter of the free memory */
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) return fail("hipMemGetInfo failed");
+		const u64 max_words = (u64)env_i64("YAKAMD_OVF_SCRATCH_WORDS", (int64_t)(std::max<u64>(fr / 4, (u64)1 << 28) / 8));
+		if (dmalloc(&d_scroff, n_ovf)) return -1;
+		for (u32 i0 = 0; i0 < n_ovf;) {
+			u64 words = 0;
+			u32 i1 = i0;
+			for (; i1 < n_ovf; ++i1) {
+				const u64 n = sbs[ovf[i1] + 1] - sbs[ovf[i1]];
+				u64 cap = 4096; while (cap < 2 * n) cap <<= 1;
+				if (i1 > i0 && words + 5 * cap > max_words) break;
+				off[i1] = words; words += 5 * cap;
+			}
+			if (dmalloc(&d_scr, words)) return -1;
+			HIPCK(hipMemcpyAsync(d_scroff + i0, off.data() + i0, (size_t)(i1 - i0) * 8, hipMemcpyHostToDevice, c->st));
+			EvTimer tm(c->st);
+			yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, d_ovf2 + i0, i1 - i0, d_scroff + i0, d_scr, c->st);
+			c->st_cur.ms_insert += tm.stop();
+			HIPCK(hipStreamSynchronize(c->st));
+			dfree(d_scr); d_scr = 0;
+			i0 = i1;
 		}
-		if (dmalloc(&d_scr, words) || dmalloc(&d_scroff, n_ovf)) return -1;
-		HIPCK(hipMemcpyAsync(d_scroff, off.data(), n_ovf * 8, hipMemcpyHostToDevice, c->st));
-		EvTimer tm(c->st);
-		yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, d_ovf2, n_ovf, d_scroff, d_scr, c->st);
-		c->st_cur.ms_insert += tm.stop();
-		HIPCK(hipStreamSynchronize(c->st));
-		dfree(d_scr); dfree(d_scroff);
+		dfree(d_scroff); d_scroff = 0;
 	}
 	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; }
 	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
@@ -1657,7 +1681,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	{
 		EvTimer tm(c->st);
 		const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
-		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= (u64)env_i64("YAKAMD_SORT_BIG", 100000);
+		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= (u64)env_i64("YAKAMD_SORT_BIG", 30000);
 		for (int shift = 0; shift < tbits; shift += 8) {
 			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st, sort_big);
 			cur ^= 1;
