@@ -16,6 +16,7 @@
  */
 #include "yk_device.h"
 #include <algorithm>
+#include <type_traits>
 
 #define WAVE 64
 
@@ -49,6 +50,20 @@ __device__ __forceinline__ u64 yk_rev2(u64 w)
 	u64 r = __brevll(w);
 	return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
 }
+
+/* A pointer read from a structure in memory has no known address space: the compiler then uses FLAT loads, which count on the LDS counter as
+ * well -- every wait for an LDS result also waits for the global load, and a prefetch hides nothing.  Device buffers are global memory: say so */
+#define YK_GLOBAL __attribute__((address_space(1)))
+#define yk_global(T, p) ((const T YK_GLOBAL*)(p))
+#define yk_global_rw(T, p) ((T YK_GLOBAL*)(p))
+typedef u64 yk_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Rec yk_global_rec(const Rec *p, u64 i)                  /* one 16-byte global load */
+{
+	const yk_u64x2 v = ((const yk_u64x2 YK_GLOBAL*)p)[i];
+	return make_ulonglong2(v.x, v.y);
+}
+#define YK_LDS __attribute__((address_space(3)))
+#define yk_lds_rw(T, p) ((T YK_LDS*)(p))                                           /* "LDS or global" stores would otherwise be merged into one FLAT store */
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1; }
 
