@@ -142,9 +142,11 @@ def test_cli_drop_in(ya, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BATCH="65536"), dict(YAKAMD_CNT2_WGS="3"), dict(YAKAMD_RETAIN2="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_BATCH="65536"),
-                                 dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_COUNT_OWN="0")],
+                                 dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_COUNT_OWN="0"),
+                                 dict(YAKAMD_CNT2_SMALL="-1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_S2_BITS="0", big="1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_CNT2_WGS="2")],
                          ids=["subbucket_records", "subbucket_records_many_batches", "subbucket_records_3_workgroups", "prefix_records", "prefix_records_many_batches",
-                              "budget_refuses", "count_kernel_not_applicable"])
+                              "budget_refuses", "count_kernel_not_applicable",
+                              "subbucket_records_big_lds_table", "subbucket_records_small_lds_table_overfull", "subbucket_records_small_lds_table"])
 @pytest.mark.parametrize("opt", [dict(k=31, bf_shift=24), dict(k=21, bf_shift=20), dict(k=31, bf_shift=22, n_hash=7)], ids=["k31b24", "k21b20", "k31b22H7"])
 def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch):
     """main.c:53-57: both passes read the same input.  With yakamd_retain_input the create_new pass keeps its hashed k-mers on the
@@ -153,9 +155,13 @@ def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, or
     that nothing usable was kept and takes the input again; either way the bytes are the oracle's, and the retained path must really
     have been taken where it applies"""
     L = ya.lib()
+    env = dict(env)
+    big = env.pop("big", None)                                 # ~390 keys per sub-bucket (one sub-bucket per sub-table): more than the small LDS table of k_cnt2 takes
+    if big and opt["k"] != 31:
+        pytest.skip("one size is enough")
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
-    img = synth(9000, g=40000, s=19)
+    img = synth(40000, g=400000, s=23) if big else synth(9000, g=40000, s=19)
     want, wtot = oracle.count_protocol_mem(img, **opt)
     d = L.yakamd_dev_alloc(len(img) + 64)
     assert L.yakamd_memcpy_h2d(d, img, len(img)) == 0

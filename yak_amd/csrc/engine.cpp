@@ -1055,7 +1055,7 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 		u32 *d_kcnt = 0;
 		if (dmalloc(&d_kcnt, c->ret2.n_keys)) return -1;
 		EvTimer tm(c->st);
-		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, c->ret2.d_segbase, d_kcnt, img_view(c), c->st);
+		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, c->ret2.d_segbase, d_kcnt, img_view(c), c->ret2.n_keys, c->st);
 		const double ms = tm.stop();
 		dfree(d_kcnt);
 		const bool bad = hipGetLastError() != hipSuccess;
