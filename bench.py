@@ -560,7 +560,7 @@ def main():
     ]
     if s2:
         st_after = last_stats[0]
-        kern.append({"kernel": "k_img_count_own (pass 2 lookup)", "ms": s2["ms_insert"], "launches": max(1, s2["n_dominant_launches"]),
+        kern.append({"kernel": "k_cnt2 + k_img_count_own (pass 2: k_cnt2 and k_cnt2_apply on the records pass 1 retained by sub-bucket, else k_img_count_own)", "ms": s2["ms_insert"], "launches": max(1, s2["n_dominant_launches"]),
                      "bytes": (B_LOOKUP + 8.0 * f_hit) * n2})
         kern.append({"kernel": "k_r2_* + k_replay (exact khashl layout: pass 1 + shrink)", "ms": s1["ms_replay"] + st_after["ms_shrink"],
                      "launches": 2, "bytes": 16.0 * (s1["n_new_keys"] + tot_all / max(1, world))})

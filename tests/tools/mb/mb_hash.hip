@@ -1,5 +1,5 @@
 // microbenchmark: yak_hash64 (k = 31 mask) as the compiler lowers it (64-bit multiply-adds for x + (x << a) + (x << b)) against explicit
-// shift-adds (v_lshl_add_u64).  build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 tests/tools/mb_hash.hip -o /tmp/mb_hash && /tmp/mb_hash
+// shift-adds (v_lshl_add_u64).  build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 tests/tools/mb/mb_hash.hip -o /tmp/mb_hash && /tmp/mb_hash
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef unsigned long long u64;

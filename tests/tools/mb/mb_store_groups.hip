@@ -1,5 +1,5 @@
 // microbenchmark: rate of aligned group stores to scattered addresses (G lanes x 8 bytes per group), the write pattern of the partition kernels.
-// build: hipcc --offload-arch=gfx950 -O3 tests/tools/mb_scatter.hip -o gpurun_out/mb_scatter ; run: gpurun_out/mb_scatter
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 tests/tools/mb/mb_store_groups.hip -o /tmp/mb && /tmp/mb   (write-only; mb_scatter.hip next to it copies, i.e. reads too)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
