@@ -27,7 +27,7 @@ def cfg45(tmp):
     """goldens for bench.py --config cfg4 / cfg5 -> tests/golden/cfg45_full.json (reference binary, build container)"""
     dst = os.path.join(ROOT, "tests", "golden", "cfg45_full.json")
     res = json.load(open(dst)) if os.path.exists(dst) else {}
-    for nc, cl in ((4, 50_000_000), (10, 100_000_000)):        # 0.2 Gb (quick) and 1 Gb (the largest the 62 GB container takes comfortably)
+    for nc, cl in ((4, 50_000_000), (10, 100_000_000), (20, 100_000_000)):        # 0.2 Gb (quick), 1 Gb, and 2 Gb (35 GB of tables: what the 62 GB container still takes)
         name = f"cfg4_{nc}x{cl}"
         if name in res:
             continue
