@@ -6,7 +6,7 @@ regenerates from a seed: nothing of the reference is needed at run time.  bench.
 with them (`verify.equals_reference`) and exits non-zero on a mismatch; here each workload is one bench step.
   * no filter, 10 M reads: 217 M distinct k-mers, one pass, every instance a put-call (htab.c:66-69);
   * 30 M reads with the filter: 4.5 G stream positions, a pass counted in two slices (> 2^32 - 16 positions);
-  * cfg4 at 1 Gb (10 x 100 Mb contigs, k = 21, count.c:28-43,120-125): sub-tables of 2 Mi slots, streaming replay
+  * cfg4 at 1 Gb and 2 Gb (10 / 20 x 100 Mb contigs, k = 21, count.c:28-43,120-125): sub-tables of 2 / 4 Mi slots, streaming replay
     through five doublings beyond the LDS-resident sizes;
   * cfg5: `yak qv -p` CT histogram of 75 K x 20 kb reads against the cfg2 table (qv.c:34-135).
 """
@@ -62,6 +62,15 @@ def test_cfg4_1gb_assembly_equals_reference():
     assert v["yak_size_bytes"] == 7998181472                   # = 16 + 8 P + 8 D, the reference's file size
 
 
+def test_cfg4_2gb_assembly_equals_reference():
+    """twice that: 20 x 100 Mb, 2.0 G distinct 21-mers in 4 Mi-slot sub-tables, 4096 sub-buckets per sub-table (the level-2 scatter in two
+    sweeps), a 16 GB .yak -- the largest size the reference itself could be run on in the build container (35 GB of tables in 62 GB)"""
+    d = bench_line("--config", "cfg4", "--contigs", "20", "--contig-len", "100000000")
+    v = d["verify"]
+    assert v["equals_reference"] is True and v["sum_sizes_equals_tot"] and v["count_mass_equals_instances"] and v["load_rule"]
+    assert v["yak_size_bytes"] == 15992705192
+
+
 def test_cfg5_qv_histogram_equals_reference():
     d = bench_line("--config", "cfg5")
     assert d["verify"]["equals_reference"] is True and d["verify"]["kmers"] == d["verify"]["kmers_expected"]
@@ -79,10 +88,12 @@ def test_cfg4_1gb_in_sweeps_over_prefix_ranges():
 
 def test_cfg4_5gb_assembly_in_sweeps():
     """BASELINE configs[3] at its full size (50 contigs x 100 Mb, k = 21, 5 G distinct k-mers: a 40 GB .yak): yak_count() in 8 sweeps over prefix
-    ranges on the one device.  No reference golden exists at this size (the reference needs more host memory than the build container has):
+    ranges on the one device, and in the 4 the library picks by itself for a file of that size.  No reference golden exists at this size (the
+    reference needs more host memory than the build container has; 2 Gb is checked against it, above):
     the size-independent properties -- every count adds up to the instances consumed, the histogram adds up to tot, two chunkings of the
     stream give the same counts -- and the distinct count both earlier rounds' runs agreed on"""
-    d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", "8")
-    v = d["verify"]
-    assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
-    assert v["distinct"] == 4994315360 and v["yak_size_bytes"] == 16 + 8 * 1024 + 8 * 4994315360
+    for sweeps in ("4", "8"):
+        d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", sweeps)
+        v = d["verify"]
+        assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
+        assert v["distinct"] == 4994315360 and v["yak_size_bytes"] == 16 + 8 * 1024 + 8 * 4994315360

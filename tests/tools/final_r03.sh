@@ -13,7 +13,9 @@ timeout 600 python bench.py --reads 30000000 $Q > $O/bench_30m.json 2> /dev/null
 timeout 600 python bench.py --no-retain $Q --no-verify > $O/bench_noretain.json 2> /dev/null
 timeout 900 python bench.py --config cfg3shard > $O/bench_cfg3shard.json 2> $O/bench_cfg3shard.err
 timeout 900 python bench.py --config cfg4 --contigs 50 --sweeps 8 > $O/bench_cfg4_5gb_sweeps8.json 2> /dev/null
-for f in default nofilter cfg4_1gb cfg5 30m noretain cfg3shard cfg4_5gb_sweeps8; do python3 - $O/bench_$f.json <<'PY'
+timeout 900 python bench.py --config cfg4 --contigs 50 --sweeps 4 > $O/bench_cfg4_5gb_sweeps4.json 2> /dev/null
+timeout 600 python bench.py --config cfg4 --contigs 20 --contig-len 100000000 > $O/bench_cfg4_2gb.json 2> /dev/null
+for f in default nofilter cfg4_1gb cfg4_2gb cfg5 30m noretain cfg3shard cfg4_5gb_sweeps8 cfg4_5gb_sweeps4; do python3 - $O/bench_$f.json <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])

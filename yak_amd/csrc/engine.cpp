@@ -1277,14 +1277,21 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		}
 	}
 	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
-	if ((par && dmalloc(&sp, 2 * tot_ext)) || dmalloc(&nk, tot_ext) || dmalloc(&nu, tot_ext / 32 + 1) || dmalloc(&su, tot_ext / 32 + 1) || dmalloc(&so, tot_ext) || dmalloc(&nd, tot) ||
+	/* k_replay's scratch arrays (ranks, second bitmap, doubling lists: 28 bytes per slot) are indexed by arena offsets.  When every sub-table it
+	 * touches is a large one -- an assembly, any pass of a big count -- it only works in the side arena behind the final one, so the arrays
+	 * cover that alone and are addressed from `tot` on: at 2 G keys they were 85 GB that nothing touched, more than the pool could keep, and the
+	 * hipMalloc / hipFree of them cost 5 s per pass (the kernels of the whole layout stage: 0.28 s) */
+	bool only_side = true;
+	for (int p = 0; p < P; ++p) if (!large[p] && (m[p] || cap0[p])) only_side = false;
+	const u64 scr_lo = only_side ? tot : 0, scr_n = tot_ext - scr_lo;
+	if ((par && dmalloc(&sp, 2 * scr_n)) || dmalloc(&nk, tot_ext) || dmalloc(&nu, tot_ext / 32 + 1) || dmalloc(&su, scr_n / 32 + 1) || dmalloc(&so, scr_n) || dmalloc(&nd, tot) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
 	HIPCK(hipMemsetAsync(nk, 0xff, tot_ext * 8, c->st));
 	HIPCK(hipMemsetAsync(nu, 0, (tot_ext / 32 + 1) * 4, c->st));
 	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
 	if (d_lastput) HIPCK(hipMemcpyAsync(d_lp2, lp_host.data(), P * 8, hipMemcpyHostToDevice, c->st));
-	legacy_replay_launch(c, tasks, d_tasks, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput ? d_lp2 : 0, d_ob, d_oc);
+	legacy_replay_launch(c, tasks, d_tasks, nk, nu, su - scr_lo / 32, so - scr_lo, sp ? sp - 2 * scr_lo : 0, d_rec_kc, d_rec_t, d_lastput ? d_lp2 : 0, d_ob, d_oc);
 	std::vector<u32> ob(P), oc(P);
 	HIPCK(hipMemcpyAsync(ob.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipMemcpyAsync(oc.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));

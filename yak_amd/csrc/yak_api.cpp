@@ -1045,7 +1045,8 @@ struct MultiJob {
 
 /* no filter + a plain file of more than YAKAMD_AUTO_SWEEP_GB (2.5) GB: nearly every k-mer instance may be a key of its own (an assembly),
  * and one pass holds ~100 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
- * prefix ranges (N so that a sweep sees ~0.7 G positions of its own).  YAKAMD_GPUS set to anything switches the rule off */
+ * prefix ranges (N so that a sweep sees at most ~1.4 G positions of its own: 5 Gb in 4 sweeps, measured 3.8 s against 4.1 s in 8 and 9.7 s in 2,
+ * where two ranks' tables and one rank's layout buffers no longer fit together).  YAKAMD_GPUS set to anything switches the rule off */
 static int auto_sweeps(const yak_copt_t *opt, const char *fn)
 {
 	if (fn == 0 || strcmp(fn, "-") == 0 || opt->bf_shift > opt->pre) return 1;
@@ -1061,7 +1062,7 @@ static int auto_sweeps(const yak_copt_t *opt, const char *fn)
 	::close(f);
 	if (gz) return 1;                                           /* compressed: the size says little; the knob is there */
 	int N = 2;
-	while (N < 16 && (double)sb.st_size / N > 0.7e9) N <<= 1;
+	while (N < 16 && (double)sb.st_size / N > 1.4e9) N <<= 1;
 	return (1 << opt->pre) % N ? 1 : N;
 }
 
