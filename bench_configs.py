@@ -103,7 +103,9 @@ def run_cfg4_sweeps(a, yak_amd):
 
 def run_cfg4(a, torch, yak_amd):
     if a.sweeps == 1 and a.contigs * a.contig_len > 2_500_000_000:
-        a.sweeps = 8                                           # beyond one pass's memory (the default 50 x 100 Mb = BASELINE configs[3])
+        a.sweeps = 2                                           # beyond one pass's memory: the library's own rule (yak_api.cpp auto_sweeps: at most 1.4 GB of input per sweep) --
+        while a.sweeps < 16 and a.contigs * a.contig_len / a.sweeps > 1.4e9:
+            a.sweeps *= 2                                      # the default 50 x 100 Mb = BASELINE configs[3] runs in 4
     if a.sweeps > 1:
         return run_cfg4_sweeps(a, yak_amd)
     K = 21

@@ -1695,6 +1695,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		}
 		c->st_cur.ms_sort += tm.stop();
 	}
+	dfree(kc[cur ^ 1]); dfree(tt[cur ^ 1]);                     /* the sort's other buffer pair: 16 bytes per key the layout stage can use */
 	{
 		EvTimer tm(c->st);
 		ro.resize(P);
