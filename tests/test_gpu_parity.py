@@ -143,10 +143,12 @@ def test_cli_drop_in(ya, oracle, tmp_path):
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BATCH="65536"), dict(YAKAMD_CNT2_WGS="3"), dict(YAKAMD_RETAIN2="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_RETAIN_GB="0"), dict(YAKAMD_RETAIN2="0", YAKAMD_COUNT_OWN="0"),
-                                 dict(YAKAMD_CNT2_SMALL="-1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_S2_BITS="0", big="1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_CNT2_WGS="2")],
+                                 dict(YAKAMD_CNT2_SMALL="-1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_S2_BITS="0", big="1"), dict(YAKAMD_CNT2_SMALL="1000000", YAKAMD_CNT2_WGS="2"),
+                                 dict(YAKAMD_LC_FLAT="1"), dict(YAKAMD_S2_BITS="8", YAKAMD_P3_MIN="3", YAKAMD_P3_LOW="4")],
                          ids=["subbucket_records", "subbucket_records_many_batches", "subbucket_records_3_workgroups", "prefix_records", "prefix_records_many_batches",
                               "budget_refuses", "count_kernel_not_applicable",
-                              "subbucket_records_big_lds_table", "subbucket_records_small_lds_table_overfull", "subbucket_records_small_lds_table"])
+                              "subbucket_records_big_lds_table", "subbucket_records_small_lds_table_overfull", "subbucket_records_small_lds_table",
+                              "subbucket_records_flat_gather", "subbucket_records_level2_two_sweeps"])
 @pytest.mark.parametrize("opt", [dict(k=31, bf_shift=24), dict(k=21, bf_shift=20), dict(k=31, bf_shift=22, n_hash=7)], ids=["k31b24", "k21b20", "k31b22H7"])
 def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch):
     """main.c:53-57: both passes read the same input.  With yakamd_retain_input the create_new pass keeps its hashed k-mers on the
@@ -317,7 +319,10 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576"),
-                                 dict(YAKAMD_S2_BITS="0", YAKAMD_OVF_SCRATCH_WORDS="200000"), dict(YAKAMD_SLICE_SB="1", YAKAMD_BATCH="65536")],
+                                 dict(YAKAMD_S2_BITS="0", YAKAMD_OVF_SCRATCH_WORDS="200000"), dict(YAKAMD_SLICE_SB="1", YAKAMD_BATCH="65536"),
+                                 dict(YAKAMD_S2_BITS="8", YAKAMD_P3_MIN="3", YAKAMD_P3_LOW="4"), dict(YAKAMD_S2_BITS="9", YAKAMD_P3_MIN="5", YAKAMD_P3_LOW="3", YAKAMD_BATCH="65536"),
+                                 dict(YAKAMD_S2_BITS="8", YAKAMD_P3_MIN="3", YAKAMD_P3_LOW="4", YAKAMD_REC8_OUT="0"), dict(YAKAMD_S2_BITS="8", YAKAMD_P3_MIN="3", YAKAMD_REC8="0"),
+                                 dict(YAKAMD_S2_BITS="14", YAKAMD_CH2="4096"), dict(YAKAMD_LC_FLAT="1"), dict(YAKAMD_LC_FLAT="1", YAKAMD_S2_BITS="5", YAKAMD_BATCH="65536"), dict(YAKAMD_LC_FLAT="0")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
                               "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
@@ -326,7 +331,9 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "lc2_three_persistent_workgroups", "pass2_plain_hashes", "pass2_plain_hashes_cross_sweep", "replay_prefix_16", "replay_prefix_1024",
                               "rec16_records", "tagged_in_rec16_out", "tagged_in_rec16_out_multibatch", "tagged_multibatch_s2_3",
                               "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices",
-                              "lds_overflow_to_global_in_groups", "slices_cut_by_sub_bucket_load"])
+                              "lds_overflow_to_global_in_groups", "slices_cut_by_sub_bucket_load",
+                              "level2_two_sweeps", "level2_two_sweeps_plain_second_multibatch", "level2_two_sweeps_rec16_out", "level2_two_sweeps_rec16_in",
+                              "level2_two_sweeps_16k_sub_buckets", "flat_gather", "flat_gather_multibatch", "one_workgroup_per_sub_table_gather"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""

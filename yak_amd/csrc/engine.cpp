@@ -787,10 +787,12 @@ static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec
 		u64 kept_n = 0;
 		for (auto &k : c->kept) kept_n += k.n;
 		const u64 per_sb = (u64)env_i64("YAKAMD_SB_INST", c->bloom_mode ? 1800 : 600);
-		if (kept_n + n_cap > (u64)(c->phi - c->plo) * (u64)env_i64("YAKAMD_SLICE_SB", 8192) * per_sb) fits = false;
+		if (kept_n + n_cap > (u64)(c->phi - c->plo) * (u64)env_i64("YAKAMD_SLICE_SB", env_i64("YAKAMD_P3_MIN", 13) < 18 ? (int64_t)1 << 18 : 8192) * per_sb) fits = false;
 	}
 	if (!c->kept.empty() && c->kept.back().fmt != fmt) fits = false;   /* tagged records carry ranks, Rec records stream positions: never in one slice */
-	if (!fits && !c->kept.empty() && t >= c->t_end && (fmt != 0 || n_pos < 0xfffffff0ull) && cost <= c->fast_budget && !c->acc.s) {
+	/* (a chunk that continues a sequence cut by the caller starts k - 1 positions before the end of the previous one, yak_api.cpp take_piece:
+	 * its first k - 1 positions complete no k-mer, so it is still "behind" everything kept) */
+	if (!fits && !c->kept.empty() && t + (u64)(c->k - 1) >= c->t_end && (fmt != 0 || n_pos < 0xfffffff0ull) && cost <= c->fast_budget && !c->acc.s) {
 		/* the kept batches are a complete prefix of the stream: count them now, exactly as if the pass
 		 * ended here (table, filter and counts carry over; the next slice meets them as existing state --
 		 * what the reference does chunk after chunk), and start a new slice with times relative to t */
@@ -1284,6 +1286,16 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	bool only_side = true;
 	for (int p = 0; p < P; ++p) if (!large[p] && (m[p] || cap0[p])) only_side = false;
 	const u64 scr_lo = only_side ? tot : 0, scr_n = tot_ext - scr_lo;
+	if (only_side) {
+		/* the scratch pointers handed to k_replay below are shifted by scr_lo: that is only sound while the kernel touches no scratch below `tot`,
+		 * i.e. while every task outside the side arena is an empty one, and while bitmap words of the two arenas do not straddle */
+		if (tot % 32 != 0) return fail("replay: arena size %llu is not a multiple of 32", (unsigned long long)tot);
+		for (int p = 0; p < P; ++p) {
+			if (large[p]) continue;
+			if (tasks[p].m != 0 || tasks[p].old_count != 0 || cap0[p] != 0) return fail("replay: sub-table %d is not empty but lies outside the side arena", p);
+			lp_host[p] = 0;                                          /* no put-call can have hit a sub-table that holds nothing: never let a stray time grow it */
+		}
+	}
 	if ((par && dmalloc(&sp, 2 * scr_n)) || dmalloc(&nk, tot_ext) || dmalloc(&nu, tot_ext / 32 + 1) || dmalloc(&su, scr_n / 32 + 1) || dmalloc(&so, scr_n) || dmalloc(&nd, tot) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
 	if (only_side) {
@@ -1514,13 +1526,22 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
 	if (c->bloom_mode && s2 < c->nb - 9 - 7 && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - 7;   /* k_lc2 stages at most 128 bloom blocks per sub-bucket */
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
-	if (s2 > 13) s2 = 13;
+	/* one sweep of the level-2 scatter takes up to 2^11 sub-buckets (2^13 in sweeps over the chunk); beyond that -- the share of an N-GPU job's rank:
+	 * 128 sub-tables of 69 M instances each -- the partition takes two sweeps (p3): the high bits first into {hash, rank} records, then 2^p3_low
+	 * sub-buckets inside every group.  2^18 sub-buckets per sub-table bound the per-sub-bucket arrays */
+	const int p3_min = (int)env_i64("YAKAMD_P3_MIN", 13), p3_low = (int)std::min<int64_t>(11, std::max<int64_t>(1, env_i64("YAKAMD_P3_LOW", 11)));
+	if (s2 > 18) s2 = 18;
 	if (s2 < 0) s2 = 0;
 	if (c->bloom_mode) {
 		if (s2 > c->nb - 9) s2 = c->nb - 9;                  /* a sub-bucket owns whole 512-bit blocks ... */
 		if (s2 < c->nb - 9 - 20) s2 = c->nb - 9 - 20;        /* ... and at most 2^20 of them (sort-key packing) */
 	}
-	fp.s2_bits = s2;
+	const bool three = s2 > p3_min;
+	if (!three && s2 > 13) s2 = 13;
+	const int s2a = three ? std::min(11, std::max(std::min(4, s2 - 1), s2 - p3_low)) : 0, s2b = s2 - s2a;   /* the first sweep keeps >= 16 groups: the write-combining scatter wants >= 4 bits */
+	if (three && s2b > 13) return fail("level-2 partition: 2^%d sub-buckets per sub-table cannot be split into two sweeps", s2);
+	fp.s2_bits = s2; fp.s2_tot = s2;
+	fp.sw = c->bloom_mode ? c->nb - 9 : s2; fp.ssh = fp.sw - s2;
 	fp.bf_virgin = 0;
 	fp.rec8_in = fmt_in; fp.tb = YK_R8_TAG_BITS + s2;
 	fp.rec8_out = 0;                                         /* set below, once the largest sub-table stream is known */
@@ -1529,7 +1550,8 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		else if (bloom_materialise(c)) return -1;
 		c->bf_virgin = false;
 	}
-	const u64 ch2 = std::max<u64>((u64)env_i64("YAKAMD_CH2", YK_CH2), (u64)32 << s2);    /* keep >= 32 records per sub-bucket run */
+	const int s2_first = three ? s2a : s2;                       /* bits of the sweep that reads the level-1 records */
+	const u64 ch2 = std::max<u64>((u64)env_i64("YAKAMD_CH2", YK_CH2), (u64)32 << s2_first);    /* keep >= 32 records per sub-bucket run */
 	/* chunk table: runs of one sub-table's records, grouped by sub-table */
 	std::vector<Chunk2> chunks;
 	std::vector<u32> chunk_first(P + 1, 0);
@@ -1555,7 +1577,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		if (chunks.size() > chunk_first[p]) chunks.back().spare = 1;   /* last chunk of its sub-table */
 	}
 	chunk_first[P] = (u32)chunks.size();
-	const size_t S2 = (size_t)1 << s2, n_sb = (size_t)P << s2;
+	const size_t n_sb = (size_t)P << s2, S2F = (size_t)1 << s2_first;
 	if (fmt_in) {
 		if (np_max >= (1ull << 32)) return fail("more than 2^32 k-mer instances of one sub-table in one slice");
 		fp.rec8_out = np_max < (1ull << fp.tb) && env_i64("YAKAMD_REC8_OUT", 1) != 0;   /* the rank must fit below the hash bits; else 16-byte records {hash, rank} */
@@ -1563,7 +1585,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		sort_tmax = np_max;
 	}
 
-	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0; Rec *d_r2 = 0;
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0, *d_sba = 0, *d_koff = 0; Rec *d_r2 = 0, *d_ra = 0;
 	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
 	LcOut lo; lo.kc = 0; lo.T = 0; lo.nsel = 0; lo.lp = 0; lo.nd = 0;
 	u64 *d_scr = 0, *d_scroff = 0;
@@ -1571,17 +1593,28 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
 		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_segcur); dfree(d_ovf); dfree(d_ovf2); dfree(d_ndist); dfree(d_bbase); dfree(d_sbstart);
 		dfree(d_segbase); dfree(d_r2); dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd);
-		dfree(d_scr); dfree(d_scroff);
+		dfree(d_scr); dfree(d_scroff); dfree(d_sba); dfree(d_ra); dfree(d_koff);
 	} };
-	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2) ||
-	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_r2, fp.rec8_out ? (n_total + 1) / 2 : n_total) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
+	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2F) ||
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
+	if (three ? (dmalloc(&d_ra, n_total) || dmalloc(&d_sba, ((size_t)P << s2a) + 1)) : dmalloc(&d_r2, fp.rec8_out ? (n_total + 1) / 2 : n_total)) return -1;
 	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));   /* NOVF, NOVF2 */
+	std::vector<u64> h_sba;
 	{
 		EvTimer tm(c->st);
-		yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
+		if (!three) yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fp, P, d_rows2, d_sbstart, d_r2, c->st);
+		else {
+			/* first sweep: the high s2a bits of the sub-bucket, {hash, rank} records out (the rank no longer fits beside the hash while only
+			 * s2a of its bits are implied by the place) */
+			FastParams fa = fp;
+			fa.s2_bits = s2a; fa.ssh = fp.sw - s2a; fa.rec8_out = 0;
+			yk_launch_part2(d_chunks, (int)chunks.size(), d_cf, d_bbase, fa, P, d_rows2, d_sba, d_ra, c->st);
+			h_sba.resize(((size_t)P << s2a) + 1);
+			HIPCK(hipMemcpyAsync(h_sba.data(), d_sba, h_sba.size() * 8, hipMemcpyDeviceToHost, c->st));
+		}
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 += c->ms_part2;
 	}
@@ -1605,7 +1638,36 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		}
 	}
 	c->kept.clear(); c->kept_bytes = 0;
-	dfree(d_chunks); dfree(d_cf); dfree(d_rows2);
+	dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_bbase);
+	if (three) {
+		/* second sweep: every group of the first is a bucket of its own (sub-table << s2a | group); its 2^s2b sub-buckets take the group's place in
+		 * the final numbering sub-table << s2 | sub-bucket, so the offsets of the first sweep are the bucket bases of the second */
+		const size_t PB = (size_t)P << s2a, S2B = (size_t)1 << s2b;
+		const u64 chb = std::max<u64>((u64)env_i64("YAKAMD_CH2", YK_CH2), (u64)32 << s2b);
+		std::vector<Chunk2> cb;
+		std::vector<u32> cfb(PB + 1, 0);
+		for (size_t q = 0; q < PB; ++q) {
+			cfb[q] = (u32)cb.size();
+			for (u64 o = h_sba[q]; o < h_sba[q + 1]; o += chb) {
+				Chunk2 ch;
+				ch.rec = d_ra + o; ch.spare = 0; ch.n = (u32)std::min<u64>(chb, h_sba[q + 1] - o); ch.bucket = (u32)q; ch.tbase = 0; ch.pad = 0; ch.before = 0; ch.after = 0;
+				cb.push_back(ch);
+			}
+			if (cb.size() > cfb[q]) cb.back().spare = 1;
+		}
+		cfb[PB] = (u32)cb.size();
+		FastParams fb = fp;
+		fb.s2_bits = s2b; fb.rec8_in = 0;                          /* routes by the low s2b bits, packs with all of them (s2_tot) */
+		if (dmalloc(&d_chunks, cb.size()) || dmalloc(&d_cf, PB + 1) || dmalloc(&d_rows2, cb.size() * S2B) || dmalloc(&d_r2, fp.rec8_out ? (n_total + 1) / 2 : n_total)) return -1;
+		HIPCK(hipMemcpyAsync(d_chunks, cb.data(), cb.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
+		HIPCK(hipMemcpyAsync(d_cf, cfb.data(), (PB + 1) * 4, hipMemcpyHostToDevice, c->st));
+		EvTimer tm(c->st);
+		yk_launch_part2(d_chunks, (int)cb.size(), d_cf, d_sba, fb, (int)PB, d_rows2, d_sbstart, d_r2, c->st);
+		const double ms = tm.stop();                                /* (the host vectors above outlive the copies) */
+		c->ms_part2 += ms; c->st_cur.ms_extract += ms; c->st_cur.ms_part2 += ms;
+		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_ra); dfree(d_sba);
+		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] level-2 partition in two sweeps: 2^%d groups, then 2^%d sub-buckets each (%llu records, %.2f ms)\n", s2a, s2b, (unsigned long long)n_total, c->ms_part2);
+	}
 	/* the keys a sub-bucket selects are written over the front of its own record range in lo.kc / lo.T */
 	if (dmalloc(&lo.kc, n_total) || dmalloc(&lo.T, n_total) || dmalloc(&lo.nsel, n_sb) || dmalloc(&lo.lp, n_sb) || dmalloc(&lo.nd, n_sb) || dmalloc(&d_ndist, P)) return -1;
 	if (c->plo > 0 || c->phi < P) {                              /* sub-buckets outside the shard are never visited */
@@ -1668,7 +1730,10 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	/* gather the fragments: keys per sub-table, then one contiguous list each */
 	std::vector<u32> m(P, 0);
 	std::vector<u64> ro(P + 1, 0);
-	yk_launch_lc_sum(lo.nsel, s2, c->plo, c->phi, d_segcur, c->st);
+	/* many sub-buckets per sub-table, or few sub-tables: the gather spread over the whole chip (k_lc_sum3 / k_nsel_scan / k_lc_gather) */
+	const bool flat = env_i64("YAKAMD_LC_FLAT", (s2 > 11 || c->phi - c->plo < 512) ? 1 : 0) != 0;
+	if (flat) yk_launch_lc_sum3(lo, s2, c->plo, c->phi, fp.t_pass0, d_segcur, c->d_lastput, d_ndist, c->st);
+	else yk_launch_lc_sum(lo.nsel, s2, c->plo, c->phi, d_segcur, c->st);
 	HIPCK(hipMemcpyAsync(m.data(), d_segcur, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	for (int p = 0; p < P; ++p) ro[p + 1] = ro[p] + m[p];
@@ -1677,7 +1742,11 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	HIPCK(hipMemcpyAsync(d_segbase, ro.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	{
 		EvTimer tm(c->st);
-		yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
+		if (flat) {
+			if (dmalloc(&d_koff, n_sb + 1)) return -1;
+			yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, d_koff, c->st);
+			yk_launch_lc_gather(lo, d_sbstart, d_koff, s2, c->plo, c->phi, kc[0], tt[0], c->st);
+		} else yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
 		c->st_cur.ms_select += tm.stop();
 	}
 	{
@@ -1689,9 +1758,10 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	}
 	if (keep2) {
 		/* the gathered list is grouped by sub-bucket (k_lc_compact walks them in order): a copy of it + the first key of every sub-bucket */
-		if (dmalloc(&c->ret2.d_koff, n_sb + 1) || dmalloc(&c->ret2.d_kkc, n_sel) || dmalloc(&c->ret2.d_segbase, P + 1)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
+		if ((!d_koff && dmalloc(&c->ret2.d_koff, n_sb + 1)) || dmalloc(&c->ret2.d_kkc, n_sel) || dmalloc(&c->ret2.d_segbase, P + 1)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
 		else {
-			yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
+			if (d_koff) { c->ret2.d_koff = d_koff; d_koff = 0; }        /* the flat gather has them already */
+			else yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
 			HIPCK(hipMemcpyAsync(c->ret2.d_kkc, kc[0], n_sel * 8, hipMemcpyDeviceToDevice, c->st));
 			c->ret2.d_sbstart = d_sbstart; d_sbstart = 0;
 			HIPCK(hipMemcpyAsync(c->ret2.d_segbase, d_segbase, (P + 1) * 8, hipMemcpyDeviceToDevice, c->st));
@@ -1699,7 +1769,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 			c->ret2.valid = true;
 		}
 	}
-	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist);
+	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist); dfree(d_koff);
 	int cur = 0;
 	{
 		EvTimer tm(c->st);

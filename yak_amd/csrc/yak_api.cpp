@@ -25,6 +25,7 @@
 #include <map>
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <cmath>
 #include "engine.h"
 #include <dlfcn.h>
@@ -356,7 +357,29 @@ void yak_ch_merge(yak_ch_t *h0, yak_ch_t *h1, int min, int max, int n_thread, in
 		for (yak_ch_t *s1 : from) {
 			u64 *d_hash = 0, n = 0; u32 *d_t = 0;
 			ok = ok && hipSetDevice(yk_ctx_device(shard_ctx(s1))) == hipSuccess && yk_ctx_list_hashes(shard_ctx(s1), min, hi, &d_hash, &d_t, &n) == 0;
-			if (ok && n) ok = yakamd_feed_hashed_dev(s0, d_hash, d_t, (int64_t)n, t0, n) == 0;   /* (a list on another device is read through peer access) */
+			const int dv0 = yk_ctx_device(c0), dv1 = yk_ctx_device(shard_ctx(s1));
+			if (ok && n && dv0 != dv1) {
+				/* the list lies on s1's device and the feed's kernels run on c0's: peer access (enabled here: nothing else in this process may have
+				 * done it), or a staged copy on c0's device when the two cannot reach each other */
+				int can = 0;
+				ok = hipSetDevice(dv0) == hipSuccess;
+				if (ok && hipDeviceCanAccessPeer(&can, dv0, dv1) == hipSuccess && can) {
+					const hipError_t pe = hipDeviceEnablePeerAccess(dv1, 0);
+					if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) can = 0;
+					(void)hipGetLastError();
+				}
+				if (ok && !can) {
+					u64 *h2 = (u64*)yakamd_dev_alloc(n * 8); u32 *t2 = (u32*)yakamd_dev_alloc(n * 4);
+					ok = h2 && t2 && hipMemcpyPeer(h2, dv0, d_hash, dv1, n * 8) == hipSuccess && hipMemcpyPeer(t2, dv0, d_t, dv1, n * 4) == hipSuccess;
+					if (ok) ok = yakamd_feed_hashed_dev(s0, h2, t2, (int64_t)n, t0, n) == 0;
+					if (ok) ok = hipStreamSynchronize(yk_ctx_stream(c0)) == hipSuccess;
+					yakamd_dev_free(h2); yakamd_dev_free(t2);
+					t0 += n;
+					yk_pool_release(d_hash); yk_pool_release(d_t);
+					continue;
+				}
+			}
+			if (ok && n) ok = yakamd_feed_hashed_dev(s0, d_hash, d_t, (int64_t)n, t0, n) == 0;
 			t0 += n;
 			yk_pool_release(d_hash); yk_pool_release(d_t);
 		}
@@ -1147,8 +1170,10 @@ static void multi_close(MultiJob *J)
 }
 
 /* one round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Partition, exchange, feed. */
-static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0)
+static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0, std::string *why)
 {
+	std::mutex why_mu;
+	auto note = [&]() { std::lock_guard<std::mutex> lk(why_mu); if (why && why->empty()) *why = yakamd_last_error(); };   /* called on the thread that failed */
 	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
 	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
 	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
@@ -1163,7 +1188,7 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 			n_rec[s] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
 			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
 			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data());
-			if (n_rec[s] < 0) ok[s] = 0;
+			if (n_rec[s] < 0) { ok[s] = 0; note(); }
 		});
 		for (auto &t : th) t.join();
 	}
@@ -1210,7 +1235,7 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s], 0)
 				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s])
 				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
-				if (rc != 0) ok[d] = 0;
+				if (rc != 0) { ok[d] = 0; note(); }
 			}
 			if (hipStreamSynchronize(yk_ctx_stream(((yak_ch_ext*)e->sub[d])->ctx)) != hipSuccess) ok[d] = 0;   /* the copies out of this set's buffers are done before the set is filled again */
 		} });
@@ -1255,6 +1280,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	std::vector<uint64_t> t0[2] = { std::vector<uint64_t>(S, 0), std::vector<uint64_t>(S, 0) };
 	std::thread worker;
 	bool worker_ok = true;
+	std::string worker_why;                                    /* yakamd_last_error() is per thread: the round's text comes back with it */
 	int cur = 0;
 	uint64_t t_stream = 0;
 	int64_t n_seq_tot = 0;
@@ -1264,7 +1290,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		wait_worker();                                          /* at most one round in flight: its set becomes the one to fill next */
 		if (ok) {
 			const int x = cur;
-			worker = std::thread([&, x]() { worker_ok = multi_round(&J, x, e, opt->k, opt->pre, create_new, fill[x], t0[x]); });
+			worker = std::thread([&, x]() { std::string why; worker_ok = multi_round(&J, x, e, opt->k, opt->pre, create_new, fill[x], t0[x], &why); if (!worker_ok) worker_why = why; });
 		}
 		cur ^= 1;
 		std::fill(fill[cur].begin(), fill[cur].end(), 0); g = 0;
@@ -1332,7 +1358,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? "RCCL exchange" : "peer copies");
 	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
-	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
+	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", !worker_why.empty() ? worker_why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
 }
 

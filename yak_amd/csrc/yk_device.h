@@ -165,6 +165,11 @@ struct FastParams {
 	int dbg, bf_virgin;             /* dbg: timing ablations only (YAKAMD_DBG); bf_virgin: filter never written (all zero) */
 	int rec8_in, rec8_out, tb;      /* level-2 input is tagged 8-byte records; its output (the counting kernels' input) is 8 bytes: (hash >> pre minus the sub-bucket bits) << tb | rank, tb = 12 + s2_bits */
 	int or_mode;                    /* loads from a .yak file (htab.c:436-470) instead of counting: 1 = the low 4 bits of a record's time are a flag, ORed into the key's low bits; 2 = the low 10 bits are the saved count, kept by new keys only */
+	/* which bits of x = hash >> pre name the sub-bucket: the top s2_tot bits of x's low `sw` bits (sw = log2 bloom blocks per sub-table with a filter -- a
+	 * sub-bucket owns a contiguous range of blocks -- else sw = s2_tot).  A partition sweep routes by s2_bits of them: ((x mod 2^sw) >> ssh) mod 2^s2_bits.
+	 * One sweep does them all (ssh = sw - s2_tot, s2_bits = s2_tot: the counting kernels always see this form); beyond 2^13 sub-buckets per sub-table a
+	 * first sweep takes the high s2_tot - 11 bits (ssh = sw - s2_bits) and a second one, on the groups of the first, the low 11 (ssh = sw - s2_tot) */
+	int sw, ssh, s2_tot;
 	u64 t_pass0;
 };
 
@@ -213,6 +218,8 @@ void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom
 void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st);
 void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
                           u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st);
+void yk_launch_lc_sum3(LcOut O, int s2_bits, int plo, int phi, u64 t_pass0, u32 *seg_cnt, u64 *lastput, u32 *ndist_p, hipStream_t st);
+void yk_launch_lc_gather(LcOut O, const u64 *sbstart, const u64 *key_off, int s2_bits, int plo, int phi, u64 *out_kc, u64 *out_T, hipStream_t st);
 void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, u64 n_keys, hipStream_t st);
 void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
