@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
     a = ap.parse_args()
     a.reads_given = any(x == "--reads" or x.startswith("--reads=") for x in sys.argv[1:])
+    a.warmup_given = any(x == "--warmup" or x.startswith("--warmup=") for x in sys.argv[1:])
     a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
     if a.config == "nofilter":

@@ -74,30 +74,72 @@ static inline u32 kh_bits_for(u32 want)
 	return lg > 2 ? lg : 2;
 }
 
-/* Device memory pool.  A counting job allocates and frees tens of GB per pass (bloom filters,
- * partition buffers, table arenas); on ROCm each hipMalloc/hipFree of that size costs tens to
- * hundreds of ms, so freed blocks are kept and handed out again (best fit within +25 %).
- * YAKAMD_POOL=0 disables it; the cache is dropped when an allocation fails. */
+/* Device memory pool.  A counting job allocates and frees tens of GB per pass (bloom filters, partition buffers, table arenas); on ROCm a
+ * hipMalloc costs ~27 ms per GB (measured: 97 GB in 2.7 s) and a hipFree of that size about as much, so freed memory is kept and handed out
+ * again.  The driver's allocations are the pool's SUPERBLOCKS; a freed range joins the free ranges next to it inside its superblock, and a
+ * request is carved from the best-fitting free range: the 97 GB a slice's first partition sweep used serve, once freed, the two 48 GB arrays of
+ * the counting stage, and the next, shorter slice finds its buffers inside the longer one's.  Small requests (< 64 MB) only take ranges of about
+ * their own size, so that they never pin a large superblock.  Beyond the cap (three quarters of the HBM idle) the superblocks that are
+ * entirely free go back to the driver, least recently used first.  YAKAMD_POOL=0 disables it; a failed allocation drops every free
+ * superblock and retries. */
 #include <map>
 #include <mutex>
 #include <unordered_map>
 struct DevPool {
 	std::mutex mu;
-	struct Idle { void *p; u64 stamp; };
-	std::multimap<size_t, Idle> idle;
-	std::map<u64, std::multimap<size_t, Idle>::iterator> by_age;   /* beyond the cap the blocks idle for longest go back to the driver */
-	std::unordered_map<void*, size_t> size_of;
-	size_t cached = 0;
+	struct Super { size_t size; u64 stamp; };
+	std::map<char*, Super> supers;                     /* by base address */
+	std::map<char*, size_t> free_at;                   /* free ranges by start address (never spanning two superblocks) */
+	std::multimap<size_t, char*> free_sz;              /* the same ranges by length */
+	std::unordered_map<void*, size_t> live;            /* ranges handed out */
+	size_t cached = 0;                                 /* bytes in free ranges */
 	u64 clock = 0;
 };
 static DevPool g_pool[16];
 static DevPool &pool_here() { int d = 0; (void)hipGetDevice(&d); return g_pool[d & 15]; }
+static const size_t POOL_SPLIT_MIN = (size_t)64 << 20;
 
-static void pool_trim(DevPool &P)
+static std::map<char*, DevPool::Super>::iterator pool_super_of(DevPool &P, char *p)
 {
-	for (auto &kv : P.idle) { (void)hipFree(kv.second.p); P.size_of.erase(kv.second.p); }
-	P.idle.clear(); P.by_age.clear(); P.cached = 0;
+	auto it = P.supers.upper_bound(p);
+	return it == P.supers.begin() ? P.supers.end() : std::prev(it);
 }
+static void pool_range_drop(DevPool &P, std::map<char*, size_t>::iterator it)
+{
+	auto r = P.free_sz.equal_range(it->second);
+	for (auto q = r.first; q != r.second; ++q) if (q->second == it->first) { P.free_sz.erase(q); break; }
+	P.cached -= it->second;
+	P.free_at.erase(it);
+}
+static void pool_range_add(DevPool &P, char *p, size_t n)
+{
+	/* join the neighbours inside the same superblock */
+	auto su = pool_super_of(P, p);
+	char *lo = su->first, *hi = su->first + su->second.size;
+	auto nx = P.free_at.lower_bound(p);
+	if (nx != P.free_at.end() && nx->first == p + n && nx->first < hi) { n += nx->second; pool_range_drop(P, nx); }
+	auto pv = P.free_at.lower_bound(p);
+	if (pv != P.free_at.begin()) { --pv; if (pv->first + pv->second == p && pv->first >= lo) { p = pv->first; n += pv->second; pool_range_drop(P, pv); } }
+	P.free_at[p] = n; P.free_sz.insert({ n, p }); P.cached += n;
+	su->second.stamp = ++P.clock;
+}
+/* give the entirely free superblocks back to the driver, least recently used first, until at most `keep` bytes stay idle */
+static void pool_release(DevPool &P, size_t keep)
+{
+	while (P.cached > keep) {
+		std::map<char*, DevPool::Super>::iterator best = P.supers.end();
+		for (auto it = P.supers.begin(); it != P.supers.end(); ++it) {
+			auto f = P.free_at.find(it->first);
+			if (f == P.free_at.end() || f->second != it->second.size) continue;
+			if (best == P.supers.end() || it->second.stamp < best->second.stamp) best = it;
+		}
+		if (best == P.supers.end()) break;
+		pool_range_drop(P, P.free_at.find(best->first));
+		(void)hipFree(best->first);
+		P.supers.erase(best);
+	}
+}
+static void pool_trim(DevPool &P) { pool_release(P, 0); }
 
 static void *pool_alloc(size_t bytes)
 {
@@ -107,12 +149,16 @@ static void *pool_alloc(size_t bytes)
 	bytes = (bytes + gran - 1) / gran * gran;
 	std::lock_guard<std::mutex> lk(P.mu);
 	if (on) {
-		auto it = P.idle.lower_bound(bytes);
-		if (it != P.idle.end() && it->first <= bytes + bytes / 4) {
-			void *p = it->second.p;
-			P.cached -= it->first;
-			P.by_age.erase(it->second.stamp);
-			P.idle.erase(it);
+		auto it = P.free_sz.lower_bound(bytes);
+		if (it != P.free_sz.end() && (it->first <= bytes + bytes / 4 || bytes >= POOL_SPLIT_MIN)) {
+			char *p = it->second;
+			const size_t have = it->first;
+			pool_range_drop(P, P.free_at.find(p));
+			size_t take = bytes;
+			if (have - take < (2u << 20) || bytes < POOL_SPLIT_MIN) take = have;      /* no crumbs; small requests never split */
+			if (have > take) { P.free_at[p + take] = have - take; P.free_sz.insert({ have - take, p + take }); P.cached += have - take; }
+			P.live[p] = take;
+			pool_super_of(P, p)->second.stamp = ++P.clock;
 			return p;
 		}
 	}
@@ -122,7 +168,8 @@ static void *pool_alloc(size_t bytes)
 		pool_trim(P);
 		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	}
-	P.size_of[p] = bytes;
+	P.supers[(char*)p] = DevPool::Super{ bytes, ++P.clock };
+	P.live[p] = bytes;
 	return p;
 }
 
@@ -143,21 +190,17 @@ static void pool_free(void *p)
 	DevPool *Pp = &pool_here();
 	{
 		bool mine;
-		{ std::lock_guard<std::mutex> lk(Pp->mu); mine = Pp->size_of.count(p) != 0; }
-		for (int d = 0; d < 16 && !mine; ++d) { std::lock_guard<std::mutex> lk(g_pool[d].mu); if (g_pool[d].size_of.count(p)) { Pp = &g_pool[d]; mine = true; } }
+		{ std::lock_guard<std::mutex> lk(Pp->mu); mine = Pp->live.count(p) != 0; }
+		for (int d = 0; d < 16 && !mine; ++d) { std::lock_guard<std::mutex> lk(g_pool[d].mu); if (g_pool[d].live.count(p)) { Pp = &g_pool[d]; mine = true; } }
 	}
 	DevPool &P = *Pp;
 	std::lock_guard<std::mutex> lk(P.mu);
-	auto it = P.size_of.find(p);
-	if (!on || it == P.size_of.end()) { if (it != P.size_of.end()) P.size_of.erase(it); (void)hipFree(p); return; }
-	const u64 stamp = ++P.clock;
-	P.by_age[stamp] = P.idle.insert({ it->second, DevPool::Idle{ p, stamp } });
-	P.cached += it->second;
-	while (P.cached > cap && !P.by_age.empty()) {          /* least recently freed first: the buffers of the running job stay */
-		auto old = P.by_age.begin()->second;
-		P.cached -= old->first; P.size_of.erase(old->second.p); (void)hipFree(old->second.p);
-		P.idle.erase(old); P.by_age.erase(P.by_age.begin());
-	}
+	auto it = P.live.find(p);
+	if (it == P.live.end()) { (void)hipFree(p); return; }          /* not the pool's */
+	const size_t n = it->second;
+	P.live.erase(it);
+	pool_range_add(P, (char*)p, n);
+	pool_release(P, on ? cap : 0);
 }
 
 size_t yk_pool_cached_bytes(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); return P.cached; }
@@ -1517,6 +1560,18 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
 	fp.dbg = (int)env_i64("YAKAMD_DBG", 0);
 	fp.or_mode = c->or_mode;
+	/* YAKAMD_VERBOSE > 1: wall-clock laps of the stages (each behind a stream synchronise: allocation stalls show up where they happen) */
+	const bool laps = env_i64("YAKAMD_VERBOSE", 0) > 1;
+	double lap_t = now_ms();
+	auto lap = [&](const char *what) {
+		if (!laps) return;
+		(void)hipStreamSynchronize(c->st);
+		const double t = now_ms();
+		size_t fr = 0, tt_ = 0;
+		(void)hipMemGetInfo(&fr, &tt_);
+		fprintf(stderr, "[yak_amd] slice stage %-28s %9.2f ms   (device memory in use %.1f GB, of it idle in the pool %.1f GB)\n", what, t - lap_t, (double)(tt_ - fr) / 1e9, (double)yk_pool_cached_bytes() / 1e9);
+		lap_t = now_ms();
+	};
 	/* mean sub-bucket <= ~600 instances: even if all are distinct the 1024-slot LDS table holds them.  With a filter the input is reads with
 	 * coverage (a filtered count of all-distinct k-mers keeps nothing): three times as many instances per sub-bucket still leave the distinct
 	 * k-mers far below the table's 624 (30 x coverage: ~100 distinct per 560 instances), and 2048 sub-buckets per sub-table are what the
@@ -1618,6 +1673,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		c->ms_part2 = tm.stop();
 		c->st_cur.ms_extract += c->ms_part2; c->st_cur.ms_part2 += c->ms_part2;
 	}
+	lap("level-2 partition (first sweep)");
 	bool keep2 = false;
 	{
 		/* the level-1 records stay for the count pass over the same input when the caller asked for that and they fit the budget
@@ -1668,6 +1724,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_ra); dfree(d_sba);
 		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] level-2 partition in two sweeps: 2^%d groups, then 2^%d sub-buckets each (%llu records, %.2f ms)\n", s2a, s2b, (unsigned long long)n_total, c->ms_part2);
 	}
+	lap("release / second sweep");
 	/* the keys a sub-bucket selects are written over the front of its own record range in lo.kc / lo.T */
 	if (dmalloc(&lo.kc, n_total) || dmalloc(&lo.T, n_total) || dmalloc(&lo.nsel, n_sb) || dmalloc(&lo.lp, n_sb) || dmalloc(&lo.nd, n_sb) || dmalloc(&d_ndist, P)) return -1;
 	if (c->plo > 0 || c->phi < P) {                              /* sub-buckets outside the shard are never visited */
@@ -1725,6 +1782,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		}
 		dfree(d_scroff); d_scroff = 0;
 	}
+	lap("insert (k_lc2 + tiers)");
 	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; }
 	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
 	/* gather the fragments: keys per sub-table, then one contiguous list each */
@@ -1738,15 +1796,34 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	HIPCK(hipStreamSynchronize(c->st));
 	for (int p = 0; p < P; ++p) ro[p + 1] = ro[p] + m[p];
 	const u64 n_sel = ro[P];
-	if (dmalloc(&kc[0], n_sel) || dmalloc(&tt[0], n_sel) || dmalloc(&kc[1], n_sel) || dmalloc(&tt[1], n_sel) || dmalloc(&d_segbase, P + 1)) return -1;
+	/* The sort by insertion time T.  Times are unique inside a sub-table and < 2^tbits, so the order needs no comparisons: one partition sweep by
+	 * the top ts_b bits of T (the level-2 partition's kernels on {key, T} pairs), then every bin ranks its keys with a bitmap of its 2^ts_w possible
+	 * times (k_ts_rank).  ts_w = 11 wherever that leaves at most 2^13 bins: a bin then never holds more keys than the ranking kernel's registers and
+	 * stage (the times of first occurrences are dense at the start of a stream of reads and sparse later), and the kernel takes 2^ts_j sparse
+	 * neighbours in one step (~1000 keys).  Times beyond 32 bits or bins wider than 2^18 times take the stable 8-bit passes as before */
+	const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
+	u32 m_max = 0;
+	for (int p = 0; p < P; ++p) m_max = std::max(m_max, m[p]);
+	int ts_b = std::min(13, std::max(0, tbits - 11));
+	ts_b = (int)std::min<int64_t>(13, std::max<int64_t>(0, env_i64("YAKAMD_TS_BITS", ts_b)));
+	const int ts_w = std::max(5, tbits - ts_b);
+	int ts_j = 0;
+	while (ts_j < ts_b && ts_w + ts_j < 15 && ((u64)m_max >> (ts_b - ts_j - 1)) <= 256) ++ts_j;   /* a mean of 256: the head of a stream of reads is several times denser */
+	ts_j = (int)std::min<int64_t>(ts_b, std::max<int64_t>(0, env_i64("YAKAMD_TS_JOIN", ts_j)));
+	/* short lists in many sub-tables (a filtered count of reads: ~50 K keys per sub-table) are done sooner by three launches of the stable pass */
+	const bool tsort = env_i64("YAKAMD_TSORT", (m_max >= 100000 || c->phi - c->plo < 512) ? 1 : 0) != 0 && tbits <= 32 && ts_w + ts_j <= 18 && n_sel > 0;
+	Rec *d_kt = 0, *d_kt2 = 0; u32 *d_tsfail = 0; u64 *d_binstart = 0;
+	struct Guard2 { std::function<void()> f; ~Guard2() { f(); } } guard2{ [&]() { dfree(d_kt); dfree(d_kt2); dfree(d_tsfail); dfree(d_binstart); } };
+	if (dmalloc(&kc[0], n_sel) || dmalloc(&tt[0], n_sel) || dmalloc(&d_segbase, P + 1)) return -1;
+	if (tsort && (dmalloc(&d_kt, n_sel) || dmalloc(&d_tsfail, 1))) return -1;
 	HIPCK(hipMemcpyAsync(d_segbase, ro.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	{
 		EvTimer tm(c->st);
 		if (flat) {
 			if (dmalloc(&d_koff, n_sb + 1)) return -1;
 			yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, d_koff, c->st);
-			yk_launch_lc_gather(lo, d_sbstart, d_koff, s2, c->plo, c->phi, kc[0], tt[0], c->st);
-		} else yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, c->st);
+			yk_launch_lc_gather(lo, d_sbstart, d_koff, s2, c->plo, c->phi, kc[0], tt[0], d_kt, c->st);
+		} else yk_launch_lc_compact(lo, d_sbstart, s2, c->plo, c->phi, fp.t_pass0, d_segbase, kc[0], tt[0], c->d_lastput, d_ndist, d_kt, c->st);
 		c->st_cur.ms_select += tm.stop();
 	}
 	{
@@ -1762,7 +1839,8 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		else {
 			if (d_koff) { c->ret2.d_koff = d_koff; d_koff = 0; }        /* the flat gather has them already */
 			else yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
-			HIPCK(hipMemcpyAsync(c->ret2.d_kkc, kc[0], n_sel * 8, hipMemcpyDeviceToDevice, c->st));
+			if (d_kt) yk_launch_kt_split(d_kt, n_sel, c->ret2.d_kkc, 0, c->st);
+			else HIPCK(hipMemcpyAsync(c->ret2.d_kkc, kc[0], n_sel * 8, hipMemcpyDeviceToDevice, c->st));
 			c->ret2.d_sbstart = d_sbstart; d_sbstart = 0;
 			HIPCK(hipMemcpyAsync(c->ret2.d_segbase, d_segbase, (P + 1) * 8, hipMemcpyDeviceToDevice, c->st));
 			c->ret2.n_keys = n_sel;
@@ -1770,10 +1848,57 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		}
 	}
 	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist); dfree(d_koff);
+	lap("gather of the selected keys");
 	int cur = 0;
-	{
+	bool sorted = false;
+	if (tsort) {
 		EvTimer tm(c->st);
-		const int tbits = std::max(1, ceil_log2_u64(sort_tmax + 1));
+		HIPCK(hipMemsetAsync(d_tsfail, 0, 4, c->st));
+		const Rec *rank_in = d_kt;
+		const u64 *rank_start = d_segbase;                        /* ts_b == 0: a sub-table is its one bin */
+		if (ts_b > 0) {
+			const u64 chs = std::max<u64>((u64)env_i64("YAKAMD_CH2", YK_CH2), (u64)32 << ts_b);
+			std::vector<Chunk2> cs;
+			std::vector<u32> cfs(P + 1, 0);
+			for (int p = 0; p < P; ++p) {
+				cfs[p] = (u32)cs.size();
+				for (u64 o = ro[p]; o < ro[p + 1]; o += chs) {
+					Chunk2 ch;
+					ch.rec = d_kt + o; ch.spare = 0; ch.n = (u32)std::min<u64>(chs, ro[p + 1] - o); ch.bucket = (u32)p; ch.tbase = 0; ch.pad = 0; ch.before = 0; ch.after = 0;
+					cs.push_back(ch);
+				}
+				if (cs.size() > cfs[p]) cs.back().spare = 1;
+			}
+			cfs[P] = (u32)cs.size();
+			Chunk2 *d_cs = 0; u32 *d_cfs = 0, *d_rows = 0;
+			struct Guard3 { std::function<void()> f; ~Guard3() { f(); } } guard3{ [&]() { dfree(d_cs); dfree(d_cfs); dfree(d_rows); } };
+			if (dmalloc(&d_cs, cs.size()) || dmalloc(&d_cfs, P + 1) || dmalloc(&d_rows, cs.size() << ts_b) || dmalloc(&d_binstart, ((size_t)P << ts_b) + 1) || dmalloc(&d_kt2, n_sel)) return -1;
+			HIPCK(hipMemcpyAsync(d_cs, cs.data(), cs.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
+			HIPCK(hipMemcpyAsync(d_cfs, cfs.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
+			FastParams ft = fp;
+			ft.s2_bits = ts_b; ft.ssh = ts_w; ft.rec8_in = 0; ft.rec8_out = 0;
+			yk_launch_part2_ts(d_cs, (int)cs.size(), d_cfs, d_segbase, ft, P, d_rows, d_binstart, d_kt2, c->st);
+			HIPCK(hipStreamSynchronize(c->st));                  /* the host tables above go out of scope */
+			rank_in = d_kt2; rank_start = d_binstart;
+			dfree(d_kt);                                            /* the pairs as gathered: no longer needed (a refused ranking re-splits the partitioned ones: same keys per sub-table) */
+		}
+		u32 h_fail = 1;
+		if (yk_launch_ts_rank(rank_start, rank_in, ts_w, ts_j, (u32)c->plo << ts_b, (u32)(c->phi - c->plo) << ts_b, kc[0], tt[0], d_tsfail, c->st) == 0) {
+			HIPCK(hipMemcpyAsync(&h_fail, d_tsfail, 4, hipMemcpyDeviceToHost, c->st));
+			HIPCK(hipStreamSynchronize(c->st));
+		}
+		sorted = h_fail == 0;
+		if (!sorted) {                                            /* a time seen twice, or the kernel could not be configured: the stable passes on the gathered pairs */
+			if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] sort by bitmap ranks refused: stable radix passes instead\n");
+			yk_launch_kt_split(rank_in, n_sel, kc[0], tt[0], c->st);
+		}
+		dfree(d_kt2); dfree(d_binstart);
+		c->st_cur.ms_sort += tm.stop();
+	}
+	dfree(d_kt);
+	if (!sorted) {
+		if (dmalloc(&kc[1], n_sel) || dmalloc(&tt[1], n_sel)) return -1;
+		EvTimer tm(c->st);
 		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= (u64)env_i64("YAKAMD_SORT_BIG", 30000);
 		for (int shift = 0; shift < tbits; shift += 8) {
 			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st, sort_big);
@@ -1782,12 +1907,14 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		c->st_cur.ms_sort += tm.stop();
 	}
 	dfree(kc[cur ^ 1]); dfree(tt[cur ^ 1]);                     /* the sort's other buffer pair: 16 bytes per key the layout stage can use */
+	lap("sort by insertion time");
 	{
 		EvTimer tm(c->st);
 		ro.resize(P);
 		if (run_replay(c, m, 0, kc[cur], tt[cur], c->d_lastput, 0, false, &ro)) return -1;
 		c->st_cur.ms_replay += tm.stop();
 	}
+	lap("exact layout");
 	return 0;
 }
 

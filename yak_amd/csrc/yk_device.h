@@ -217,9 +217,12 @@ int yk_lc2_ok(FastParams fp);
 void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters, u32 *ovf_list, hipStream_t st);
 void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st);
 void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
-                          u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, hipStream_t st);
+                          u64 *out_kc, u64 *out_T, u64 *lastput, u32 *ndist_p, Rec *out_kt, hipStream_t st);
+void yk_launch_part2_ts(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, FastParams fp, int P, u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
+int yk_launch_ts_rank(const u64 *binstart, const Rec *in, int w, int j, u32 bin_lo, u32 n_bins, u64 *out_kc, u64 *out_t, u32 *fail, hipStream_t st);
+void yk_launch_kt_split(const Rec *in, u64 n, u64 *out_kc, u64 *out_t, hipStream_t st);
 void yk_launch_lc_sum3(LcOut O, int s2_bits, int plo, int phi, u64 t_pass0, u32 *seg_cnt, u64 *lastput, u32 *ndist_p, hipStream_t st);
-void yk_launch_lc_gather(LcOut O, const u64 *sbstart, const u64 *key_off, int s2_bits, int plo, int phi, u64 *out_kc, u64 *out_T, hipStream_t st);
+void yk_launch_lc_gather(LcOut O, const u64 *sbstart, const u64 *key_off, int s2_bits, int plo, int phi, u64 *out_kc, u64 *out_T, Rec *out_kt, hipStream_t st);
 void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, u64 n_keys, hipStream_t st);
 void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
