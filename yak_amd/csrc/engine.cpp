@@ -307,10 +307,9 @@ static int img_reset_empty(yakamd_ctx *c)
 	const int P = c->P;
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
 	c->n_slots = (u64)P * 32;
-	if (dmalloc(&c->d_keys, c->n_slots) || dmalloc(&c->d_used, c->n_slots / 32) || dmalloc(&c->d_delta, c->n_slots)) return -1;
+	if (dmalloc(&c->d_keys, c->n_slots) || dmalloc(&c->d_used, c->n_slots / 32)) return -1;   /* d_delta: see delta_ensure */
 	HIPCK(hipMemsetAsync(c->d_keys, 0xff, c->n_slots * 8, c->st));
 	HIPCK(hipMemsetAsync(c->d_used, 0, c->n_slots / 8, c->st));
-	HIPCK(hipMemsetAsync(c->d_delta, 0, c->n_slots * 4, c->st));
 	c->h_bits.assign(P, YK_NOCAP); c->h_count.assign(P, 0); c->h_off.resize(P);
 	for (int p = 0; p < P; ++p) c->h_off[p] = (u64)p * 32;
 	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
@@ -318,6 +317,17 @@ static int img_reset_empty(yakamd_ctx *c)
 	HIPCK(hipStreamSynchronize(c->st));
 	c->img_keys_total = 0;
 	c->host_valid = false;
+	return 0;
+}
+
+/* the per-slot pending increments (4 bytes per slot of the arena: 8.6 GB beside a 2 Gb assembly's table) exist only while a pass can add to the
+ * counts of stored keys -- a count-existing pass, or puts of the accumulator path on a table that holds keys -- and are folded in and released when
+ * that pass ends */
+static int delta_ensure(yakamd_ctx *c)
+{
+	if (c->d_delta) return 0;
+	if (dmalloc(&c->d_delta, c->n_slots)) return -1;
+	HIPCK(hipMemsetAsync(c->d_delta, 0, c->n_slots * 4, c->st));
 	return 0;
 }
 
@@ -465,6 +475,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipSetDevice(c->dev));
 	(void)hipGetLastError();                                   /* whatever other users of the runtime left behind is not this pass's (see yakamd_pass_end) */
 	c->create_new = create_new;
+	if (!create_new && delta_ensure(c)) return -1;
 	if (create_new) { retained_drop(c); c->retain_broken = false; }
 	c->n_slices = 0;
 	c->bloom_mode = create_new && c->has_bloom && !c->gate_off;
@@ -748,6 +759,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		return 0;
 	}
 	const int img_nonempty = c->img_keys_total > 0;
+	if (img_nonempty && delta_ensure(c)) return -1;
 	if (c->bloom_mode && bloom_materialise(c)) return -1;
 	if (acc_reserve(c, (u64)n_rec) || new_reserve(c, n_rec)) return -1;
 	u64 h_cnt[YKC_N];
@@ -1248,10 +1260,10 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	std::vector<u32> trail(P, 0);
 	std::vector<u64> lp_host(P, 0);
 	u32 *d_m = 0, *d_trail = 0; u64 *d_ro = 0, *d_lp2 = 0;
-	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
+	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
 	ReplayTask *d_tasks = 0; R2Tab *d_tabs = 0; R2Act *d_acts = 0; R2Load *d_ld = 0; R2Pub *d_pub = 0;
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
-		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so); dfree(nd);
+		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so);
 		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
 	} };
 	if (d_lastput) {
@@ -1339,9 +1351,22 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			lp_host[p] = 0;                                          /* no put-call can have hit a sub-table that holds nothing: never let a stray time grow it */
 		}
 	}
-	if ((par && dmalloc(&sp, 2 * scr_n)) || dmalloc(&nk, tot_ext) || dmalloc(&nu, tot_ext / 32 + 1) || dmalloc(&su, scr_n / 32 + 1) || dmalloc(&so, scr_n) || dmalloc(&nd, tot) ||
+	/* Every sub-table that holds anything is a large one and ends at the capacity the arena reserves for it (no trailing doubling left out): the
+	 * two buffers the doublings alternate between are then laid out exactly like the arena, and whichever holds most of the final tables BECOMES the
+	 * table image -- the others' tables are copied over, nothing else is (the copy of every slot into a third array was 12 ms and 34 GB beside a
+	 * 2 Gb assembly).  k_replay's side arena is then all that `nk` / `nu` hold; they are addressed from `tot` on like its scratch */
+	bool inplace = only_side && env_i64("YAKAMD_R2_INPLACE", 1) != 0;
+	for (int p = 0; p < P && inplace; ++p) if (large[p] && (1ull << bitsF[p]) != std::max<u64>(32, capm[p])) inplace = false;
+	const u64 nk_lo = inplace ? tot : 0;
+	u64 *nk_al = 0; u32 *nu_al = 0, *img_u = 0;                  /* what was allocated: nk / nu below are shifted by nk_lo; img_u: the image's bitmap when a buffer becomes the image */
+	struct GuardNk { std::function<void()> f; ~GuardNk() { f(); } } guard_nk{ [&]() { dfree(nk_al); dfree(nu_al); dfree(img_u); nk = 0; nu = 0; } };
+	if ((par && dmalloc(&sp, 2 * scr_n)) || dmalloc(&nk_al, tot_ext - nk_lo) || dmalloc(&nu_al, (tot_ext - nk_lo) / 32 + 1) || dmalloc(&su, scr_n / 32 + 1) || dmalloc(&so, scr_n) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
-	if (only_side) {
+	nk = nk_al - nk_lo; nu = nu_al - nk_lo / 32;
+	if (inplace) {
+		HIPCK(hipMemsetAsync(nk_al, 0xff, (tot_ext - tot) * 8, c->st));
+		HIPCK(hipMemsetAsync(nu_al, 0, ((tot_ext - tot) / 32 + 1) * 4, c->st));
+	} else if (only_side) {
 		/* k_r2_publish writes every slot and every bitmap word of a large sub-table: only the side arena and the (empty, 32-slot) regions of
 		 * the other sub-tables need the empty pattern -- not 8 bytes per slot of the whole arena (1 Gb assembly: 2.9 ms) */
 		HIPCK(hipMemsetAsync(nk + tot, 0xff, (tot_ext - tot) * 8, c->st));
@@ -1359,7 +1384,6 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		HIPCK(hipMemsetAsync(nk, 0xff, tot_ext * 8, c->st));
 		HIPCK(hipMemsetAsync(nu, 0, (tot_ext / 32 + 1) * 4, c->st));
 	}
-	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
 	if (d_lastput) HIPCK(hipMemcpyAsync(d_lp2, lp_host.data(), P * 8, hipMemcpyHostToDevice, c->st));
 	legacy_replay_launch(c, tasks, d_tasks, nk, nu, su - scr_lo / 32, so - scr_lo, sp ? sp - 2 * scr_lo : 0, d_rec_kc, d_rec_t, d_lastput ? d_lp2 : 0, d_ob, d_oc);
@@ -1374,7 +1398,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	const int SEGLOG = yk_r2_seg_log();
 	u64 tot2 = 0, nseg_tot = 0; u32 bmaxF = 0, bmaxS = 0;
 	for (int p = 0; p < P; ++p) {
-		tabs[p].off = tot2; tabs[p].rec_off = rec_off[p];
+		tabs[p].off = inplace ? new_off[p] : tot2; tabs[p].rec_off = rec_off[p];
 		if (!large[p]) continue;
 		if (cap0[p] <= SMALLCAP && (ob[p] != bitsS[p] || oc[p] != cntS[p])) return fail("replay: sub-table %d left k_replay with 2^%u slots / %u keys, the schedule says 2^%u / %u", p, ob[p], oc[p], bitsS[p], cntS[p]);
 		tot2 += 1ull << bitsF[p];
@@ -1402,6 +1426,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		}
 		pub[p].bits = bitsF[p]; pub[p].src = src;
 	}
+	if (inplace) tot2 = tot;                                     /* the buffers are arenas */
 	const u32 spill_cap = (u32)std::min<u64>(1u << 28, std::max<u64>(1u << 20, tot2 / 16));   /* also the list of long runs of a doubling round */
 	u64 n_keys = 0;
 	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
@@ -1446,7 +1471,27 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		}
 		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, c->st); lap("place", k, bp, &tl); }
 	}
-	yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, nk, nu, c->st);
+	u64 *img_k = 0;                                               /* the new image, once it is certain */
+	if (inplace) {
+		u64 in1 = 0, in0 = 0;
+		for (int p = 0; p < P; ++p) if (large[p]) (pub[p].src ? in1 : in0) += 1ull << bitsF[p];
+		u64 *A = in1 > in0 ? K1 : K0;
+		if (dmalloc(&img_u, tot / 32 + 1)) return -1;
+		/* the regions of the sub-tables that hold nothing: empty pattern, no bit */
+		for (int p = 0; p < P;) {
+			if (large[p]) { ++p; continue; }
+			int q = p;
+			while (q < P && !large[q]) ++q;
+			const u64 a = new_off[p], b = q < P ? new_off[q] : tot;
+			HIPCK(hipMemsetAsync(A + a, 0xff, (b - a) * 8, c->st));
+			HIPCK(hipMemsetAsync(img_u + a / 32, 0, (b - a) / 32 * 4, c->st));
+			p = q;
+		}
+		for (int p = 0; p < P; ++p) pub[p].new_off = tabs[p].off;
+		HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
+		yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, A, img_u, c->st);   /* a table already in A only gets its bitmap */
+		img_k = A;
+	} else yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, nk, nu, c->st);
 	lap("publish", n_steps, bmaxF, &tl);
 	u32 h_fail = 0;
 	HIPCK(hipMemcpyAsync(&h_fail, d_fail, 4, hipMemcpyDeviceToHost, c->st));
@@ -1462,8 +1507,11 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		else { c->h_bits[p] = ob[p]; c->h_count[p] = oc[p]; }
 	}
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
-	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
-	nk = 0; nu = 0; nd = 0;
+	if (inplace) {
+		c->d_keys = img_k; c->d_used = img_u; img_u = 0;
+		if (img_k == K0) K0 = 0; else K1 = 0;                     /* the guard releases the other one */
+	} else { c->d_keys = nk_al; c->d_used = nu_al; nk_al = 0; nu_al = 0; }
+	c->n_slots = tot;
 	c->h_off = new_off;
 	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
@@ -1501,17 +1549,16 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 		tot += std::max<u64>(32, capm);
 	}
 	(void)d_seg_off;
-	u64 *nk = 0, *sp = 0; u32 *nu = 0, *su = 0, *so = 0, *nd = 0, *d_ob = 0, *d_oc = 0;
+	u64 *nk = 0, *sp = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0;
 	ReplayTask *d_tasks = 0;
-	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {   /* nk / nu / nd are handed to the context on success (set to 0 there) */
-		dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc); dfree(nk); dfree(nu); dfree(nd);
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {   /* nk / nu are handed to the context on success (set to 0 there) */
+		dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc); dfree(nk); dfree(nu);
 	} };
 	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
-	if ((par && dmalloc(&sp, 2 * tot)) || dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) || dmalloc(&nd, tot) ||
+	if ((par && dmalloc(&sp, 2 * tot)) || dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) ||
 	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
 	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
 	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
-	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
 	/* few, large sub-tables (a shard of a multi-GPU job): more lanes per sub-table */
 	const int n_active = c->phi - c->plo;
@@ -1534,8 +1581,8 @@ static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg
 	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
-	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
-	nk = 0; nu = 0; nd = 0;
+	c->d_keys = nk; c->d_used = nu; c->n_slots = tot;
+	nk = 0; nu = 0;
 	c->h_off = new_off;
 	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
@@ -1940,8 +1987,9 @@ static int64_t pass_end_body(yakamd_ctx *c)
 	int64_t n_ins = 0;
 	if (c->k >= 32 && yk_bad_hash_seen(c->st)) { pass_free(c); return fail("a 64-bit k-mer hash equals the empty-slot pattern: unsupported input for k >= 32"); }
 	if (!c->create_new) {
-		yk_launch_img_fold(img_view(c), c->n_slots, c->st);
+		if (c->d_delta) yk_launch_img_fold(img_view(c), c->n_slots, c->st);
 		HIPCK(hipStreamSynchronize(c->st));
+		dfree(c->d_delta);
 		c->host_valid = false;
 		retained_drop(c);                                        /* used or not: the next pass is another input's */
 	} else if (c->or_mode && !(c->fast && !c->acc.s)) {
@@ -1954,7 +2002,7 @@ static int64_t pass_end_body(yakamd_ctx *c)
 	} else {
 		if (c->fast && fast_abandon(c)) return -1;          /* cannot happen today; keeps the invariant explicit */
 		const u64 before = c->keys_at_begin;                 /* slices counted earlier in this pass included */
-		if (c->img_keys_total) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* put-calls that hit existing keys */
+		if (c->img_keys_total && c->d_delta) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* put-calls that hit existing keys */
 		std::vector<u32> m(P, 0);
 		std::vector<u64> seg_off(P + 1, 0);
 		u32 *d_segcnt = 0, *d_segcur = 0; u64 *d_segoff = 0, *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
@@ -2111,17 +2159,16 @@ static int resize_tables(yakamd_ctx *c, const std::vector<u32> &new_bits)
 		t.new_off = new_off[p] = tot;
 		tot += std::max<u64>(32, std::max(n, N));
 	}
-	u64 *nk = 0; u32 *nu = 0, *su = 0, *nd = 0; ResizeTask *d_tasks = 0;
-	if (dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&nd, tot) || dmalloc(&d_tasks, P)) return -1;
+	u64 *nk = 0; u32 *nu = 0, *su = 0; ResizeTask *d_tasks = 0;
+	if (dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&d_tasks, P)) return -1;
 	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
 	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
-	HIPCK(hipMemsetAsync(nd, 0, tot * 4, c->st));
 	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ResizeTask), hipMemcpyHostToDevice, c->st));
 	yk_launch_resize(d_tasks, P, c->d_keys, c->d_used, nk, nu, su, c->st);
 	HIPCK(hipStreamSynchronize(c->st));
 	dfree(su); dfree(d_tasks);
 	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
-	c->d_keys = nk; c->d_used = nu; c->d_delta = nd; c->n_slots = tot;
+	c->d_keys = nk; c->d_used = nu; c->n_slots = tot;
 	c->h_off = new_off; c->h_bits = bits_after;
 	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
