@@ -125,6 +125,160 @@ def maybe_spawn(a):
                               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
 
+def run_multi_c(a):
+    """N > 1, the product's own multi-GPU driver (yakamd_count_multi_dev, the device-resident twin of yak_count() under YAKAMD_GPUS): ONE process
+    -- rank 0 -- holds every GPU of the node, the library partitions the chunks on their devices, exchanges the records (RCCL grouped send / recv
+    over xGMI, or peer copies) and counts every rank's prefix range; the other ranks torch.distributed.run started only take part in the
+    barriers (gloo: they never touch a GPU).  Default workload: weak scaling of BASELINE configs[2] -- 75 M x 150 bp reads per GPU (8 GPUs = the
+    600 M reads), G = 5 x reads, e = 0.1 %, no filter, one pass; --bf-shift B runs the filtered two-pass protocol instead."""
+    import torch
+    import torch.distributed as dist
+    import yak_amd
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+    P = 1 << PRE
+    if P % a.gpus:
+        raise SystemExit("the number of GPUs must divide 1024 sub-tables")
+    bf = a.bf_shift if a.bf_shift_given else 0
+    per_gpu = a.reads if a.reads_given else 75_000_000
+    if a.scaling == "strong":
+        if a.total_reads <= 0:
+            raise SystemExit("--scaling strong needs --total-reads")
+        per_gpu = a.total_reads // a.gpus
+    err = 0.001 if bf == 0 else 0.005
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if rank != 0:                                           # the job is rank 0's process; the others keep the launcher's contract
+        for _ in range(3):
+            barrier()
+        dist.destroy_process_group()
+        return
+    L = yak_amd.lib()
+    n_dev = torch.cuda.device_count()
+    if L.yakamd_device_count() < 1 or n_dev < 1:
+        raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")
+    N = a.gpus
+    devs = [r % n_dev for r in range(N)]                     # fewer devices than ranks: ranks share them (a one-GPU box posing as N)
+    sdev = []
+    for d in devs:
+        if d not in sdev:
+            sdev.append(d)
+    S = len(sdev)
+    genome = 5 * per_gpu * N
+    rec_len = READ_LEN + 1
+    # the job's reads, dealt in rounds of one chunk per device (chunk c = round * S + device: the job's own read numbering, as yak_count() deals a file)
+    per_dev = per_gpu * N // S
+    chunk_reads = min(per_dev, max(1, a.batch_reads if a.batch_reads_given else (1 << 29) // rec_len))
+    n_rounds = -(-per_dev // chunk_reads)
+    threads = min(os.cpu_count() or 8, 64)
+    syn = synth_lib()
+    h_buf = torch.empty(chunk_reads * rec_len, dtype=torch.uint8, pin_memory=True)
+    bufs, ptrs, sizes = [], [], []
+    tg = time.perf_counter()
+    for b in range(n_rounds):
+        for s in range(S):
+            first = (b * S + s) * chunk_reads
+            n_reads = max(0, min(chunk_reads, per_dev - b * chunk_reads))
+            t = torch.empty(max(16, n_reads * rec_len), dtype=torch.uint8, device=f"cuda:{sdev[s]}")
+            if n_reads:
+                syn.yaksynth_reads(h_buf.data_ptr(), n_reads, READ_LEN, genome, 42, err, 0.0005, first, threads)
+                t[:n_reads * rec_len].copy_(h_buf[:n_reads * rec_len])
+                torch.cuda.synchronize(sdev[s])
+            bufs.append(t); ptrs.append(t.data_ptr()); sizes.append(n_reads * rec_len)
+    gen_s = time.perf_counter() - tg
+    d_chunk = (C.c_void_p * len(ptrs))(*ptrs)
+    n_bytes = (C.c_int64 * len(sizes))(*sizes)
+    dev_arr = (C.c_int * N)(*devs)
+    opt = yak_amd.CoptT(); L.yak_copt_init(C.byref(opt)); opt.k, opt.pre, opt.bf_shift, opt.bf_n_hash = K, PRE, bf, N_HASH
+    exch = C.c_int(-1)
+
+    def sync_all():
+        for d in sdev:
+            torch.cuda.synchronize(d)
+
+    def step(keep=False):
+        h = L.yakamd_count_multi_dev(C.byref(opt), None, N, dev_arr, n_rounds, d_chunk, n_bytes, C.byref(exch))
+        if not h:
+            raise RuntimeError("yakamd_count_multi_dev: " + yak_amd._err())
+        if bf > 0:
+            L.yak_ch_destroy_bf(h); L.yak_ch_clear(h, 1)
+            if not L.yakamd_count_multi_dev(C.byref(opt), h, N, dev_arr, n_rounds, d_chunk, n_bytes, C.byref(exch)):
+                raise RuntimeError("yakamd_count_multi_dev (count pass): " + yak_amd._err())
+            L.yak_ch_shrink(h, 2, 1023, 1)
+        sync_all()
+        tot = h.contents.tot
+        if keep:
+            return h, tot
+        L.yak_ch_destroy(h)
+        return None, tot
+
+    for _ in range(a.warmup):
+        step()
+    sync_all(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        _, tot = step()
+    sync_all(); barrier()
+    dt = time.perf_counter() - t0
+    inst = sum(sizes) // rec_len * (READ_LEN - K + 1) * (2 if bf else 1)
+    verify = None
+    if a.job_md5 or per_gpu * N <= 4_000_000:
+        # the sharded table's .yak bytes against ONE unsharded table fed the same stream, chunk after chunk
+        h, _ = step(keep=True)
+        tm = yak_amd.Table(K, PRE, N_HASH, bf, ptr=h)
+        md5_n = tm.dump_md5()[0]
+        tm.close()
+        torch.cuda.set_device(sdev[0])
+        t1 = yak_amd.Table(K, PRE, N_HASH, bf)
+        feeds, off = [], 0
+        for i, (p_, n_) in enumerate(zip(ptrs, sizes)):
+            if n_:
+                if S > 1:                                    # bring the chunk to device 0
+                    c0 = bufs[i].to(f"cuda:{sdev[0]}"); bufs.append(c0); p_ = c0.data_ptr()
+                feeds.append((p_, n_, off))
+            off += n_
+        t1.count_pass(1, feeds)
+        if bf > 0:
+            t1.destroy_bf(); t1.clear(); t1.count_pass(0, feeds); t1.shrink(2, 1023)
+        md5_1 = t1.dump_md5()[0]
+        t1.close()
+        verify = {"job_yak_md5": md5_n, "one_table_yak_md5": md5_1, "equals_one_table": md5_n == md5_1}
+        if md5_n != md5_1:
+            raise SystemExit("FAILED: the sharded job's .yak differs from the single table's")
+    barrier()
+    ms = dt / a.steps * 1e3
+    by = (32.0 if bf == 0 else 16.0 + 128.0 + 16.0 + 16.0 + 8.0 + 8.0) * (inst / (2 if bf else 1))
+    out = {"metric": "distinct k-mers counted/sec (k=31), prefix-sharded over the GPUs of one node, .yak bit-exact",
+           "value": tot / (dt / a.steps), "unit": "distinct k-mers/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": f"yak count -k{K}" + (f" -b{bf}, both passes + shrink" if bf else ", no filter, one pass") +
+                                  f" on {per_gpu * N} x {READ_LEN} bp synthetic reads ({per_gpu} per GPU; G={genome}, e={err * 100:g}%, N=0.05%), 30x"
+                                  + ("; 8 GPUs = BASELINE configs[2]" if (bf == 0 and per_gpu == 75_000_000) else ""),
+                      "reads_per_gpu": per_gpu, "k": K, "pre": PRE, "bf_shift": bf,
+                      "sharding": f"{N} ranks own {P // N} sub-tables each; per round one chunk of {chunk_reads} reads per device, k-mers grouped by prefix on the device that holds the chunk, "
+                                  "8-byte tagged records to the owner of their prefix",
+                      "driver": "C: yakamd_count_multi_dev (libyak_amd.so), one process holding all devices; torch only allocates the input buffers",
+                      "exchange": {0: "none (all ranks on one device: slices are fed where the partition left them)", 1: "RCCL grouped ncclSend/ncclRecv (one round per chunk set)",
+                                   2: "hipMemcpyPeerAsync peer copies (RCCL unavailable or switched off)"}.get(exch.value, "?"),
+                      "devices": devs, "rounds": n_rounds},
+           "kmer_instances_per_s": inst / (dt / a.steps), "final_distinct": tot,
+           "input_generation_s_not_timed": round(gen_s, 2),
+           "roofline": {"bound": "hbm", "kernel": "whole job step (partition + exchange + per-rank count + exact layout), all GPUs", "achieved": by / (dt / a.steps) / 1e9,
+                        "peak": HBM_PEAK_GBS * S, "unit": "GB/s", "frac": by / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * S), "traffic": None,
+                        "algorithmic_bytes_per_instance": by / max(1, inst / (2 if bf else 1))},
+           "verify": verify}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,11 +309,16 @@ def main():
     ap.add_argument("--no-nofilter", action="store_true", help="skip the unfiltered-protocol side measurement (roofline.no_bloom_step_frac)")
     ap.add_argument("--no-retain", action="store_true", help="pass 2 extracts and hashes the input again instead of counting the records pass 1 retained")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default); gloo lets several ranks share one GPU for testing")
+    ap.add_argument("--driver", default="c", choices=["c", "torch"], help="N > 1: c = the library's own multi-GPU driver (yakamd_count_multi_dev: one process, RCCL inside the library; default); "
+                                                                          "torch = one process per GPU, yak_amd/shard.py + torch.distributed all-to-all")
     a = ap.parse_args()
     a.reads_given = any(x == "--reads" or x.startswith("--reads=") for x in sys.argv[1:])
     a.warmup_given = any(x == "--warmup" or x.startswith("--warmup=") for x in sys.argv[1:])
+    a.batch_reads_given = any(x == "--batch-reads" or x.startswith("--batch-reads=") for x in sys.argv[1:])
     a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
+    if a.gpus > 1 and a.driver == "c" and a.config == "cfg2" and not a.force_exchange:
+        return run_multi_c(a)
     if a.config == "nofilter":
         a.bf_shift = 0
     if a.config in ("cfg3shard", "cfg4", "cfg5"):

@@ -133,6 +133,17 @@ int yakamd_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 /* diagnostics: [0] doublings done by the parallel replay routine, [1] sent back to the serial one */
 void yakamd_debug_counters(uint32_t *out4);
 
+/* yak_count() on several GPUs with the input already in HBM (the multi-GPU driver of reference count.c:129-143's kt_for over prefixes, without
+ * the reader): the stream is cut into rounds of one chunk per DISTINCT device of dev_of_rank (in the order the devices first appear there); chunk s
+ * of round b lies at d_chunk[b * S + s] on that device, n_bytes[b * S + s] bytes of the base image (ASCII, sequences separated by a non-ACGT byte;
+ * at most 2^31 - 4096; 0 = none); stream order = round by round, device by device, exactly as yak_count() deals a file under YAKAMD_GPUS.  Every
+ * device groups its chunk's k-mers by prefix, one RCCL grouped send / recv per round (or peer copies, or nothing on one device) moves them to their
+ * owners, each rank counts its prefix range.  h0 == 0: returns a new table sharded over n_rank ranks (every yak_ch_* entry point takes it);
+ * h0 != 0 (a table this call made): counts the chunks' k-mers that are in it (count.c:155-157) and returns h0.  NULL on failure.
+ * *exchange_out (may be NULL): 0 nothing exchanged (one device), 1 RCCL, 2 peer copies */
+yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
+                                 const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out);
+
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
 

@@ -28,7 +28,7 @@ def run_bench(args, nproc=1, port=29547):
 @pytest.mark.parametrize("bf", [34, 0])
 def test_two_ranks_equal_one_rank(bf):
     common = ["--bf-shift", str(bf), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--no-qv", "--job-md5"]
-    two = run_bench(["--gpus", "2", "--backend", "gloo", "--reads", "150000"] + common, nproc=2, port=29547 + bf)
+    two = run_bench(["--gpus", "2", "--driver", "torch", "--backend", "gloo", "--reads", "150000"] + common, nproc=2, port=29547 + bf)
     one = run_bench(["--reads", "300000"] + common)
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["final_distinct"] == one["final_distinct"] and one["final_distinct"] > 0
@@ -44,3 +44,15 @@ def test_single_rank_exchange_path_matches_direct_path():
     c = run_bench(common + ["--force-exchange", "--no-overlap"])
     assert a["final_distinct"] == b["final_distinct"] == c["final_distinct"] > 0
     assert a["job_yak_md5"] == b["job_yak_md5"] == c["job_yak_md5"]
+
+
+@pytest.mark.parametrize("n,bf,extra", [(2, 0, []), (2, 34, []), (4, 0, ["--batch-reads", "70000"])], ids=["two_ranks_no_filter", "two_ranks_filtered_protocol", "four_ranks_several_rounds"])
+def test_bench_n_gpus_runs_the_librarys_own_driver(n, bf, extra):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, N processes): rank 0 runs the library's C driver
+    (yakamd_count_multi_dev) over the N ranks -- on this one-GPU box they share device 0, so nothing is exchanged -- and the sharded table's
+    .yak bytes equal those of ONE table fed the same stream (the bench compares them itself under --job-md5 and fails loudly)"""
+    args = ["--gpus", str(n), "--reads", "150000", "--steps", "1", "--warmup", "0", "--job-md5"] + (["--bf-shift", str(bf)] if bf else []) + extra
+    r = run_bench(args, nproc=n, port=29580 + n + bf)
+    assert r["n_gpus"] == n and r["verify"]["equals_one_table"] and r["final_distinct"] > 0
+    assert r["config"]["driver"].startswith("C: yakamd_count_multi_dev") and r["config"]["exchange"].startswith("none")
+    assert r["config"]["bf_shift"] == bf and r["config"]["reads_per_gpu"] == 150000

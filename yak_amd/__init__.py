@@ -32,7 +32,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
     "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
-    "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances",
+    "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
 ]
 
 
@@ -153,6 +153,8 @@ def lib():
     L.yakamd_retain_input.restype = C.c_int; L.yakamd_retain_input.argtypes = [P(ChT), C.c_int]
     L.yakamd_count_retained.restype = C.c_int; L.yakamd_count_retained.argtypes = [P(ChT)]
     L.yakamd_retained_instances.restype = C.c_int64; L.yakamd_retained_instances.argtypes = [P(ChT)]
+    L.yakamd_count_multi_dev.restype = P(ChT)
+    L.yakamd_count_multi_dev.argtypes = [P(CoptT), P(ChT), C.c_int, P(C.c_int), C.c_int, P(C.c_void_p), P(C.c_int64), P(C.c_int)]
     L.yakamd_qv_reduce_dev.restype = C.c_int
     L.yakamd_qv_reduce_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]

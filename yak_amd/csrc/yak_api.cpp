@@ -1028,6 +1028,8 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const s
  * feeds the slices in chunk order, which is the stream order of the file, so the N-GPU bytes are the
  * 1-GPU bytes.  librccl is opened only when a job asks for several distinct GPUs.
  * ------------------------------------------------------------------------------------------ */
+static bool env_fast_default() { const char *f = getenv("YAKAMD_FAST"); return !(f && atoi(f) == 0); }   /* the exclusive-ownership path (the only one that takes tagged records) is on */
+
 struct RcclApi {
 	void *lib;
 	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
@@ -1064,6 +1066,7 @@ struct MultiJob {
 	std::vector<uint8_t*> d_base[2];                           /* [set][slot]: chunk of sequence */
 	std::vector<uint64_t*> d_send[2], d_recv[2];               /* [set][slot]: records grouped by prefix / slices received from the other slots */
 	int64_t chunk, send_words, recv_words;
+	bool ext_base;                                             /* d_base points at the caller's device buffers (yakamd_count_multi_dev) */
 };
 
 /* no filter + a plain file of more than YAKAMD_AUTO_SWEEP_GB (2.5) GB: nearly every k-mer instance may be a key of its own (an assembly),
@@ -1115,7 +1118,7 @@ static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *
 	return N;
 }
 
-static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
+static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, int64_t chunk_dev = 0, bool tagged_only = false)   /* chunk_dev > 0: the chunks are the caller's device buffers of at most that many bytes */
 {
 	J->N = N; J->P = P; J->dev = dev;
 	J->sdev.clear(); J->slot_of.assign(N, 0);
@@ -1130,8 +1133,10 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
 	for (int x = 0; x < 2; ++x) { J->d_base[x].assign(S, 0); J->d_send[x].assign(S, 0); J->d_recv[x].assign(S, 0); }
 	const char *c = getenv("YAKAMD_MGPU_CHUNK");
 	J->chunk = c && atoll(c) > 0 ? atoll(c) : (int64_t)1 << 28;
+	if (chunk_dev > 0) J->chunk = chunk_dev;
 	J->chunk = (J->chunk + 4095) & ~(int64_t)4095;
-	J->send_words = 2 * J->chunk;                             /* one 16-byte record per position at most (8-byte tagged records use half of it) */
+	J->ext_base = chunk_dev > 0;
+	J->send_words = (tagged_only ? 1 : 2) * J->chunk;          /* one 16-byte record per position at most (8-byte tagged records use half of it) */
 	/* a slot receives, for the ranks it hosts, their share of the S - 1 other chunks: (ranks here / N) each on average; refused beyond 1.5 x that */
 	int most = 0;
 	for (int s = 0; s < S; ++s) { int n_here = 0; for (int r = 0; r < N; ++r) n_here += J->slot_of[r] == s; most = std::max(most, n_here); }
@@ -1148,10 +1153,10 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev)
 		if (hipSetDevice(J->sdev[s]) != hipSuccess || hipStreamCreate(&J->st[s]) != hipSuccess || hipStreamCreateWithFlags(&J->cp[s], hipStreamNonBlocking) != hipSuccess) return false;
 		if (!J->use_rccl) for (int q = 0; q < S; ++q) if (q != s) (void)hipDeviceEnablePeerAccess(J->sdev[q], 0);
 		for (int x = 0; x < 2; ++x) {
-			J->d_base[x][s] = (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
+			J->d_base[x][s] = J->ext_base ? 0 : (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
 			J->d_send[x][s] = (uint64_t*)yakamd_dev_alloc((size_t)J->send_words * 8);
 			J->d_recv[x][s] = J->recv_words ? (uint64_t*)yakamd_dev_alloc((size_t)J->recv_words * 8) : 0;
-			if (!J->d_base[x][s] || !J->d_send[x][s] || (J->recv_words && !J->d_recv[x][s])) return false;
+			if ((!J->ext_base && !J->d_base[x][s]) || !J->d_send[x][s] || (J->recv_words && !J->d_recv[x][s])) return false;
 		}
 	}
 	(void)hipGetLastError();
@@ -1162,7 +1167,7 @@ static void multi_close(MultiJob *J)
 {
 	for (int s = 0; s < J->S; ++s) {
 		hipSetDevice(J->sdev[s]);
-		for (int x = 0; x < 2; ++x) { yakamd_dev_free(J->d_base[x][s]); yakamd_dev_free(J->d_send[x][s]); yakamd_dev_free(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
+		for (int x = 0; x < 2; ++x) { if (!J->ext_base) yakamd_dev_free(J->d_base[x][s]); yakamd_dev_free(J->d_send[x][s]); yakamd_dev_free(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
 		if (J->st[s]) { hipStreamDestroy(J->st[s]); J->st[s] = 0; }
 		if (J->cp[s]) { hipStreamDestroy(J->cp[s]); J->cp[s] = 0; }
 		if (J->use_rccl && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
@@ -1177,6 +1182,7 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
 	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
 	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
+	for (int s = 0; s < S; ++s) if (fill[s] * W > J->send_words) { fprintf(stderr, "[E::yak_count] a chunk of %lld positions does not fit the send buffer (%lld words): 16-byte records were not planned for\n", (long long)fill[s], (long long)J->send_words); return false; }
 	std::vector<std::vector<uint64_t> > bst(S, std::vector<uint64_t>(P + 1, 0));
 	std::vector<int64_t> n_rec(S, 0);
 	std::vector<char> ok(std::max(N, S), 1);
@@ -1219,6 +1225,22 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 			}
 		if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
 		for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
+		if (!ok[0] && J->use_rccl) {
+			/* the collective library let the round down: the same slices as plain peer copies, from here on */
+			fprintf(stderr, "[W::yak_count] RCCL exchange failed (%s): peer copies from now on\n", hipGetErrorString(hipGetLastError()));
+			J->use_rccl = false; ok[0] = 1;
+			for (int s = 0; s < S; ++s) for (int q = 0; q < S; ++q) if (q != s) { hipSetDevice(J->sdev[s]); (void)hipDeviceEnablePeerAccess(J->sdev[q], 0); }
+			(void)hipGetLastError();
+			for (int s = 0; s < S; ++s)
+				for (int d = 0; d < N; ++d) {
+					const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
+					const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
+					if (cnt == 0 || s == sd) continue;
+					hipSetDevice(J->sdev[sd]);
+					if (hipMemcpyPeerAsync(J->d_recv[x][sd] + roff[d][s] * W, J->sdev[sd], J->d_send[x][s] + bst[s][lo] * W, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
+				}
+			for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
+		}
 		if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
 	}
 	{	/* every owner takes its slices, in chunk order = stream order; owners that share a device take turns (a feed may count a whole slice of the pass) */
@@ -1245,6 +1267,7 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 	return true;
 }
 
+static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector<int> &dev);
 static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t *h0, int N, const std::vector<int> &dev)
 {
 	FxReader fx;
@@ -1253,21 +1276,8 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	yak_ch_t *h = h0;
 	const int create_new = h0 ? 0 : 1;
 	if (h0 == 0) {                                             /* N tables, one per rank, each owning its prefix range */
-		yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
-		e->magic = EXT_MAGIC; e->n_sub = N; e->sub = (yak_ch_t**)calloc(N, sizeof(yak_ch_t*));
-		h = &e->pub;
-		h->k = opt->k; h->pre = opt->pre;
-		h->h = (yak_ch1_t*)calloc((size_t)P, sizeof(yak_ch1_t));
-		bool ok = true;
-		for (int r = 0; r < N && ok; ++r) {
-			yk_ctx_next_device(dev[r]);
-			e->sub[r] = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
-			ok = e->sub[r] && yakamd_set_shard(e->sub[r], r * (P / N), (r + 1) * (P / N)) == 0;
-		}
-		if (!ok) { for (int r = 0; r < N; ++r) if (e->sub[r]) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); fx.close_file(); return 0; }
-		e->ctx = 0;                                               /* no context of its own: every yakamd_* entry point refuses a sharded table instead of working on one shard */
-		h->n_hash = e->sub[0]->n_hash; h->n_shift = e->sub[0]->n_shift;
-		for (int p = 0; p < P; ++p) h->h[p].b = e->sub[0]->h[p].b;   /* descriptors only: "has a filter" for callers that look */
+		h = multi_table_new(opt, N, dev);
+		if (!h) { fx.close_file(); return 0; }
 	}
 	yak_ch_ext *e = (yak_ch_ext*)h;
 	MultiJob J;
@@ -1286,7 +1296,28 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	int64_t n_seq_tot = 0;
 	int g = 0;                                                 /* the slot whose chunk is being filled */
 	auto wait_worker = [&]() { if (worker.joinable()) worker.join(); if (!worker_ok) ok = false; };
+	/* host -> device through two pinned staging buffers: while one is on its way over the bus the reader copies the next piece into the other (a
+	 * copy from pageable memory is staged by the runtime anyway, but behind a synchronise per piece) */
+	const size_t STG = (size_t)std::max<int64_t>(1 << 20, getenv("YAKAMD_MGPU_STAGE") ? atoll(getenv("YAKAMD_MGPU_STAGE")) : (int64_t)32 << 20);
+	uint8_t *stg[2] = { 0, 0 };
+	hipEvent_t stg_ev[2] = { 0, 0 };
+	bool stg_busy[2] = { false, false };
+	int stg_i = 0;
+	for (int i = 0; i < 2 && ok; ++i) ok = hipHostMalloc((void**)&stg[i], STG) == hipSuccess && hipEventCreateWithFlags(&stg_ev[i], hipEventDisableTiming) == hipSuccess;
+	auto to_device = [&](int gdev, uint8_t *dst, const char *src, size_t n) -> bool {
+		hipSetDevice(J.sdev[gdev]);
+		for (size_t o = 0; o < n; o += STG) {
+			const size_t m = std::min(STG, n - o);
+			if (stg_busy[stg_i] && hipEventSynchronize(stg_ev[stg_i]) != hipSuccess) return false;
+			memcpy(stg[stg_i], src + o, m);
+			if (hipMemcpyAsync(dst + o, stg[stg_i], m, hipMemcpyHostToDevice, J.cp[gdev]) != hipSuccess || hipEventRecord(stg_ev[stg_i], J.cp[gdev]) != hipSuccess) return false;
+			stg_busy[stg_i] = true; stg_i ^= 1;
+		}
+		return true;
+	};
+	auto copies_done = [&]() { for (int s = 0; s < S && ok; ++s) { hipSetDevice(J.sdev[s]); ok = hipStreamSynchronize(J.cp[s]) == hipSuccess; } };
 	auto round = [&]() {
+		copies_done();                                          /* the chunks of this set are on their devices */
 		wait_worker();                                          /* at most one round in flight: its set becomes the one to fill next */
 		if (ok) {
 			const int x = cur;
@@ -1314,8 +1345,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 				}
 			}
 			if (fill[cur][g] == 0) t0[cur][g] = t_stream;
-			hipSetDevice(J.sdev[g]);
-			ok = hipMemcpyAsync(J.d_base[cur][g] + fill[cur][g], img, m, hipMemcpyHostToDevice, J.cp[g]) == hipSuccess && hipStreamSynchronize(J.cp[g]) == hipSuccess;
+			ok = to_device(g, J.d_base[cur][g] + fill[cur][g], img, m);
 			fill[cur][g] += (int64_t)m;
 			t_stream += m - back; img += m - back; n -= m - back;
 			if (fill[cur][g] == J.chunk || n > 0) { if (++g == S) round(); }
@@ -1341,6 +1371,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	}
 	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
 	wait_worker();
+	for (int i = 0; i < 2; ++i) { if (stg_busy[i]) (void)hipEventSynchronize(stg_ev[i]); if (stg_ev[i]) (void)hipEventDestroy(stg_ev[i]); if (stg[i]) (void)hipHostFree(stg[i]); }
 	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
 	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
 		 * scratch of only one of them is alive at a time (one device posing as N = the pass in N sweeps over prefix ranges: what lets a
@@ -1359,6 +1390,95 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", !worker_why.empty() ? worker_why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
+	return h;
+}
+
+/* a table sharded over N ranks (dev[r] = device of rank r), every rank owning its prefix range */
+static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector<int> &dev)
+{
+	const int P = 1 << opt->pre;
+	yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
+	e->magic = EXT_MAGIC; e->n_sub = N; e->sub = (yak_ch_t**)calloc(N, sizeof(yak_ch_t*));
+	yak_ch_t *h = &e->pub;
+	h->k = opt->k; h->pre = opt->pre;
+	h->h = (yak_ch1_t*)calloc((size_t)P, sizeof(yak_ch1_t));
+	bool ok = true;
+	for (int r = 0; r < N && ok; ++r) {
+		yk_ctx_next_device(dev[r]);
+		e->sub[r] = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
+		ok = e->sub[r] && yakamd_set_shard(e->sub[r], r * (P / N), (r + 1) * (P / N)) == 0;
+	}
+	if (!ok) { for (int r = 0; r < N; ++r) if (e->sub[r]) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); return 0; }
+	e->ctx = 0;                                               /* no context of its own: every yakamd_* entry point refuses a sharded table instead of working on one shard */
+	h->n_hash = e->sub[0]->n_hash; h->n_shift = e->sub[0]->n_shift;
+	for (int p = 0; p < P; ++p) h->h[p].b = e->sub[0]->h[p].b;   /* descriptors only: "has a filter" for callers that look */
+	return h;
+}
+
+/* The same job with its input already on the devices (the benchmark's N-GPU mode; a caller with its own reader): the stream is cut into rounds of
+ * one chunk per DEVICE -- chunk s of round b lies at d_chunk[b * S + s] on the s-th distinct device of `dev` (n_bytes[b * S + s] bytes of the base
+ * image, at most 2^31 - 4096; 0 = none), and the stream order is round by round, device by device, exactly as yak_count() deals a file.  h0 == 0:
+ * a new table sharded over the n_rank ranks (dev[r] = device of rank r; several ranks may share a device) comes back; h0 != 0: its k-mers are counted
+ * (count.c:155-157).  exchange_out (may be 0): 1 = RCCL grouped send / recv, 2 = peer copies, 0 = one device, nothing exchanged.  The caller keeps
+ * the chunks alive until the call returns */
+extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
+                                            const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out)
+{
+	const int P = 1 << opt->pre, N = n_rank;
+	if (N < 1 || P % N) { fprintf(stderr, "[E::yakamd_count_multi_dev] %d ranks do not divide the %d sub-tables\n", N, P); return 0; }
+	std::vector<int> dev(dev_of_rank, dev_of_rank + N);
+	if (h0) {
+		yak_ch_ext *e0 = (yak_ch_ext*)h0;
+		if (e0->n_sub != N) { fprintf(stderr, "[E::yakamd_count_multi_dev] the table is sharded over %d ranks, not %d\n", e0->n_sub > 0 ? e0->n_sub : 1, N); return 0; }
+		assert(h0->k == opt->k && h0->pre == opt->pre);
+	}
+	const int create_new = h0 ? 0 : 1;
+	yak_ch_t *h = h0 ? h0 : multi_table_new(opt, N, dev);
+	if (!h) return 0;
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	MultiJob J;
+	J.S = 0;
+	int64_t cmax = 4096;
+	{	/* the distinct devices, in rank order: that is the order of the chunks inside a round */
+		std::vector<int> sd;
+		for (int r = 0; r < N; ++r) if (std::find(sd.begin(), sd.end(), dev[r]) == sd.end()) sd.push_back(dev[r]);
+		for (int i = 0; i < n_rounds * (int)sd.size(); ++i) cmax = std::max<int64_t>(cmax, n_bytes[i]);
+	}
+	if (cmax > ((int64_t)1 << 31) - 4096) { fprintf(stderr, "[E::yakamd_count_multi_dev] a chunk holds at most 2^31 - 4096 stream positions\n"); if (!h0) yak_ch_destroy(h); return 0; }
+	const bool tagged_only = create_new && yakamd_tagged_ok(opt->k, opt->pre) && !getenv("YAKAMD_MGPU_REC16") && env_fast_default();
+	bool ok = multi_open(&J, N, P, dev, cmax, tagged_only || !create_new);
+	const int S = J.S;
+	yk_realtime();
+	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
+	std::string why;
+	uint64_t t_stream = 0;
+	for (int b = 0; b < n_rounds && ok; ++b) {
+		std::vector<int64_t> fill(S, 0);
+		std::vector<uint64_t> t0(S, 0);
+		for (int s = 0; s < S; ++s) {
+			fill[s] = n_bytes[(size_t)b * S + s];
+			t0[s] = t_stream; t_stream += (uint64_t)fill[s];
+			J.d_base[b & 1][s] = (uint8_t*)d_chunk[(size_t)b * S + s];
+		}
+		ok = multi_round(&J, b & 1, e, opt->k, opt->pre, create_new, fill, t0, &why);
+	}
+	const int exch = S == 1 ? 0 : J.use_rccl ? 1 : 2;
+	for (int x = 0; x < 2; ++x) for (int s = 0; s < S; ++s) J.d_base[x][s] = 0;
+	multi_close(&J);
+	{
+		std::vector<int64_t> n_ins(N, 0);
+		std::vector<std::thread> th;
+		std::vector<std::string> whyr(N);
+		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int r = 0; r < N; ++r) if (J.slot_of[r] == sd) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) whyr[r] = yakamd_last_error(); } });
+		for (auto &t : th) t.join();
+		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) { fprintf(stderr, "[E::yakamd_count_multi_dev] rank %d of %d (device %d): %s\n", r, N, dev[r], whyr[r].c_str()); ok = false; }
+		for (int r = 0; r < N; ++r) if (n_ins[r] >= 0) e->sub[r]->tot += (uint64_t)n_ins[r];
+	}
+	multi_tot(h);
+	if (exchange_out) *exchange_out = exch;
+	fprintf(stderr, "[M::%s::%.3f*%.2f] %d rounds of device-resident chunks; %ld distinct k-mers in the hash table (%d ranks, %s)\n", "yakamd_count_multi_dev",
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), n_rounds, (long)h->tot, N, exch == 0 ? "one device: nothing exchanged" : exch == 1 ? "RCCL exchange" : "peer copies");
+	if (!ok) { fprintf(stderr, "[E::yakamd_count_multi_dev] %s\n", !why.empty() ? why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
 }
 
