@@ -631,7 +631,7 @@ def main():
         ms_nb = (time.perf_counter() - tq) / 2 * 1e3
         nb_probe = {"ms_per_step": ms_nb, "distinct": tot_nb, "instances": st_nb["n_instances"], "bytes_per_instance": 32.0,
                     "step_frac": 32.0 * st_nb["n_instances"] / (ms_nb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "phase_ms": {k: round(v, 3) for k, v in st_nb.items() if k.startswith("ms_")}}
+                    "phase_ms": {k: round(v, 3) for k, v in st_nb.items() if k.startswith("ms_") and k != "ms_bloom"}}
 
     # the rate with the base image handed over from HOST memory in both passes (yakamd_feed_bases_host, what
     # yak_count() does after parsing) and the whole `yak-amd count` command on the same reads as a FASTQ file
@@ -733,7 +733,7 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc, pmc_src = {}, None
-    for cand_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for cand_ in (("r04_pmc_traffic_nofilter.json",) if a.bf_shift == 0 else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand_)))
             pmc_src = "profiles/" + cand_
@@ -742,12 +742,12 @@ def main():
             pass
     for k_ in kern:
         keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
-        cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift == 37 else []
+        cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift in (37, 0) else []
         steps_pmc = max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))     # k_lc2 (any template variant) runs once per step: the steps of the profiled command
         k_["traffic_bytes"] = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
         # how busy the HBM really is while this kernel (group) runs: counter bytes / its time / peak
         k_["hbm_util"] = (k_["traffic_bytes"] / (k_["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (k_["traffic_bytes"] and k_["ms"] > 0) else None
-    default_cfg = a.reads == 10_000_000 and world == 1 and a.bf_shift == 37
+    default_cfg = a.reads == 10_000_000 and world == 1 and a.bf_shift in (37, 0)
     step_traffic = None
     if default_cfg and pmc:                                       # every kernel of one protocol step, whatever its name
         steps_pmc = max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))
@@ -762,6 +762,7 @@ def main():
     ms_p1 = w.get("pass1", 0.0)
     frac = lambda by, ms: by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
     b_step = b_pass1 + b_pass2
+    b_step_nc = ((16.0 + 16.0 * f_ins) * n1 if bloom_on else 32.0 * n1) + b_pass2       # the same step without the 128 B per instance of bloom-block credit
     step_gbs = b_step / (ms_step * 1e-3) / 1e9 if world == 1 else None
     # the dominant KERNEL: the single kernel with the largest time (the extraction and replay rows are groups of several kernels)
     dom = max([k_ for k_ in kern if not k_["kernel"].startswith(("k_xpart", "k_r2_"))], key=lambda x: x["ms"])
@@ -778,8 +779,8 @@ def main():
                    "sharding": "prefix-sharded sub-tables, RCCL all-to-all of hashed k-mers" if sharded else "1 GPU"},
         "kmer_instances_per_s": inst_all / (dt / a.steps),
         "final_distinct": tot_all,
-        "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_")},
-                               "pass2": {k: round(v, 3) for k, v in s2.items() if k.startswith("ms_")} if s2 else None},
+        "phase_ms_last_step": {"pass1": {k: round(v, 3) for k, v in s1.items() if k.startswith("ms_") and k != "ms_bloom"},
+                               "pass2": {k: round(v, 3) for k, v in s2.items() if k.startswith("ms_") and k != "ms_bloom"} if s2 else None},
         "phase_wall_ms_last_step": {k: round(v, 2) for k, v in wall_timed.items()},
         "pass1_distinct_seen": s1["n_distinct_seen"], "pass1_table_keys": s1["n_new_keys"],
         "bloom_exact_resolutions": s1["n_bloom_candidates"],
@@ -799,6 +800,9 @@ def main():
                      "pass1_frac": frac(b_pass1, ms_p1),
                      "pass2_frac": frac(b_pass2, w.get("pass2", 0.0)) if s2 else None,
                      "step_frac": frac(b_step, ms_step if world == 1 else 0.0),
+                     "no_credit_step_frac": frac(b_step_nc, ms_step if world == 1 else 0.0),
+                     "no_credit_note": "the step priced without the model's 128 B per instance for the reference's bloom-block read-modify-write (this design stages each bloom range once in LDS): "
+                                       "pass 1 = 16 + 16 f_ins, pass 2 unchanged.  frac (credit in), hbm_util (counter bytes) and no_bloom_step_frac (the unfiltered protocol at 32 B) stand beside it",
                      "no_bloom_step_frac": nb_probe["step_frac"] if nb_probe else None,
                      "no_bloom_step": nb_probe,
                      "pass_bytes": {"pass1": b_pass1, "pass2": b_pass2, "per_instance_pass1": b_pass1 / max(1, n1), "per_instance_pass2": (b_pass2 / n2) if n2 else None},

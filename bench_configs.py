@@ -39,6 +39,26 @@ def _gold(name):
         return None
 
 
+def pmc_step_traffic(name):
+    """HBM bytes of ONE step of a configuration from its committed rocprofv3 counter passes (profiles/r04_pmc_traffic_<name>.json: FETCH_SIZE x 2 as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, of a `--steps 1 --warmup 0 --no-verify` run of that very command): (bytes, source) or (None, None)"""
+    fn = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{name}.json")
+    try:
+        d = json.load(open(fn))
+    except Exception:
+        return None, None
+    by = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in d.values() if isinstance(v, dict) and "launches" in v)
+    return by, f"profiles/r04_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE)"
+
+
+def _roof_traffic(roof, name, seconds):
+    by, src = pmc_step_traffic(name)
+    roof["traffic"] = by
+    roof["hbm_util"] = (by / seconds / 1e9 / HBM_PEAK_GBS) if by else None
+    roof["traffic_source"] = src
+    return roof
+
+
 def _timed(torch, steps, warmup, fn):
     for _ in range(warmup):
         fn()
@@ -159,11 +179,12 @@ def run_cfg4(a, torch, yak_amd):
            "config": {"workload": f"yak count -k{K} on a synthetic assembly: {a.contigs} contigs x {a.contig_len} bp tiling a random genome (tools/yaksynth -T, seed 42), "
                                   "no filter, one pass, base image resident in HBM", "k": K, "pre": PRE, "bf_shift": 0},
            "kmer_instances_per_s": inst / dt, "final_distinct": tot,
-           "phase_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
+           "phase_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_") and k != "ms_bloom"},
            "roofline": {"bound": "hbm", "kernel": "whole pass (extract + partition + insert + exact layout)", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_instance": 32.0,
                         "extract_insert_frac": by / ((stats["ms_extract"] + stats["ms_insert"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "verify": verify}
+    _roof_traffic(out["roofline"], f"cfg4_{a.contigs}x{a.contig_len}", dt)
     return out
 
 
@@ -220,8 +241,8 @@ def run_cfg5(a, torch, yak_amd):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"yak qv -p -K3.2g: {nq} x {QL} bp reads (e = 0.2 %) of the genome the table's {a.reads} x 150 bp reads come from (yak count -k31 -b37), "
                                    "reads resident in HBM, per-position lookup + per-read reduction + 1024-bin histogram", "k": K, "pre": PRE},
-            "roofline": {"bound": "hbm", "kernel": "k_lookup + k_qv_reduce", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_instance": 8.0},
+            "roofline": _roof_traffic({"bound": "hbm", "kernel": "k_lookup + k_qv_reduce", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_instance": 8.0}, "cfg5", dt),
             "verify": verify}
 
 
@@ -361,8 +382,8 @@ def run_cfg3shard(a, torch, yak_amd):
             "prediction": {"label": "PREDICTED, not measured: all ranks take this rank's time; the exchange (8-byte records over of-1 xGMI links at 80 % of 153 GB/s) is added in full, not overlapped",
                            "exchange_seconds": exch_s, "job_seconds": rank_s + exch_s, "job_distinct_kmers_per_s": tot * of / (rank_s + exch_s),
                            "job_reads": per_src * of},
-            "roofline": {"bound": "hbm", "kernel": "this rank's passes (own partition + feeds + finish)", "achieved": by / rank_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": by / rank_s / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "roofline": _roof_traffic({"bound": "hbm", "kernel": "this rank's passes (own partition + feeds + finish)", "achieved": by / rank_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": by / rank_s / 1e9 / HBM_PEAK_GBS, "traffic": None}, "cfg3shard", rank_s),
             "verify": verify}
 
 

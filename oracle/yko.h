@@ -84,6 +84,12 @@ int       yko_ch_dump(const yko_ch_t *h, const char *fn);
 yko_ch_t *yko_ch_restore(const char *fn);
 /* htab.c:396-476; mode as YAK_LOAD_* (yak.h:16-21); min_cnt / mid_cnt only in modes 2, 3 */
 yko_ch_t *yko_ch_restore_core(yko_ch_t *ch0, const char *fn, int mode, int min_cnt, int mid_cnt);
+/* Prefix-range mode (sizes whose tables do not fit the host at once: the 5 Gb assembly of BASELINE configs[3] needs ~80 GB): with a range set,
+ * the counting drivers below insert only the k-mers of sub-tables [lo, hi) -- every sub-table is a function of its own k-mers alone (htab.c:51-78,
+ * count.c:133 kt_for over prefixes), so the sub-tables of the range come out exactly as in a full run -- and yko_ch_dump_range writes the bytes
+ * of those sub-tables (behind the 16-byte header when lo == 0): the files of consecutive ranges, concatenated, are the full .yak file */
+void      yko_set_prefix_range(int lo, int hi);               /* lo < 0: all (the default) */
+int       yko_ch_dump_range(const yko_ch_t *h, const char *fn, int lo, int hi);
 /* serialise to memory in .yak format; caller frees *out */
 size_t    yko_ch_dump_mem(const yko_ch_t *h, uint8_t **out);
 /* sub-table introspection for tests */

@@ -447,6 +447,29 @@ size_t yko_ch_dump_mem(const yko_ch_t *h, uint8_t **out)
 	return sz;
 }
 
+int yko_ch_dump_range(const yko_ch_t *h, const char *fn, int lo, int hi)   /* htab.c:373-394, sub-tables [lo, hi) only; header iff lo == 0 */
+{
+	int p;
+	uint32_t t[3];
+	FILE *fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout;
+	if (!fp) return -1;
+	if (lo == 0) {
+		fwrite("YAK\2", 1, 4, fp);
+		t[0] = h->k; t[1] = h->pre; t[2] = YKO_COUNTER_BITS;
+		fwrite(t, 4, 3, fp);
+	}
+	for (p = lo; p < hi; ++p) {
+		const yko_set_t *g = h->h[p].h;
+		uint32_t i, cap = yko_set_capacity(g);
+		t[0] = cap; t[1] = g->count;
+		fwrite(t, 4, 2, fp);
+		for (i = 0; i < cap; ++i)
+			if (USED(g->used, i)) fwrite(&g->keys[i], 8, 1, fp);
+	}
+	if (fp != stdout) fclose(fp);
+	return 0;
+}
+
 int yko_ch_dump(const yko_ch_t *h, const char *fn)
 {
 	uint8_t *buf;

@@ -169,12 +169,16 @@ static int64_t fx_read(fx_t *f)
 }
 
 /* ------------------------------------------------------------------ chunked serial driver */
+static int g_range_lo = -1, g_range_hi = -1;                 /* yko_set_prefix_range: only these sub-tables are counted */
+void yko_set_prefix_range(int lo, int hi) { g_range_lo = lo; g_range_hi = hi; }
+
 static uint64_t flush_buffers(yko_ch_t *h, int create_new, yko_kbuf_t *buf)
 {
 	int p, P = 1 << h->pre;
 	uint64_t n_ins = 0;
 	for (p = 0; p < P; ++p) {                                /* count.c:133 kt_for over prefixes */
 		int64_t off = 0;
+		if (g_range_lo >= 0 && (p < g_range_lo || p >= g_range_hi)) { buf[p].n = 0; continue; }   /* the sub-tables are independent of each other */
 		/* yak_ch_insert_list takes an int count; feed long buckets in pieces (same put order) */
 		while (off < buf[p].n) {
 			int64_t w = buf[p].n - off;

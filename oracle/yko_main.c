@@ -52,15 +52,15 @@ int main(int argc, char *argv[])
 	yko_copt_t opt;
 	yko_ch_t *h;
 	const char *out = 0;
-	int c;
+	int c, rlo = -1, rhi = -1;
 	if (argc >= 2 && strcmp(argv[1], "qv") == 0) return main_qv(argc - 1, argv + 1);
 	if (argc < 2 || strcmp(argv[1], "count") != 0) {
-		fprintf(stderr, "Usage: yko count [-k31] [-p10] [-K chunk] [-t thr] [-b bloom_bits] [-H n_hash] [-o out.yak] <in.fa> [in2.fa]\n");
+		fprintf(stderr, "Usage: yko count [-k31] [-p10] [-K chunk] [-t thr] [-b bloom_bits] [-H n_hash] [-R lo:hi (sub-tables of this prefix range only; the outputs of consecutive ranges concatenate to the .yak file)] [-o out.yak] <in.fa> [in2.fa]\n");
 		return 1;
 	}
 	yko_copt_init(&opt);
 	--argc; ++argv;
-	while ((c = getopt(argc, argv, "k:p:K:t:b:H:o:")) >= 0) {
+	while ((c = getopt(argc, argv, "k:p:K:t:b:H:o:R:")) >= 0) {
 		if (c == 'k') opt.k = atoi(optarg);
 		else if (c == 'p') opt.pre = atoi(optarg);
 		else if (c == 'K') opt.chunk_size = parse_num(optarg);
@@ -68,12 +68,16 @@ int main(int argc, char *argv[])
 		else if (c == 'b') opt.bf_shift = atoi(optarg);
 		else if (c == 'H') opt.bf_n_hash = (int)parse_num(optarg);
 		else if (c == 'o') out = optarg;
+		else if (c == 'R') { if (sscanf(optarg, "%d:%d", &rlo, &rhi) != 2) return 1; }
 	}
 	if (argc - optind < 1 || opt.pre < YKO_COUNTER_BITS || opt.k >= 64) return 1;   /* main.c:30-52 */
+	if (rlo >= 0 && (rlo >= rhi || rhi > (1 << opt.pre))) return 1;
+	if (rlo >= 0) yko_set_prefix_range(rlo, rhi);
 	h = yko_count_protocol_file(argv[optind], argc - optind >= 2 ? argv[optind + 1] : 0, &opt);
 	if (h == 0) return 2;
 	fprintf(stderr, "[yko] %ld distinct k-mers\n", (long)h->tot);
-	if (out) yko_ch_dump(h, out);
+	if (out && rlo >= 0) yko_ch_dump_range(h, out, rlo, rhi);
+	else if (out) yko_ch_dump(h, out);
 	yko_ch_destroy(h);
 	return 0;
 }
