@@ -97,16 +97,26 @@ def run_cfg4_sweeps(a, yak_amd):
             hist = (C.c_int64 * 1024)()
             L.yak_ch_hist(h, hist, 1)
             tot = h.contents.tot
-            res.append((dt, tot, list(hist)))
+            md5 = None
+            g = _gold(f"cfg4_{a.contigs}x{a.contig_len}")
+            if g and not res and not a.no_verify:              # the .yak bytes against the golden of this very input (first chunking; the second must agree on the counts)
+                tm = yak_amd.Table(K, PRE, 0, 0, ptr=h)
+                md5, nbytes = tm.dump_md5()
+                tm.h = None
+                if (md5, nbytes) != (g["md5"], g["size"]):
+                    raise SystemExit(f"FAILED: .yak differs from the golden ({md5} / {nbytes} bytes against {g['md5']} / {g['size']})")
+            res.append((dt, tot, list(hist), md5))
             L.yak_ch_destroy(h)
-            L.yakamd_trim()
         for k_ in ("YAKAMD_GPUS", "YAKAMD_GPU_LIST", "YAKAMD_MGPU_CHUNK"):
             del os.environ[k_]
     finally:
         subprocess.call(["rm", "-rf", tmp])
-    dt, tot, hist = res[0]
+    dt, tot, hist, md5 = res[0]
+    g = _gold(f"cfg4_{a.contigs}x{a.contig_len}")
     verify = {"count_mass_equals_instances": sum(c * hist[c] for c in range(1024)) == inst and hist[1023] == 0, "sum_hist_equals_tot": sum(hist) == tot,
-              "chunking_independent": res[0][1:] == res[1][1:], "yak_size_bytes": 16 + 8 * (1 << PRE) + 8 * tot, "distinct": tot}
+              "chunking_independent": res[0][1:3] == res[1][1:3], "yak_size_bytes": 16 + 8 * (1 << PRE) + 8 * tot, "distinct": tot}
+    if md5:
+        verify.update(yak_md5=md5, golden_md5=g["md5"], equals_golden=md5 == g["md5"], golden_produced_by=g.get("produced_by"))
     if not all(v for v in verify.values() if isinstance(v, bool)):
         raise SystemExit(f"FAILED: {verify}")
     by = 32.0 * inst
@@ -123,9 +133,9 @@ def run_cfg4_sweeps(a, yak_amd):
 
 def run_cfg4(a, torch, yak_amd):
     if a.sweeps == 1 and a.contigs * a.contig_len > 2_500_000_000:
-        a.sweeps = 2                                           # beyond one pass's memory: the library's own rule (yak_api.cpp auto_sweeps: at most 1.4 GB of input per sweep) --
-        while a.sweeps < 16 and a.contigs * a.contig_len / a.sweeps > 1.4e9:
-            a.sweeps *= 2                                      # the default 50 x 100 Mb = BASELINE configs[3] runs in 4
+        a.sweeps = 2                                           # beyond one pass's memory: the library's own rule (yak_api.cpp auto_sweeps: at most 2.8 GB of input per sweep) --
+        while a.sweeps < 16 and a.contigs * a.contig_len / a.sweeps > 2.8e9:
+            a.sweeps *= 2                                      # the default 50 x 100 Mb = BASELINE configs[3] runs in 2
     if a.sweeps > 1:
         return run_cfg4_sweeps(a, yak_amd)
     K = 21

@@ -87,13 +87,16 @@ def test_cfg4_1gb_in_sweeps_over_prefix_ranges():
 
 
 def test_cfg4_5gb_assembly_in_sweeps():
-    """BASELINE configs[3] at its full size (50 contigs x 100 Mb, k = 21, 5 G distinct k-mers: a 40 GB .yak): yak_count() in 8 sweeps over prefix
-    ranges on the one device, and in the 4 the library picks by itself for a file of that size.  No reference golden exists at this size (the
-    reference needs more host memory than the build container has; 2 Gb is checked against it, above):
-    the size-independent properties -- every count adds up to the instances consumed, the histogram adds up to tot, two chunkings of the
-    stream give the same counts -- and the distinct count both earlier rounds' runs agreed on"""
-    for sweeps in ("4", "8"):
-        d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", sweeps)
+    """BASELINE configs[3] at its full size (50 contigs x 100 Mb, k = 21, 5 G distinct k-mers: a 40 GB .yak): yak_count() in the 2 sweeps over
+    prefix ranges the library picks by itself for a file of that size, and in 4.  The reference needs ~80 GB of host memory at this size; the
+    golden md5 comes from the ORACLE run in 8 prefix ranges (`yko count -R lo:hi`, tests/gen_golden_full.py --cfg4-ranges 50), a procedure that
+    reproduces the reference's own md5 at 2 Gb (tests/golden/cfg45_full.json: cfg4_20x100000000.oracle_prefix_ranges_reproduce_it).  The
+    2-sweep run is compared byte for byte (md5 of the 40 GB dump); both runs keep the size-independent properties"""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg45_full.json"))).get("cfg4_50x100000000")
+    for sweeps in ("2", "4"):
+        d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", sweeps, *(() if sweeps == "2" else ("--no-verify",)))
         v = d["verify"]
         assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]
         assert v["distinct"] == 4994315360 and v["yak_size_bytes"] == 16 + 8 * 1024 + 8 * 4994315360
+        if sweeps == "2" and gold:
+            assert v["equals_golden"] is True and v["yak_md5"] == gold["md5"] and gold["size"] == v["yak_size_bytes"]

@@ -140,3 +140,30 @@ def test_block_gzip_is_parsed_in_parallel(no_libdeflate, oracle, tmp_path, monke
     bad = str(tmp_path / "bad.fq.gz"); open(bad, "wb").write(bytes(raw))
     got = yak_amd.host_image(bad, 31, fast=True)
     assert want.startswith(got[:got.rfind(b"\n", 0, len(got) - 1) + 1][:1000]) and len(got) < len(want)
+
+
+def test_long_fasta_records_are_stripped_by_several_threads(oracle, tmp_path):
+    """a record whose body passes 1 MB (a chromosome) is stripped of its line ends by the parser threads straight from the mapped file
+    (FxReader::bulk_body): wrapped at 60 / 61 / ragged widths, CRLF, blank lines, a '+' or '@' line that ends the body the way kseq.h:209
+    says, short records around it, no final newline -- every shape against the oracle's reader"""
+    rnd = random.Random(5)
+
+    def body(n, width, eol="\n", ragged=False):
+        out, i = [], 0
+        while i < n:
+            w = rnd.randint(1, width) if ragged else width
+            out.append("".join(rnd.choice("ACGT") for _ in range(min(w, n - i))) + eol)
+            i += w
+        return "".join(out)
+    cases = {
+        "wrap60.fa": ">a desc\n" + body(2_500_000, 60) + ">b\nACGTACGTAC\n>c\n" + body(1_300_000, 61) + ">d\nACGT\n",
+        "crlf.fa": ">a\r\n" + body(1_400_000, 70, "\r\n") + ">b\r\n" + body(50, 70, "\r\n"),
+        "ragged_blank.fa": ">a\n" + body(700_000, 90, ragged=True) + "\n\n" + body(900_000, 90, ragged=True) + ">b\n" + body(2_000_000, 80, ragged=True).rstrip("\n"),
+        "plus_in_fasta.fa": ">a\n" + body(1_500_000, 60) + "+\n" + "I" * 100 + "\n>b\n" + body(1_200_000, 60) + "@c\n" + body(100, 60),
+        "one_line.fa": ">a\n" + body(3_000_000, 3_000_000) + ">b\n" + body(10, 10),
+    }
+    for name, text in cases.items():
+        fn = str(tmp_path / name)
+        open(fn, "w", newline="").write(text)
+        for k in (0, 31):
+            same(fn, oracle, k)

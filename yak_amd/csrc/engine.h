@@ -34,6 +34,7 @@ int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
 u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);
 int  yk_ctx_device(yakamd_ctx *c);
 size_t yk_pool_cached_bytes(void);
+void yk_pool_report(const char *what);
 hipStream_t yk_ctx_stream(yakamd_ctx *c);
 void yk_ctx_set_source(yakamd_ctx *c, const uint64_t id[4], int64_t n_seq);
 bool yk_ctx_same_source(yakamd_ctx *c, const uint64_t id[4], int64_t *n_seq);

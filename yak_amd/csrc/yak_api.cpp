@@ -634,8 +634,16 @@ struct ByteSource {
 	struct Blk { int64_t foff, uoff; uint32_t csize, usize; };   /* offset of the deflate payload, offset in the uncompressed stream, bytes of both */
 	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
 	uint64_t gen;                                                 /* identity of this source for the per-thread block cache (an address can be reused by the next job's source) */
+	const unsigned char *map; size_t map_len;                     /* a plain file, mapped: the body of a long FASTA record is stripped of its line ends by several threads straight from here */
 	static uint64_t next_gen() { static uint64_t g = 0; return __atomic_add_fetch(&g, 1, __ATOMIC_RELAXED); }
-	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()) {}
+	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0) {}
+	~ByteSource() { if (map) munmap((void*)map, map_len); }
+	ByteSource(const ByteSource&) = delete; ByteSource &operator=(const ByteSource&) = delete;
+	void map_plain() {
+		if (bgzf || fd < 0 || size <= 0 || map || getenv("YAKAMD_NO_MMAP")) return;
+		void *m = mmap(0, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m != MAP_FAILED) { map = (const unsigned char*)m; map_len = (size_t)size; (void)madvise(m, map_len, MADV_SEQUENTIAL); }
+	}
 	typedef void *(*ld_alloc_t)(void); typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*); typedef void (*ld_free_t)(void*);
 	static void ld_api(ld_alloc_t *al, ld_dec_t *de, ld_free_t *fr = 0) {
 		static ld_alloc_t a = 0; static ld_dec_t d = 0; static ld_free_t f = 0; static bool tried = false;
@@ -825,6 +833,125 @@ struct FxReader {
 		beg = nbeg; last = nlast;
 		return slen;
 	}
+	/* The body of a long FASTA record (a chromosome: 1.7 M lines), from a mapped plain file: `n_thr` threads each take a range of the bytes from
+	 * `from` on, walk the lines that START in their range -- a line that begins with '>', '@' or '+' ends the body (kseq.h:209) -- and count the
+	 * bytes the lines contribute (kseq.h:145: a '\r' before the line end is dropped; the sequence is longer than one byte here); then every thread
+	 * copies its lines to their place in `out`.  Returns the offset where the body scan stopped (a line start: the marker line, or the end of
+	 * the span / file); out grows by the body's bytes.  `from` must be a line start */
+	template <class V> int64_t bulk_body(V &out, int64_t from, int n_thr) {
+		const unsigned char *m = psrc->map;
+		const int64_t fend = (int64_t)psrc->map_len, span_end = std::min<int64_t>(fend, from + ((int64_t)1 << 30));
+		if (n_thr > 64) n_thr = 64;
+		const int64_t step = (span_end - from + n_thr - 1) / n_thr;
+		struct Part { int64_t a, stop, bytes; bool hit; };
+		std::vector<Part> part(n_thr);
+		auto walk = [&](int t, char *dst) {                             /* dst == 0: count; else copy */
+			Part &P = part[t];
+			int64_t p = P.a;
+			const int64_t lim = dst ? P.stop : std::min<int64_t>(span_end, from + (int64_t)(t + 1) * step);
+			int64_t nb = 0;
+			bool hit = false;
+			while (p < lim) {                                          /* p is a line start */
+				const unsigned char c = m[p];
+				if (c == '>' || c == '@' || c == '+') { hit = true; break; }
+				const unsigned char *q = (const unsigned char*)memchr(m + p, '\n', (size_t)(fend - p));
+				const int64_t e = q ? (int64_t)(q - m) : fend;
+				int64_t len = e - p;
+				if (len > 0 && m[e - 1] == '\r') --len;
+				if (dst) memcpy(dst + nb, m + p, (size_t)len);
+				nb += len;
+				p = q ? e + 1 : fend;
+			}
+			if (!dst) { P.stop = p; P.bytes = nb; P.hit = hit; }
+		};
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_thr; ++t) {
+			int64_t a = from + (int64_t)t * step;
+			if (t > 0 && a < span_end) {                                /* first line start at or behind the cut */
+				const unsigned char *q = (const unsigned char*)memchr(m + a - 1, '\n', (size_t)(fend - (a - 1)));
+				a = q ? (int64_t)(q - m) + 1 : fend;
+			}
+			part[t].a = std::min(a, span_end); part[t].stop = part[t].a; part[t].bytes = 0; part[t].hit = false;
+		}
+		for (int t = 1; t < n_thr; ++t) th.emplace_back(walk, t, (char*)0);
+		walk(0, 0);
+		for (auto &x : th) x.join();
+		th.clear();
+		/* a part whose first line lies beyond its range walked nothing; the body ends at the first marker.  Parts tile the span: part t stops
+		 * where part t + 1 starts, unless a marker stopped it */
+		int n_use = 0;
+		int64_t total = 0, stop = part[0].a;
+		std::vector<int64_t> off(n_thr, 0);
+		for (int t = 0; t < n_thr; ++t) {
+			if (part[t].a != stop) break;                               /* (a long line swallowed this part's range) */
+			off[t] = total; total += part[t].bytes; stop = part[t].stop; ++n_use;
+			if (part[t].hit) break;
+		}
+		const size_t at = out.size();
+		out.resize(at + (size_t)total);
+		char *base = &out[0] + at;
+		for (int t = 1; t < n_use; ++t) th.emplace_back(walk, t, base + off[t]);
+		if (n_use > 0) walk(0, base + off[0]);
+		for (auto &x : th) x.join();
+		return stop;
+	}
+	/* next(), with the sequence appended to `out` (+ '\n') when it has >= min_len bytes, and long FASTA bodies of a mapped file stripped by
+	 * bulk_threads threads.  Same return values and reader state as next() */
+	template <class V> int64_t next_to(V &out, int64_t min_len, int bulk_threads) {
+		if (!(psrc && psrc->map && bulk_threads > 1)) {
+			const int64_t l = next();
+			if (l >= min_len) { out.insert(out.end(), seq.begin(), seq.end()); out.push_back('\n'); }
+			return l;
+		}
+		int c, d;
+		if (last == 0) {
+			while ((c = getc()) != -1 && c != '>' && c != '@') {}
+			if (c == -1) return -1;
+			last = c;
+		}
+		seq.clear(); name.clear(); qlen = 0; qlast = 0;
+		if (until(false, 3, &d) < 0) return -1;
+		if (d != '\n') until(true, 0, 0);
+		const size_t at0 = out.size();
+		int64_t bulked = 0;
+		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n') continue;
+			seq.push_back((char)c);
+			until(true, 1, 0);
+			if (seq.size() >= ((size_t)1 << 20)) {                       /* a long body: what is read so far goes out, the rest in parallel from the map */
+				out.insert(out.end(), seq.begin(), seq.end());
+				bulked += (int64_t)seq.size();
+				seq.clear();
+				int64_t p = pos0 + beg;                                 /* the reader stands at a line start (or at the end of the file) */
+				for (;;) {
+					const size_t before = out.size();
+					const int64_t q = bulk_body(out, p, bulk_threads);
+					bulked += (int64_t)(out.size() - before);
+					const bool more = q > p && q < (int64_t)psrc->map_len && psrc->map[q] != '>' && psrc->map[q] != '@' && psrc->map[q] != '+';   /* the span ended before the body did */
+					p = q;
+					if (!more) break;
+				}
+				beg = end = 0; eof = 0; poff = p;                       /* the buffered reader goes on from there */
+				seq.push_back('x'); seq.push_back('x');                 /* (kseq.h:145 looks at the sequence's length: "more than one byte" stays true) */
+			}
+		}
+		const int64_t slen = bulked ? bulked + (int64_t)seq.size() - 2 : (int64_t)seq.size();
+		if (bulked) { out.insert(out.end(), seq.begin() + 2, seq.end()); }
+		else if ((int64_t)seq.size() >= min_len) out.insert(out.end(), seq.begin(), seq.end());
+		if (c == '>' || c == '@') last = c;
+		int64_t ret = slen;
+		if (c == '+') {
+			while ((c = getc()) != -1 && c != '\n') {}
+			if (c == -1) ret = -2;
+			else {
+				while (until(true, 2, 0) >= 0 && (int64_t)qlen < slen) {}
+				last = 0;
+				if ((int64_t)qlen != slen) ret = -2;
+			}
+		}
+		if (ret >= min_len) out.push_back('\n'); else out.resize(at0);
+		return ret;
+	}
 	int64_t next() {
 		int c, d;
 		if (last == 0) {
@@ -888,6 +1015,8 @@ template <class T> struct PinAlloc {
 		return (T*)p;
 	}
 	void deallocate(T *p, size_t) { if (hipHostFree((void*)p) != hipSuccess) { (void)hipGetLastError(); free((void*)p); } }
+	template <class U> void construct(U*) {}                        /* resize() leaves new bytes alone: they are written right away (no zero fill of a 100 MB sequence) */
+	template <class U, class A0> void construct(U *p, const A0 &a) { ::new ((void*)p) U(a); }
 	template <class U> bool operator==(const PinAlloc<U>&) const { return true; }
 	template <class U> bool operator!=(const PinAlloc<U>&) const { return false; }
 };
@@ -917,7 +1046,7 @@ static int64_t guess_record_start(const ByteSource *src, int64_t from, int64_t l
 	return -1;
 }
 
-static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, int min_len)
+static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, int min_len, int bulk_threads)
 {
 	FxReader r;
 	r.open_at(src, sg->start);
@@ -929,8 +1058,7 @@ static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, i
 		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = true; break; }
 		if (r.marker_pos() >= sg->end) { sg->stop = r.marker_pos(); break; }
 		if ((l = r.fast(sg->img, min_len)) == FxReader::NOT_FAST) {
-			if ((l = r.next()) < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
-			if (l >= min_len) { sg->img.insert(sg->img.end(), r.seq.begin(), r.seq.end()); sg->img.push_back('\n'); }
+			if ((l = r.next_to(sg->img, min_len, bulk_threads)) < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
 		}
 		if (l >= min_len) { ++sg->n_seq; sg->sum_len += l; }
 	}
@@ -953,8 +1081,10 @@ static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t
 	}
 	for (int i = 0; i < n_seg; ++i) seg[i].end = i + 1 < n_seg ? seg[i + 1].start : wend;
 	std::vector<std::thread> th;
-	for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len);
-	parse_segment(fd, size, &seg[0], min_len);
+	/* few segments (long records: a cut finds no record start nearby): their threads' share of the parser threads strips the long bodies */
+	const int bulk_threads = std::max(1, std::min(n_thr, (int)std::thread::hardware_concurrency()) / std::max(1, n_seg));
+	for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len, bulk_threads);
+	parse_segment(fd, size, &seg[0], min_len, bulk_threads);
 	for (auto &t : th) t.join();
 	int64_t at = pos;
 	int n_ok = 0;
@@ -978,6 +1108,7 @@ static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64
 	if (fx.fd >= 0) {
 		if (fstat(fx.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= min_size) return false;
 		src->fd = fx.fd; src->size = sb.st_size; src->bgzf = false;
+		src->map_plain();
 		return true;
 	}
 	if (fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_BGZF")) return false;
@@ -1070,9 +1201,10 @@ struct MultiJob {
 };
 
 /* no filter + a plain file of more than YAKAMD_AUTO_SWEEP_GB (2.5) GB: nearly every k-mer instance may be a key of its own (an assembly),
- * and one pass holds ~100 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
- * prefix ranges (N so that a sweep sees at most ~1.4 G positions of its own: 5 Gb in 4 sweeps, measured 3.8 s against 4.1 s in 8 and 9.7 s in 2,
- * where two ranks' tables and one rank's layout buffers no longer fit together).  YAKAMD_GPUS set to anything switches the rule off */
+ * and one pass holds ~70 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
+ * prefix ranges (N so that a sweep sees at most ~2.8 G positions of its own: 5 Gb in 2 sweeps, 2.4 s on a device whose memory has been in use
+ * before, 2.4 s in 4; round 3 needed 4 -- a rank of 2 held a third copy of its table and 4 bytes of pending counts per slot while its layout
+ * was replayed).  YAKAMD_GPUS set to anything switches the rule off */
 static int auto_sweeps(const yak_copt_t *opt, const char *fn)
 {
 	if (fn == 0 || strcmp(fn, "-") == 0 || opt->bf_shift > opt->pre) return 1;
@@ -1088,7 +1220,7 @@ static int auto_sweeps(const yak_copt_t *opt, const char *fn)
 	::close(f);
 	if (gz) return 1;                                           /* compressed: the size says little; the knob is there */
 	int N = 2;
-	while (N < 16 && (double)sb.st_size / N > 1.4e9) N <<= 1;
+	while (N < 16 && (double)sb.st_size / N > 2.8e9) N <<= 1;
 	return (1 << opt->pre) % N ? 1 : N;
 }
 
@@ -1296,6 +1428,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	int64_t n_seq_tot = 0;
 	int g = 0;                                                 /* the slot whose chunk is being filled */
 	auto wait_worker = [&]() { if (worker.joinable()) worker.join(); if (!worker_ok) ok = false; };
+	double t_sink = 0, t_round_wait = 0;                        /* YAKAMD_VERBOSE: where the reader's time goes */
 	/* host -> device through two pinned staging buffers: while one is on its way over the bus the reader copies the next piece into the other (a
 	 * copy from pageable memory is staged by the runtime anyway, but behind a synchronise per piece) */
 	const size_t STG = (size_t)std::max<int64_t>(1 << 20, getenv("YAKAMD_MGPU_STAGE") ? atoll(getenv("YAKAMD_MGPU_STAGE")) : (int64_t)32 << 20);
@@ -1317,8 +1450,10 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	};
 	auto copies_done = [&]() { for (int s = 0; s < S && ok; ++s) { hipSetDevice(J.sdev[s]); ok = hipStreamSynchronize(J.cp[s]) == hipSuccess; } };
 	auto round = [&]() {
+		const double tw0 = yk_realtime();
 		copies_done();                                          /* the chunks of this set are on their devices */
 		wait_worker();                                          /* at most one round in flight: its set becomes the one to fill next */
+		t_round_wait += yk_realtime() - tw0;
 		if (ok) {
 			const int x = cur;
 			worker = std::thread([&, x]() { std::string why; worker_ok = multi_round(&J, x, e, opt->k, opt->pre, create_new, fill[x], t0[x], &why); if (!worker_ok) worker_why = why; });
@@ -1328,7 +1463,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	};
 	/* a piece (whole sequences, each followed by '\n') goes to the chunk being filled; a chunk is closed between two
 	 * sequences, or inside one that is longer than a whole chunk */
-	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool {
+	auto take_piece_body = [&](const char *img, size_t n, int64_t ns) -> bool {
 		n_seq_tot += ns;
 		while (n > 0 && ok) {
 			const size_t room = (size_t)(J.chunk - fill[cur][g]);
@@ -1352,6 +1487,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		}
 		return ok;
 	};
+	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
 	const bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
@@ -1371,6 +1507,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	}
 	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
 	wait_worker();
+	const double t_fed = yk_realtime();
 	for (int i = 0; i < 2; ++i) { if (stg_busy[i]) (void)hipEventSynchronize(stg_ev[i]); if (stg_ev[i]) (void)hipEventDestroy(stg_ev[i]); if (stg[i]) (void)hipHostFree(stg[i]); }
 	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
 	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
@@ -1385,6 +1522,11 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		for (int r = 0; r < N; ++r) { if (n_ins[r] < 0) ok = false; else e->sub[r]->tot += (uint64_t)n_ins[r]; }
 	}
 	multi_tot(h);
+	if (getenv("YAKAMD_VERBOSE") && atoi(getenv("YAKAMD_VERBOSE")) > 0) {
+		fprintf(stderr, "[yak_amd] %d ranks: input read, dealt and fed by %.3f s (%d parser threads; %.3f s inside the sink that copies the pieces to the devices, %.3f s of it waiting for copies and the round before), the ranks' passes finished by %.3f s\n",
+		        N, t_fed, n_thr, t_sink, t_round_wait, yk_realtime());
+		for (int s = 0; s < S; ++s) { hipSetDevice(J.sdev[s]); yk_pool_report("the job"); }
+	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? "RCCL exchange" : "peer copies");
 	if (psrc_fd >= 0) ::close(psrc_fd);
