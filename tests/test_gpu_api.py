@@ -501,3 +501,27 @@ def test_packed_image_feed_equals_ascii_feed(k, bf, ya, oracle, synth):
     tp.close(); ta.close(); O.yko_ch_destroy(o)
     for d in (d_a, d_c, d_v):
         L.yakamd_dev_free(d)
+
+
+@pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BF_DEFER="0")], ids=["filter_rebuilt_from_retained_records", "filter_written_by_the_pass"])
+def test_filter_survives_a_pass_that_kept_it_in_lds(env, ya, oracle, synth, monkeypatch):
+    """a filtered pass that retains its records does not write its 2^bf_shift filter bits back (yak_ch_destroy_bf usually follows, main.c:55); a later
+    create_new call on the same table -- yak_ch_insert_list here (htab.c:51-78 consults the filter, htab.c:63-65) -- must still meet exactly the bits
+    every instance of the pass set (bbf.c:34-40): the filter is rebuilt from the retained records before they are dropped"""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    L, O = ya.lib(), oracle.lib()
+    img = synth(6000, g=30000, s=77)
+    t = ya.Table(31, 10, 4, 22)
+    assert L.yakamd_retain_input(t.h, 1) == 0
+    d = L.yakamd_dev_alloc(len(img) + 64)
+    assert L.yakamd_memcpy_h2d(d, img, len(img)) == 0
+    t.count_pass(1, [(d, len(img), 0)])
+    assert L.yakamd_retained_instances(t.h) > 0
+    o = O.yko_count_mem(img, len(img), C.byref(oracle.copt(31, 10, 4, 22, 10000000)), None)
+    lists = _lists(oracle, 9, 30, 400)
+    for i, a in enumerate(lists):
+        arr = (C.c_uint64 * len(a))(*a)
+        assert L.yak_ch_insert_list(t.h, 1, len(a), arr) == O.yko_ch_insert_list(o, 1, len(a), arr), i
+    assert t.dump_bytes() == oracle.dump_bytes(o)
+    t.close(); O.yko_ch_destroy(o); L.yakamd_dev_free(d)

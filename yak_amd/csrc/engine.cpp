@@ -249,6 +249,7 @@ struct yakamd_ctx {
 	/* bloom */
 	u32 *d_bf; size_t bf_words;
 	bool bf_virgin;                    /* allocated but never written: logically all zero */
+	bool bf_deferred;                  /* the last pass left its bits in LDS only (FastParams.bf_nowb): the filter is whatever k_bf_rebuild makes of the retained records (ret2) */
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
@@ -356,7 +357,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	c->k = k; c->pre = pre; c->P = 1 << pre; c->plo = 0; c->phi = c->P;
 	c->n_hash = 0; c->bf_shift = 0; c->nb = 0; c->has_bloom = false;
 	c->d_bits = 0; c->d_used = 0; c->d_delta = 0; c->d_off = 0; c->d_keys = 0; c->n_slots = 0;
-	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false;
+	c->d_bf = 0; c->bf_words = 0; c->d_multi = 0; c->multi_bits = 0; c->bf_virgin = false; c->bf_deferred = false;
 	c->in_pass = false; c->gate_off = false; c->or_mode = 0; c->acc.s = 0; c->acc_count = 0;
 	c->d_counters = 0; c->d_lastput = 0; c->d_lpbatch = 0; c->d_missing = 0; c->d_nmissing = 0;
 	c->d_rec = 0; c->rec_cap = 0; c->d_newlist = 0; c->d_miss = 0; c->d_cand = 0; c->new_cap = 0;
@@ -397,8 +398,21 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 	return c;
 }
 
+/* a filter whose write-back was skipped becomes real before the records it can be rebuilt from go away */
+static void bloom_undefer(yakamd_ctx *c)
+{
+	if (!c->bf_deferred) return;
+	c->bf_deferred = false;
+	if (!c->d_bf || !c->ret2.valid) return;
+	(void)hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st);
+	yk_launch_bf_rebuild(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->d_bf, c->st);
+	(void)hipStreamSynchronize(c->st);
+	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] the filter of the last pass rebuilt from its retained records (its write-back had been skipped)\n");
+}
+
 static void retained_drop(yakamd_ctx *c)
 {
+	bloom_undefer(c);
 	for (auto &r : c->retained) dfree(r.d_rec);
 	c->retained.clear(); c->retained_bytes = 0; c->src_set = false;
 	dfree(c->ret2.d_r2); dfree(c->ret2.d_sbstart); dfree(c->ret2.d_koff); dfree(c->ret2.d_kkc); dfree(c->ret2.d_segbase);
@@ -420,6 +434,7 @@ void yk_ctx_destroy(yakamd_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->dev);
 	pass_free(c);
+	c->bf_deferred = false;                                    /* nobody will read it */
 	retained_drop(c);
 	dfree(c->d_stage); dfree(c->d_rows); dfree(c->d_partial); dfree(c->d_bstart);
 	{ uint8_t *q = (uint8_t*)c->d_scratch; dfree(q); c->d_scratch = 0; }
@@ -437,7 +452,7 @@ int yk_ctx_destroy_bf(yakamd_ctx *c)
 {
 	hipSetDevice(c->dev);
 	dfree(c->d_bf); dfree(c->d_multi);
-	c->has_bloom = false;
+	c->has_bloom = false; c->bf_deferred = false;
 	return 0;
 }
 
@@ -1621,6 +1636,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.img_nonempty = c->img_keys_total > 0; fp.plo = c->plo; fp.phi = c->phi; fp.t_pass0 = c->t_pass0;
 	fp.dbg = (int)env_i64("YAKAMD_DBG", 0);
 	fp.or_mode = c->or_mode;
+	fp.bf_nowb = 0;
 	/* YAKAMD_VERBOSE > 1: wall-clock laps of the stages (each behind a stream synchronise: allocation stalls show up where they happen) */
 	const bool laps = env_i64("YAKAMD_VERBOSE", 0) > 1;
 	double lap_t = now_ms();
@@ -1795,6 +1811,9 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
 	u64 h_cnt[YKC_N];
 	const bool lc2 = yk_lc2_ok(fp) != 0;
+	/* every record of the pass stays on the device (keep2) and the filter has never been written: k_lc2 keeps the bits in LDS and the 2^bf_shift
+	 * bits are not written at all -- yak_ch_destroy_bf usually comes next (main.c:55); whatever reads the filter first rebuilds it (bloom_undefer) */
+	fp.bf_nowb = lc2 && keep2 && fp.bf_virgin && env_i64("YAKAMD_BF_DEFER", 1) != 0;
 	{
 		EvTimer tm(c->st);
 		if (lc2) yk_launch_lc2(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, d_ovf2, c->st);
@@ -1844,7 +1863,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		dfree(d_scroff); d_scroff = 0;
 	}
 	lap("insert (k_lc2 + tiers)");
-	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; }
+	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; c->ret2.fp.bf_nowb = 0; }
 	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
 	/* gather the fragments: keys per sub-table, then one contiguous list each */
 	std::vector<u32> m(P, 0);
@@ -1896,7 +1915,16 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	}
 	if (keep2) {
 		/* the gathered list is grouped by sub-bucket (k_lc_compact walks them in order): a copy of it + the first key of every sub-bucket */
-		if ((!d_koff && dmalloc(&c->ret2.d_koff, n_sb + 1)) || dmalloc(&c->ret2.d_kkc, n_sel) || dmalloc(&c->ret2.d_segbase, P + 1)) { retained_drop(c); c->retain_broken = true; keep2 = false; }
+		if ((!d_koff && dmalloc(&c->ret2.d_koff, n_sb + 1)) || dmalloc(&c->ret2.d_kkc, n_sel) || dmalloc(&c->ret2.d_segbase, P + 1)) {
+			if (fp.bf_nowb) {                                         /* the records go after all: the filter they stood for is written now */
+				FastParams fr = fp;
+				fr.bf_nowb = 0;
+				HIPCK(hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st));
+				yk_launch_bf_rebuild(fr, d_sbstart, c->ret2.d_r2, c->d_bf, c->st);
+				HIPCK(hipStreamSynchronize(c->st));
+			}
+			retained_drop(c); c->retain_broken = true; keep2 = false;
+		}
 		else {
 			if (d_koff) { c->ret2.d_koff = d_koff; d_koff = 0; }        /* the flat gather has them already */
 			else yk_launch_nsel_scan(lo.nsel, s2, c->plo, c->phi, P, d_segbase, c->ret2.d_koff, c->st);
@@ -1906,6 +1934,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 			HIPCK(hipMemcpyAsync(c->ret2.d_segbase, d_segbase, (P + 1) * 8, hipMemcpyDeviceToDevice, c->st));
 			c->ret2.n_keys = n_sel;
 			c->ret2.valid = true;
+			c->bf_deferred = fp.bf_nowb != 0;
 		}
 	}
 	dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd); dfree(d_sbstart); dfree(d_ndist); dfree(d_koff);

@@ -170,6 +170,7 @@ struct FastParams {
 	 * One sweep does them all (ssh = sw - s2_tot, s2_bits = s2_tot: the counting kernels always see this form); beyond 2^13 sub-buckets per sub-table a
 	 * first sweep takes the high s2_tot - 11 bits (ssh = sw - s2_bits) and a second one, on the groups of the first, the low 11 (ssh = sw - s2_tot) */
 	int sw, ssh, s2_tot;
+	int bf_nowb;                    /* k_lc2: the staged filter ranges are not written back (the caller keeps every record of the pass and rebuilds the filter from them if anything ever reads it: k_bf_rebuild) */
 	u64 t_pass0;
 };
 
@@ -221,6 +222,7 @@ void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int
 void yk_launch_part2_ts(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first, const u64 *bbase, FastParams fp, int P, u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
 int yk_launch_ts_rank(const u64 *binstart, const Rec *in, int w, int j, u32 bin_lo, u32 n_bins, u64 *out_kc, u64 *out_t, u32 *fail, hipStream_t st);
 void yk_launch_kt_split(const Rec *in, u64 n, u64 *out_kc, u64 *out_t, hipStream_t st);
+void yk_launch_bf_rebuild(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, hipStream_t st);
 void yk_launch_lc_sum3(LcOut O, int s2_bits, int plo, int phi, u64 t_pass0, u32 *seg_cnt, u64 *lastput, u32 *ndist_p, hipStream_t st);
 void yk_launch_lc_gather(LcOut O, const u64 *sbstart, const u64 *key_off, int s2_bits, int plo, int phi, u64 *out_kc, u64 *out_T, Rec *out_kt, hipStream_t st);
 void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, u64 n_keys, hipStream_t st);
