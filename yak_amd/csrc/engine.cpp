@@ -253,6 +253,7 @@ struct yakamd_ctx {
 	u32 *d_multi; int multi_bits;
 
 	/* running pass */
+	bool delta_dirty;                  /* the running pass left pending counts in d_delta (k_img_fold at its end) */
 	bool in_pass; int create_new; bool bloom_mode; bool gate_off; int or_mode;   /* gate_off: puts of a merge never consult the filter */
 	AccTab acc; u64 acc_count;
 	u64 *d_counters, *d_lastput, *d_lpbatch;
@@ -504,6 +505,7 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 	HIPCK(hipSetDevice(c->dev));
 	(void)hipGetLastError();                                   /* whatever other users of the runtime left behind is not this pass's (see yakamd_pass_end) */
 	c->create_new = create_new;
+	c->delta_dirty = false;
 	if (!create_new && delta_ensure(c)) return -1;
 	if (create_new) { retained_drop(c); c->retain_broken = false; }
 	c->n_slices = 0;
@@ -751,6 +753,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 	c->st_cur.n_instances += n_rec;
 	if (batch_hi > c->t_end) c->t_end = batch_hi;
 	if (!c->create_new) {
+		c->delta_dirty = true;
 		EvTimer tm(c->st);
 		/* records grouped by sub-table and every sub-table small enough for LDS rank counters:
 		 * exclusive-ownership counting, no global atomics */
@@ -788,7 +791,7 @@ static int consume_records(yakamd_ctx *c, int64_t n_rec, u64 t0, u64 batch_lo, u
 		return 0;
 	}
 	const int img_nonempty = c->img_keys_total > 0;
-	if (img_nonempty && delta_ensure(c)) return -1;
+	if (img_nonempty) { if (delta_ensure(c)) return -1; c->delta_dirty = true; }
 	if (c->bloom_mode && bloom_materialise(c)) return -1;
 	if (acc_reserve(c, (u64)n_rec) || new_reserve(c, n_rec)) return -1;
 	u64 h_cnt[YKC_N];
@@ -1101,6 +1104,7 @@ extern "C" int yakamd_count_hashes_dev(yak_ch_t *h, const void *d_hash_u64, int6
 	if (!c || !c->in_pass || c->create_new) return fail("count_hashes needs an open create_new = 0 pass");
 	HIPCK(hipSetDevice(c->dev));
 	if (n <= 0) return 0;
+	c->delta_dirty = true;
 	EvTimer tm(c->st);
 	yk_launch_img_count_h((const u64*)d_hash_u64, n, img_view(c), c->st);
 	const double ms = tm.stop();
@@ -1140,9 +1144,13 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 	if (c->ret2.valid && !c->retain_broken && env_i64("YAKAMD_RETAIN", 1) != 0) {
 		u32 *d_kcnt = 0;
 		if (dmalloc(&d_kcnt, c->ret2.n_keys)) return -1;
+		HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));          /* (a spare word of the context: "some instance went through the pending counts") */
 		EvTimer tm(c->st);
-		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, c->ret2.d_segbase, d_kcnt, img_view(c), c->ret2.n_keys, c->st);
+		yk_launch_cnt2(c->ret2.fp, c->ret2.d_sbstart, c->ret2.d_r2, c->ret2.d_koff, c->ret2.d_kkc, c->ret2.d_segbase, d_kcnt, img_view(c), c->ret2.n_keys, c->d_nmissing, c->st);
+		u32 used = 1;
+		(void)hipMemcpyAsync(&used, c->d_nmissing, 4, hipMemcpyDeviceToHost, c->st);
 		const double ms = tm.stop();
+		if (used) c->delta_dirty = true;
 		dfree(d_kcnt);
 		const bool bad = hipGetLastError() != hipSuccess;
 		c->st_cur.n_instances += (int64_t)c->ret2.n_total;
@@ -2030,7 +2038,7 @@ static int64_t pass_end_body(yakamd_ctx *c)
 	int64_t n_ins = 0;
 	if (c->k >= 32 && yk_bad_hash_seen(c->st)) { pass_free(c); return fail("a 64-bit k-mer hash equals the empty-slot pattern: unsupported input for k >= 32"); }
 	if (!c->create_new) {
-		if (c->d_delta) yk_launch_img_fold(img_view(c), c->n_slots, c->st);
+		if (c->d_delta && c->delta_dirty) yk_launch_img_fold(img_view(c), c->n_slots, c->st);   /* (k_cnt2_apply writes its counts straight into the keys) */
 		HIPCK(hipStreamSynchronize(c->st));
 		dfree(c->d_delta);
 		c->host_valid = false;

@@ -225,7 +225,7 @@ void yk_launch_kt_split(const Rec *in, u64 n, u64 *out_kc, u64 *out_t, hipStream
 void yk_launch_bf_rebuild(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, hipStream_t st);
 void yk_launch_lc_sum3(LcOut O, int s2_bits, int plo, int phi, u64 t_pass0, u32 *seg_cnt, u64 *lastput, u32 *ndist_p, hipStream_t st);
 void yk_launch_lc_gather(LcOut O, const u64 *sbstart, const u64 *key_off, int s2_bits, int plo, int phi, u64 *out_kc, u64 *out_T, Rec *out_kt, hipStream_t st);
-void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, u64 n_keys, hipStream_t st);
+void yk_launch_cnt2(FastParams fp, const u64 *sbstart, const Rec *rec, const u64 *key_off, const u64 *key_kc, const u64 *seg_base, u32 *key_cnt, ImgView img, u64 n_keys, u32 *used_delta, hipStream_t st);
 void yk_launch_nsel_scan(const u32 *nsel, int s2_bits, int plo, int phi, int P, const u64 *seg_base, u64 *key_off, hipStream_t st);
 void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, const u64 *src_kc, const u64 *src_t,
                               u64 *dst_kc, u64 *dst_t, int shift, hipStream_t st, int big);
