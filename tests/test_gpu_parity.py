@@ -307,7 +307,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
 @pytest.mark.parametrize("env", [dict(YAKAMD_FAST="0"), dict(YAKAMD_S2_BITS="0"), dict(YAKAMD_FAST_BUDGET="100000"),
                                  dict(YAKAMD_S2_BITS="3", YAKAMD_BATCH="32768"), dict(YAKAMD_PART_BITS="6"),
                                  dict(YAKAMD_S2_BITS="6"), dict(YAKAMD_S2_BITS="11", YAKAMD_CH2="4096"), dict(YAKAMD_S2_BITS="13"),
-                                 dict(YAKAMD_XP_WC="0", YAKAMD_P2_WC="0", YAKAMD_S2_BITS="6"),
+                                 dict(YAKAMD_P2_WC="0", YAKAMD_S2_BITS="6"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="5", YAKAMD_XLIST_CAP="0"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="6", YAKAMD_XLIST_CAP="7"),
@@ -417,7 +417,7 @@ def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
                       ("YAKAMD_REPLAY_LDS", [None, None, "0", "1024", "4096", "32768"]), ("YAKAMD_COUNT_LDS", [None, None, "0"]),
                       ("YAKAMD_COUNT_OWN", [None, None, "0"]), ("YAKAMD_OWN_LDS", [None, None, "18500", "24000"]), ("YAKAMD_OWN_MAXRB", [None, "12"]), ("YAKAMD_LC2", [None, None, None, "0"]),
                       ("YAKAMD_R2_SMALL_BITS", [None, "5", "6", "8"]), ("YAKAMD_R2_SEG_LOG", [None, "10", "11", "12"]), ("YAKAMD_REPLAY2", [None, None, None, "0"]), ("YAKAMD_REC8", [None, None, "0"]), ("YAKAMD_REC8_OUT", [None, None, "0"]),
-                      ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_XP_WC", [None, None, "0", "1", "2"]), ("YAKAMD_FAST", [None, None, None, "0"])):
+                      ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_FAST", [None, None, None, "0"])):
         v = rnd.choice(vals)
         if v is not None:
             monkeypatch.setenv(key, v)

@@ -180,12 +180,10 @@ static void *pool_alloc(size_t bytes)
 static void pool_free(void *p)
 {
 	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
-	/* idle bytes kept per device: three quarters of the HBM unless YAKAMD_POOL_MAX_GB says otherwise.  A step of the larger configurations
+	/* idle bytes kept per device: three quarters of the HBM.  A step of the larger configurations
 	 * (1 Gb assembly, 30 M reads) turns over > 100 GB; a cap below the turnover makes every step pay the driver for its buffers again
 	 * (measured with 96 GB: 2.3 s instead of 0.27 s per cfg4 pass).  An allocation that fails drops the whole cache and retries */
 	static const size_t cap = []() -> size_t {
-		const int64_t e = env_i64("YAKAMD_POOL_MAX_GB", -1);
-		if (e >= 0) return (size_t)e << 30;
 		size_t fr = 0, tot = 0;
 		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)96 << 30; }
 		return tot / 4 * 3;
@@ -1997,7 +1995,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	if (!sorted) {
 		if (dmalloc(&kc[1], n_sel) || dmalloc(&tt[1], n_sel)) return -1;
 		EvTimer tm(c->st);
-		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= (u64)env_i64("YAKAMD_SORT_BIG", 30000);
+		const int sort_big = n_sel / (u64)std::max(1, c->phi - c->plo) >= 30000;
 		for (int shift = 0; shift < tbits; shift += 8) {
 			yk_launch_seg_sort_pass2(d_segbase, d_segcur, P, kc[cur], tt[cur], kc[cur ^ 1], tt[cur ^ 1], shift, c->st, sort_big);
 			cur ^= 1;

@@ -998,23 +998,19 @@ static int parse_threads(int n_thread)
 	return n < 1 ? 1 : n > 32 ? 32 : n;
 }
 
-/* Parsed base images can live in page-locked host memory (YAKAMD_PIN=1: the copy to the device is then a DMA
- * transfer); the buffers are reused from window to window. */
+/* The parsed base images' buffers (reused from window to window; pageable: page-locking them cost more than the runtime's staged copies of
+ * pageable memory -- CLI run 1.44 s against 2.2 s -- and the multi-GPU reader stages through its own two pinned buffers) */
 extern "C++" {
 template <class T> struct PinAlloc {
 	typedef T value_type;
 	PinAlloc() {}
 	template <class U> PinAlloc(const PinAlloc<U>&) {}
 	T *allocate(size_t n) {
-		static const bool pin = getenv("YAKAMD_PIN") && atoi(getenv("YAKAMD_PIN")) != 0;   /* off by default: on the test box page-locking the buffers costs more than the staged copies of pageable memory (CLI run 1.44 s against 2.2 s) */
-		void *p = 0;
-		if (pin && hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) == hipSuccess) return (T*)((uintptr_t)p);
-		(void)hipGetLastError();
-		p = malloc(n * sizeof(T) + 16);
+		void *p = malloc(n * sizeof(T) + 16);
 		if (!p) throw std::bad_alloc();
 		return (T*)p;
 	}
-	void deallocate(T *p, size_t) { if (hipHostFree((void*)p) != hipSuccess) { (void)hipGetLastError(); free((void*)p); } }
+	void deallocate(T *p, size_t) { free((void*)p); }
 	template <class U> void construct(U*) {}                        /* resize() leaves new bytes alone: they are written right away (no zero fill of a 100 MB sequence) */
 	template <class U, class A0> void construct(U *p, const A0 &a) { ::new ((void*)p) U(a); }
 	template <class U> bool operator==(const PinAlloc<U>&) const { return true; }
@@ -1431,7 +1427,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	double t_sink = 0, t_round_wait = 0;                        /* YAKAMD_VERBOSE: where the reader's time goes */
 	/* host -> device through two pinned staging buffers: while one is on its way over the bus the reader copies the next piece into the other (a
 	 * copy from pageable memory is staged by the runtime anyway, but behind a synchronise per piece) */
-	const size_t STG = (size_t)std::max<int64_t>(1 << 20, getenv("YAKAMD_MGPU_STAGE") ? atoll(getenv("YAKAMD_MGPU_STAGE")) : (int64_t)32 << 20);
+	const size_t STG = (size_t)32 << 20;
 	uint8_t *stg[2] = { 0, 0 };
 	hipEvent_t stg_ev[2] = { 0, 0 };
 	bool stg_busy[2] = { false, false };
@@ -1761,7 +1757,7 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 		ByteSource psrc; int psrc_fd = -1;
 		if (parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd)) {
 			size_t total = 0;
-			parse_parallel(&psrc, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; if (!getenv("YAKAMD_PARSE_DISCARD")) img.insert(img.end(), part, part + part_n); return true; });
+			parse_parallel(&psrc, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; img.insert(img.end(), part, part + part_n); return true; });
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
 			if (psrc_fd >= 0) ::close(psrc_fd);
 			fx.close_file();
