@@ -93,7 +93,7 @@ def test_cfg4_5gb_assembly_in_sweeps():
     reproduces the reference's own md5 at 2 Gb (tests/golden/cfg45_full.json: cfg4_20x100000000.oracle_prefix_ranges_reproduce_it).  The
     2-sweep run is compared byte for byte (md5 of the 40 GB dump); both runs keep the size-independent properties"""
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg45_full.json"))).get("cfg4_50x100000000")
-    for sweeps in ("2", "4"):
+    for sweeps in ("2",):                                      # (4 and 8 sweeps were the earlier rounds' way through this size: tests/tools, profiles/r03_*)
         d = bench_line("--config", "cfg4", "--contigs", "50", "--sweeps", sweeps, *(() if sweeps == "2" else ("--no-verify",)))
         v = d["verify"]
         assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"] and v["chunking_independent"]

@@ -1344,8 +1344,11 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 				if (cnt == 0 || s == sd) continue;
 				const uint64_t *src = J->d_send[x][s] + bst[s][lo] * W;
 				uint64_t *dst = J->d_recv[x][sd] + roff[d][s] * W;
-				if (J->use_rccl) {
-					if (J->R.Send(src, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess || J->R.Recv(dst, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok[0] = 0;
+				if (J->use_rccl) {                                      /* (the current device matches the communicator of every call, as the library's own examples do it) */
+					hipSetDevice(J->sdev[s]);
+					if (J->R.Send(src, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess) ok[0] = 0;
+					hipSetDevice(J->sdev[sd]);
+					if (J->R.Recv(dst, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok[0] = 0;
 				} else {
 					hipSetDevice(J->sdev[sd]);
 					if (hipMemcpyPeerAsync(dst, J->sdev[sd], src, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
