@@ -50,9 +50,57 @@ def synth_lib():
     return L
 
 
-def make_reads(n_reads, genome, seed, first, torch, threads):
-    """reads of this rank as a pinned uint8 tensor (memory image: 150 bases + '\\n' per read)"""
-    t = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, pin_memory=True)
+class HostBuf:
+    """page-locked host bytes from the library's own runtime (yakamd_host_alloc): the single-GPU mode needs no PyTorch"""
+    def __init__(self, L, nbytes):
+        self.L, self.n = L, nbytes
+        self.p = L.yakamd_host_alloc(max(1, nbytes))
+        if not self.p:
+            raise MemoryError("yakamd_host_alloc")
+
+    def data_ptr(self):
+        return self.p
+
+    def numel(self):
+        return self.n
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.yakamd_host_free(self.p); self.p = None
+
+
+class DevBuf:
+    """device bytes (yakamd_dev_alloc)"""
+    def __init__(self, L, nbytes):
+        self.L, self.n = L, nbytes
+        self.p = L.yakamd_dev_alloc(max(16, nbytes))
+        if not self.p:
+            raise MemoryError("yakamd_dev_alloc")
+
+    def data_ptr(self):
+        return self.p
+
+    def numel(self):
+        return self.n
+
+    def to_numpy(self, dtype):
+        import numpy as np
+        out = np.empty(self.n // np.dtype(dtype).itemsize, dtype=dtype)
+        if self.L.yakamd_memcpy_d2h(out.ctypes.data, self.p, out.nbytes) != 0:
+            raise RuntimeError("d2h")
+        return out
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.yakamd_dev_free(self.p); self.p = None
+
+
+def make_reads(n_reads, genome, seed, first, torch, threads, L=None):
+    """reads of this rank in page-locked host memory (memory image: 150 bases + '\\n' per read): a pinned uint8 tensor for the torch driver, else a HostBuf"""
+    if torch is not None:
+        t = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, pin_memory=True)
+    else:
+        t = HostBuf(L, n_reads * (READ_LEN + 1))
     synth_lib().yaksynth_reads(t.data_ptr(), n_reads, READ_LEN, genome, seed, 0.005, 0.0005, first, threads)
     return t
 
@@ -329,8 +377,6 @@ def main():
             raise SystemExit("--scaling strong needs --total-reads")
         a.reads = a.total_reads // max(1, a.gpus)
 
-    import torch
-    import torch.distributed as dist
     import yak_amd
 
     rank = int(os.environ.get("RANK", "0"))
@@ -338,10 +384,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     sharded = world > 1 or a.force_exchange
+    torch = dist = dev = None                       # PyTorch only serves the torch driver of the N > 1 mode (device buffers of the all-to-all, torch.distributed)
+    if sharded:
+        import torch
+        import torch.distributed as dist
+        local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if sharded:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
@@ -353,6 +403,15 @@ def main():
     L = yak_amd.lib()
     if L.yakamd_device_count() < 1:
         raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")
+
+    def dev_sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        elif L.yakamd_device_sync() != 0:
+            raise RuntimeError(yak_amd._err())
+
+    def dev_empty(nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev) if torch is not None else DevBuf(L, nbytes)
 
     P = 1 << PRE
     if P % world:
@@ -369,13 +428,16 @@ def main():
     batch_reads = a.reads // n_batches
     rec_len = READ_LEN + 1
     B = batch_reads * rec_len                       # bytes (= stream positions) of a full chunk
-    d_reads = torch.empty(a.reads * rec_len, dtype=torch.uint8, device=dev)
+    d_reads = dev_empty(a.reads * rec_len)
     h_reads = None
     for b in range(n_batches):
         nb_reads = min(batch_reads, a.reads - b * batch_reads)
-        h_reads = make_reads(nb_reads, genome, 42, (b * world + rank) * batch_reads, torch, min(threads, 64))
-        d_reads[b * B:b * B + nb_reads * rec_len].copy_(h_reads, non_blocking=False)
-    torch.cuda.synchronize()
+        h_reads = make_reads(nb_reads, genome, 42, (b * world + rank) * batch_reads, torch, min(threads, 64), L)
+        if torch is not None:
+            d_reads[b * B:b * B + nb_reads * rec_len].copy_(h_reads, non_blocking=False)
+        elif L.yakamd_memcpy_h2d(d_reads.data_ptr() + b * B, h_reads.data_ptr(), nb_reads * rec_len) != 0:
+            raise RuntimeError("h2d")
+    dev_sync()
     n_bytes = d_reads.numel()
     batch_span = [(b * B, min(B, n_bytes - b * B)) for b in range(n_batches)]
 
@@ -452,7 +514,7 @@ def main():
 
     def step(keep=False):
         def tick(name, t0):
-            torch.cuda.synchronize()
+            dev_sync()
             t1 = time.perf_counter()
             wall[name] = (t1 - t0) * 1e3
             return t1
@@ -487,7 +549,7 @@ def main():
     def barrier():
         if sharded:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     for _ in range(a.warmup):
         step()
@@ -562,13 +624,13 @@ def main():
     packed_probe = None
     if not a.no_packed and not sharded:
         nw = (n_bytes + 31) // 32
-        d_codes = torch.empty(2 * nw + 4, dtype=torch.int32, device=dev)
-        d_valid = torch.empty(nw + 4, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        d_codes = dev_empty(4 * (2 * nw + 4))
+        d_valid = dev_empty(4 * (nw + 4))
+        dev_sync()
         tpk = time.perf_counter()
         if L.yakamd_pack_bases_dev(d_reads.data_ptr(), n_bytes, d_codes.data_ptr(), d_valid.data_ptr(), None) != 0:
             raise RuntimeError("pack: " + yak_amd._err())
-        torch.cuda.synchronize()
+        dev_sync()
         pack_ms = (time.perf_counter() - tpk) * 1e3
         packed[0] = (d_codes, d_valid)
         step()
@@ -592,17 +654,20 @@ def main():
     qv_probe = None
     if not a.no_qv and not sharded:
         t_q, _, _, _ = step(keep=True)
-        d_t16 = torch.empty(n_bytes, dtype=torch.int16, device=dev)
+        d_t16 = dev_empty(2 * n_bytes)
         L.yakamd_lookup_dev(t_q.h, d_reads.data_ptr(), n_bytes, d_t16.data_ptr())       # warm-up
-        torch.cuda.synchronize()
+        dev_sync()
         tq = time.perf_counter()
         for _ in range(3):
             if L.yakamd_lookup_dev(t_q.h, d_reads.data_ptr(), n_bytes, d_t16.data_ptr()) != 0:
                 raise RuntimeError("lookup")
-        torch.cuda.synchronize()
+        dev_sync()
         ms_q = (time.perf_counter() - tq) / 3 * 1e3
-        n_q = int((d_t16 != -1).sum().item())
-        present = int((d_t16 > 0).sum().item())
+        import numpy as np
+        h_t16 = d_t16.to_numpy(np.uint16)
+        n_q = int((h_t16 != 0xffff).sum())
+        present = int(((h_t16 != 0xffff) & (h_t16 > 0)).sum())
+        del h_t16
         # lookup = 8 algorithmic bytes per k-mer instance (+ the input, reported separately)
         qv_probe = {"kernel": "k_lookup", "kmers_looked_up": n_q, "present": present, "ms": ms_q, "lookups_per_s": n_q / (ms_q * 1e-3),
                     "achieved_GBs": 8.0 * n_q / (ms_q * 1e-3) / 1e9, "frac_of_hbm_peak": 8.0 * n_q / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -654,7 +719,7 @@ def main():
                     t.destroy_bf(); t.clear()
             if a.bf_shift > 0:
                 t.shrink(2, 1023)
-            torch.cuda.synchronize()
+            dev_sync()
             tot_ = t.tot
             t.close()
             return tot_
@@ -676,7 +741,7 @@ def main():
                 # A process that starts right after another one released tens of GB of HBM waits for the driver to hand those pages
                 # out again (measured: +1.5 s before its first batch).  So this process gives its cached device memory back first and
                 # the device gets a few idle seconds before each run; both runs are reported, `ms` is the better one
-                L.yakamd_trim(); torch.cuda.empty_cache()
+                L.yakamd_trim()
                 runs = []
                 for _ in range(2):
                     time.sleep(8.0)

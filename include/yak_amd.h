@@ -144,6 +144,12 @@ void yakamd_debug_counters(uint32_t *out4);
 yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
                                  const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out);
 
+/* runtime services for callers without a HIP runtime of their own: page-locked host memory, a device-wide synchronise, free / total device memory */
+void *yakamd_host_alloc(size_t bytes);
+void yakamd_host_free(void *p);
+int yakamd_device_sync(void);
+int yakamd_mem_info(size_t *free_bytes, size_t *total_bytes);
+
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
 

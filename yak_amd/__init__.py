@@ -33,6 +33,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
     "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
     "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
+    "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info",
 ]
 
 
@@ -158,9 +159,13 @@ def lib():
     L.yakamd_qv_reduce_dev.restype = C.c_int
     L.yakamd_qv_reduce_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    L.yakamd_host_alloc.restype = C.c_void_p; L.yakamd_host_alloc.argtypes = [C.c_size_t]
+    L.yakamd_host_free.argtypes = [C.c_void_p]
+    L.yakamd_device_sync.restype = C.c_int
+    L.yakamd_mem_info.restype = C.c_int; L.yakamd_mem_info.argtypes = [P(C.c_size_t), P(C.c_size_t)]
     L.yakamd_dev_alloc.restype = C.c_void_p; L.yakamd_dev_alloc.argtypes = [C.c_size_t]
     L.yakamd_dev_free.argtypes = [C.c_void_p]
-    L.yakamd_memcpy_h2d.restype = C.c_int; L.yakamd_memcpy_h2d.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.yakamd_memcpy_h2d.restype = C.c_int; L.yakamd_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.yakamd_memcpy_d2h.restype = C.c_int; L.yakamd_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
     return L

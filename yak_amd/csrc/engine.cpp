@@ -345,6 +345,8 @@ static int delta_ensure(yakamd_ctx *c)
 	return 0;
 }
 
+static hipStream_t stream_get(int dev);
+static void stream_put(int dev, hipStream_t x);
 static thread_local int g_next_device = -1;          /* device of the next context created on this thread (multi-GPU tables) */
 void yk_ctx_next_device(int dev) { g_next_device = dev; }
 
@@ -376,7 +378,7 @@ yakamd_ctx *yk_ctx_create(int k, int pre, int n_hash, int n_shift)
 		if (!getenv("YAKAMD_DEVICE") && lr && hipGetDeviceCount(&nd) == hipSuccess && nd > 0) c->dev = atoi(lr) % nd;
 	}
 	if (g_next_device >= 0) { c->dev = g_next_device; g_next_device = -1; }
-	if (hipSetDevice(c->dev) != hipSuccess || hipStreamCreate(&c->st) != hipSuccess) { fail("cannot open device %d", c->dev); delete c; return 0; }
+	if (hipSetDevice(c->dev) != hipSuccess || (c->st = stream_get(c->dev)) == 0) { fail("cannot open device %d", c->dev); delete c; return 0; }
 	if (n_hash > 0 && n_shift > pre) {                       /* reference htab.c:23-27 */
 		c->n_hash = n_hash; c->bf_shift = n_shift; c->nb = n_shift - pre;
 		c->has_bloom = c->nb >= 9 && c->nb + 9 <= 64;        /* yak_bf_init returns NULL otherwise (bbf.c:9) */
@@ -443,7 +445,7 @@ void yk_ctx_destroy(yakamd_ctx *c)
 	if (c->hm_keys) hipHostFree(c->hm_keys);
 	if (c->hm_used) hipHostFree(c->hm_used);
 	free(c->hts);
-	if (c->st) hipStreamDestroy(c->st);
+	if (c->st) stream_put(c->dev, c->st);
 	delete c;
 }
 
@@ -527,11 +529,34 @@ extern "C" int yakamd_pass_begin(yak_ch_t *h, int create_new)
 
 static int bloom_materialise(yakamd_ctx *c);
 
+/* events and streams are kept and handed out again: creating and destroying them costs a runtime call each (a millisecond per stream with the
+ * ROCm 7.2 runtime), and a counting job of 60 ms opens a table per step and times a dozen stages */
+struct HipCache {
+	std::mutex mu;
+	std::vector<hipEvent_t> ev[16];
+	std::vector<hipStream_t> st[16];
+};
+static HipCache g_hc;
+static hipEvent_t ev_get()
+{
+	int d = 0; (void)hipGetDevice(&d); d &= 15;
+	{ std::lock_guard<std::mutex> lk(g_hc.mu); if (!g_hc.ev[d].empty()) { hipEvent_t e = g_hc.ev[d].back(); g_hc.ev[d].pop_back(); return e; } }
+	hipEvent_t e = 0; (void)hipEventCreate(&e); return e;
+}
+static void ev_put(hipEvent_t e) { int d = 0; (void)hipGetDevice(&d); d &= 15; std::lock_guard<std::mutex> lk(g_hc.mu); g_hc.ev[d].push_back(e); }
+static hipStream_t stream_get(int dev)
+{
+	{ std::lock_guard<std::mutex> lk(g_hc.mu); auto &v = g_hc.st[dev & 15]; if (!v.empty()) { hipStream_t x = v.back(); v.pop_back(); return x; } }
+	hipStream_t x = 0;
+	return hipStreamCreate(&x) == hipSuccess ? x : 0;
+}
+static void stream_put(int dev, hipStream_t x) { (void)hipStreamSynchronize(x); std::lock_guard<std::mutex> lk(g_hc.mu); g_hc.st[dev & 15].push_back(x); }
+
 struct EvTimer {
 	hipEvent_t a, b; hipStream_t st;
-	EvTimer(hipStream_t s) : st(s) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
+	EvTimer(hipStream_t s) : st(s) { a = ev_get(); b = ev_get(); hipEventRecord(a, st); }
 	double stop() { float ms = 0; hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); return ms; }
-	~EvTimer() { hipEventDestroy(a); hipEventDestroy(b); }
+	~EvTimer() { ev_put(a); ev_put(b); }
 };
 
 /* bloom gate over the keys first seen in the batch just inserted (kernels.hip K2) */
@@ -1179,6 +1204,9 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 
 /* yak_count(): the file whose records are retained (device, inode, size, mtime) and its sequence count, for the log line */
 void yk_ctx_set_source(yakamd_ctx *c, const uint64_t id[4], int64_t n_seq) { memcpy(c->src_id, id, 32); c->src_id[4] = (u64)n_seq; c->src_set = true; }
+/* (The retained key lists name the keys pass 1 put into the table.  Nothing can add a key between the two passes without a create_new pass -- which
+ * drops what is retained (yakamd_pass_begin) -- and yak_ch_inc / setcnt / clear only touch counts; keys removed in between (shrink, subtract) are
+ * simply not found by the count) */
 bool yk_ctx_same_source(yakamd_ctx *c, const uint64_t id[4], int64_t *n_seq)
 {
 	if (!c->src_set || (c->retained.empty() && !c->ret2.valid) || c->retain_broken || memcmp(c->src_id, id, 32) != 0) return false;
@@ -2109,6 +2137,12 @@ extern "C" void yakamd_debug_counters(uint32_t *out4)
 	out4[2] = g_r2_used; out4[3] = g_r2_refused;
 }
 
+/* small runtime services for callers that hold no HIP runtime of their own (bench.py's single-GPU mode, the tests): page-locked host memory and
+ * "everything queued on the current device is done" */
+extern "C" void *yakamd_host_alloc(size_t bytes) { void *p = 0; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : 0; }
+extern "C" void yakamd_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int yakamd_device_sync(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : fail("hipDeviceSynchronize: %s", hipGetErrorString(hipGetLastError())); }
+extern "C" int yakamd_mem_info(size_t *free_bytes, size_t *total_bytes) { return hipMemGetInfo(free_bytes, total_bytes) == hipSuccess ? 0 : -1; }
 extern "C" void *yakamd_dev_alloc(size_t bytes) { void *p = 0; return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : 0; }
 extern "C" void yakamd_dev_free(void *p) { if (p) (void)hipFree(p); }
 extern "C" int yakamd_memcpy_h2d(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
