@@ -1489,6 +1489,22 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		}
 		pub[p].bits = bitsF[p]; pub[p].src = src;
 	}
+	/* the buffer that becomes the image, known before anything runs (the schedule is simulated): a sub-table that ends there with a placement gets
+	 * its "used" bits from that step's kernels (R2Act.pad0) and needs no pass of k_r2_publish */
+	bool img_is1 = false;
+	std::vector<char> pub_needed(P, 1);
+	if (inplace) {
+		u64 in1 = 0, in0 = 0;
+		for (int p = 0; p < P; ++p) if (large[p]) (pub[p].src ? in1 : in0) += 1ull << bitsF[p];
+		img_is1 = in1 > in0;
+		if (dmalloc(&img_u, tot / 32 + 1)) return -1;
+		if (env_i64("YAKAMD_R2_BITS_IN_PLACE", 1) != 0)
+			for (int p = 0; p < P; ++p) {
+				if (!large[p] || sched[p].empty() || sched[p].back().kind != 1 || (pub[p].src != 0) != img_is1) continue;
+				acts[(sched[p].size() - 1) * P + p].pad0 = 1;
+				pub_needed[p] = 0;
+			}
+	}
 	if (inplace) tot2 = tot;                                     /* the buffers are arenas */
 	const u32 spill_cap = (u32)std::min<u64>(1u << 28, std::max<u64>(1u << 20, tot2 / 16));   /* also the list of long runs of a doubling round */
 	u64 n_keys = 0;
@@ -1532,14 +1548,11 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st);
 			lap("double (fused rounds)", k, bd, &tl);
 		}
-		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, c->st); lap("place", k, bp, &tl); }
+		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, c->st); lap("place", k, bp, &tl); }
 	}
 	u64 *img_k = 0;                                               /* the new image, once it is certain */
 	if (inplace) {
-		u64 in1 = 0, in0 = 0;
-		for (int p = 0; p < P; ++p) if (large[p]) (pub[p].src ? in1 : in0) += 1ull << bitsF[p];
-		u64 *A = in1 > in0 ? K1 : K0;
-		if (dmalloc(&img_u, tot / 32 + 1)) return -1;
+		u64 *A = img_is1 ? K1 : K0;
 		/* the regions of the sub-tables that hold nothing: empty pattern, no bit */
 		for (int p = 0; p < P;) {
 			if (large[p]) { ++p; continue; }
@@ -1550,7 +1563,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			HIPCK(hipMemsetAsync(img_u + a / 32, 0, (b - a) / 32 * 4, c->st));
 			p = q;
 		}
-		for (int p = 0; p < P; ++p) pub[p].new_off = tabs[p].off;
+		for (int p = 0; p < P; ++p) { pub[p].new_off = tabs[p].off; if (!pub_needed[p]) pub[p].bits = YK_NOCAP; }
 		HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
 		yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, A, img_u, c->st);   /* a table already in A only gets its bitmap */
 		img_k = A;
