@@ -1,0 +1,43 @@
+#!/bin/bash
+# round-4 final measurements: the default bench line (all side figures) and the other configurations (their roofline.traffic comes from the
+# counter passes already under profiles/r04_pmc_traffic*.json), kernel stats of the default / unfiltered / 1 Gb commands, layout dispatch traces
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04final; mkdir -p $O
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+Q="--no-cpu-baseline --no-pcie --no-qv --no-packed --no-nofilter"
+timeout 600 python bench.py --config nofilter $Q > $O/bench_nofilter.json 2> /dev/null
+timeout 600 python bench.py --config cfg4 --contigs 10 --contig-len 100000000 > $O/bench_cfg4_1gb.json 2> /dev/null
+timeout 600 python bench.py --config cfg4 --contigs 20 --contig-len 100000000 > $O/bench_cfg4_2gb.json 2> /dev/null
+timeout 600 python bench.py --config cfg5 > $O/bench_cfg5.json 2> /dev/null
+timeout 600 python bench.py --reads 30000000 $Q > $O/bench_30m.json 2> /dev/null
+timeout 600 python bench.py --no-retain $Q --no-verify > $O/bench_noretain.json 2> /dev/null
+YAKAMD_VERBOSE=1 timeout 900 python bench.py --config cfg3shard --warmup 1 > $O/bench_cfg3shard.json 2> $O/bench_cfg3shard.err
+YAKAMD_VERBOSE=1 timeout 900 python bench.py --config cfg4 --contigs 50 > $O/bench_cfg4_5gb_sweeps2.json 2> $O/bench_cfg4_5gb.err
+grep "ranks: input\|pool after" $O/bench_cfg4_5gb.err | head -4 > $O/cfg4_5gb_stages.txt
+grep "pool after\|level-2 partition\|k_lc2" $O/bench_cfg3shard.err | tail -8 > $O/cfg3shard_stages.txt
+for f in default nofilter cfg4_1gb cfg4_2gb cfg5 30m noretain cfg3shard cfg4_5gb_sweeps2; do python3 - $O/bench_$f.json <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r = d.get("roofline", {})
+    print(sys.argv[1].split("/")[-1], "ms", round(d["ms_per_step"], 2), "value", round(d["value"] / 1e6, 1), "M/s", {k: round(v, 4) for k, v in r.items() if ("frac" in k or k == "hbm_util") and isinstance(v, float)}, "traffic", r.get("traffic"), d.get("verify"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
+for cfg in "default:" "nofilter:--config nofilter" "cfg4_1gb:--config cfg4 --contigs 10 --contig-len 100000000"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-pcie --no-packed --no-nofilter --no-qv $args > $O/bench_profiled_$name.json 2>/dev/null
+  cp $(find $O/trace_$name -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$name.csv
+  rm -rf $O/trace_$name
+done
+python3 - $O/kernel_stats_default.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if float(r["Percentage"]) > 0.4: print(r["Name"][:56].ljust(56), r["Calls"].rjust(5), "%9.3f ms avg" % (float(r["AverageNs"])/1e6), "%9.2f ms tot" % (float(r["TotalDurationNs"])/1e6), r["Percentage"]+"%")
+PY
+R2OUT=r04final/r2_nofilter bash tests/tools/trace_r2.sh --config nofilter > /dev/null 2>&1; cp gpurun_out/r04final/r2_nofilter/r2_dispatches.txt $O/r2_dispatches_nofilter.txt
+R2OUT=r04final/r2_cfg4 bash tests/tools/trace_r2.sh --config cfg4 --contigs 20 --contig-len 100000000 > /dev/null 2>&1; cp gpurun_out/r04final/r2_cfg4/r2_dispatches.txt $O/r2_dispatches_cfg4_2gb.txt
+timeout 300 bash tests/tools/r04_e2e.sh gz > $O/e2e_cli.txt 2>&1
+ls $O

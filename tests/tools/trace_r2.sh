@@ -12,7 +12,7 @@ out = []
 prev_end = None
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    if n.startswith(("k_r2_", "k_replay", "k_seg_sort", "k_shrink", "k_lc_", "k_cnt2", "k_nsel", "__amd_rocclr_fill")):
+    if n.startswith(("k_r2_", "k_replay", "k_seg_sort", "k_shrink", "k_lc_", "k_cnt2", "k_nsel", "k_ts_", "k_part2<0, true", "k_part2<1, true", "k_part2_wc<true", "k_part2_scan", "k_kt_", "__amd_rocclr_fill")):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - prev_end) / 1e3 if prev_end else 0
         out.append("%-18s %8.1f us  gap %6.1f us  grid %s" % (n[:18], (e - s) / 1e3, gap, r.get("Grid_Size_X", "") + "x" + r.get("Grid_Size_Y", "")))
