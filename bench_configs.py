@@ -39,7 +39,7 @@ def _gold(name):
         return None
 
 
-def pmc_step_traffic(name):
+def pmc_step_traffic(name, scale=None):
     """HBM bytes of ONE step of a configuration from its committed rocprofv3 counter passes (profiles/r04_pmc_traffic_<name>.json: FETCH_SIZE x 2 as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, of a `--steps 1 --warmup 0 --no-verify` run of that very command): (bytes, source) or (None, None)"""
     fn = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{name}.json")
@@ -47,12 +47,14 @@ def pmc_step_traffic(name):
         d = json.load(open(fn))
     except Exception:
         return None, None
-    by = sum(v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in d.values() if isinstance(v, dict) and "launches" in v)
+    def w(k_):                                                # cfg3shard: the stand-ins for the peers' GPUs partition 7 of 8 chunks on this device
+        return next((f for pre, f in (scale or {}).items() if k_.startswith(pre)), 1.0)
+    by = sum(w(k_) * v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for k_, v in d.items() if isinstance(v, dict) and "launches" in v)
     return by, f"profiles/r04_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE)"
 
 
-def _roof_traffic(roof, name, seconds):
-    by, src = pmc_step_traffic(name)
+def _roof_traffic(roof, name, seconds, scale=None):
+    by, src = pmc_step_traffic(name, scale)
     roof["traffic"] = by
     roof["hbm_util"] = (by / seconds / 1e9 / HBM_PEAK_GBS) if by else None
     roof["traffic_source"] = src
@@ -393,7 +395,8 @@ def run_cfg3shard(a, torch, yak_amd):
                            "exchange_seconds": exch_s, "job_seconds": rank_s + exch_s, "job_distinct_kmers_per_s": tot * of / (rank_s + exch_s),
                            "job_reads": per_src * of},
             "roofline": _roof_traffic({"bound": "hbm", "kernel": "this rank's passes (own partition + feeds + finish)", "achieved": by / rank_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": by / rank_s / 1e9 / HBM_PEAK_GBS, "traffic": None}, "cfg3shard", rank_s),
+                                       "frac": by / rank_s / 1e9 / HBM_PEAK_GBS, "traffic": None}, "cfg3shard", rank_s,
+                                      scale={"k_xpart": 1.0 / of, "k_part_": 1.0 / of}),   # (the profiled command ran one job: --warmup 0)
             "verify": verify}
 
 
