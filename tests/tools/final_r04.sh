@@ -13,7 +13,7 @@ timeout 600 python bench.py --config cfg5 > $O/bench_cfg5.json 2> /dev/null
 timeout 600 python bench.py --reads 30000000 $Q > $O/bench_30m.json 2> /dev/null
 timeout 600 python bench.py --no-retain $Q --no-verify > $O/bench_noretain.json 2> /dev/null
 YAKAMD_VERBOSE=1 timeout 900 python bench.py --config cfg3shard --warmup 1 > $O/bench_cfg3shard.json 2> $O/bench_cfg3shard.err
-YAKAMD_VERBOSE=1 timeout 900 python bench.py --config cfg4 --contigs 50 > $O/bench_cfg4_5gb_sweeps2.json 2> $O/bench_cfg4_5gb.err
+YAKAMD_VERBOSE=1 timeout 900 python bench.py --config cfg4 --contigs 50 --warmup 1 > $O/bench_cfg4_5gb_sweeps2.json 2> $O/bench_cfg4_5gb.err
 grep "ranks: input\|pool after" $O/bench_cfg4_5gb.err | head -4 > $O/cfg4_5gb_stages.txt
 grep "pool after\|level-2 partition\|k_lc2" $O/bench_cfg3shard.err | tail -8 > $O/cfg3shard_stages.txt
 for f in default nofilter cfg4_1gb cfg4_2gb cfg5 30m noretain cfg3shard cfg4_5gb_sweeps2; do python3 - $O/bench_$f.json <<'PY'

@@ -2337,6 +2337,7 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 	return 0;
 }
 void yk_pool_release(void *p) { if (p) pool_free(p); }
+void *yk_pool_get(size_t bytes) { return pool_alloc(bytes ? bytes : 1); }   /* the current device's pool (multi-GPU chunk and exchange buffers: a job's second call finds the first one's) */
 
 /* the stored keys of every sub-table in ascending slot order, packed (what a .yak file holds, htab.c:385-389), copied
  * to `out` (room for the sum of the sub-table sizes): the dump moves 8 bytes per key instead of the whole slot arrays */

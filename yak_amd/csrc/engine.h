@@ -19,6 +19,7 @@ int  yk_ctx_tighten(yakamd_ctx *c);
 int  yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other);
 int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n);
 void yk_pool_release(void *p);
+void *yk_pool_get(size_t bytes);
 int  yk_ctx_dump_keys(yakamd_ctx *c, u64 *out);
 void yk_ctx_gate(yakamd_ctx *c, bool on);
 void yk_ctx_or_mode(yakamd_ctx *c, int mode);   /* 0 counting; 1 flag loads; 2 saved-count loads (yk_device.h FastParams.or_mode) */

@@ -1281,9 +1281,11 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, i
 		if (hipSetDevice(J->sdev[s]) != hipSuccess || hipStreamCreate(&J->st[s]) != hipSuccess || hipStreamCreateWithFlags(&J->cp[s], hipStreamNonBlocking) != hipSuccess) return false;
 		if (!J->use_rccl) for (int q = 0; q < S; ++q) if (q != s) (void)hipDeviceEnablePeerAccess(J->sdev[q], 0);
 		for (int x = 0; x < 2; ++x) {
-			J->d_base[x][s] = J->ext_base ? 0 : (uint8_t*)yakamd_dev_alloc((size_t)J->chunk + 4096);
-			J->d_send[x][s] = (uint64_t*)yakamd_dev_alloc((size_t)J->send_words * 8);
-			J->d_recv[x][s] = J->recv_words ? (uint64_t*)yakamd_dev_alloc((size_t)J->recv_words * 8) : 0;
+			/* (from the engine's pool: a process that counts again -- a benchmark's steps, the second pass of the filtered protocol -- finds these buffers there
+			 * instead of asking the driver while the pool holds most of the device) */
+			J->d_base[x][s] = J->ext_base ? 0 : (uint8_t*)yk_pool_get((size_t)J->chunk + 4096);
+			J->d_send[x][s] = (uint64_t*)yk_pool_get((size_t)J->send_words * 8);
+			J->d_recv[x][s] = J->recv_words ? (uint64_t*)yk_pool_get((size_t)J->recv_words * 8) : 0;
 			if ((!J->ext_base && !J->d_base[x][s]) || !J->d_send[x][s] || (J->recv_words && !J->d_recv[x][s])) return false;
 		}
 	}
@@ -1295,7 +1297,7 @@ static void multi_close(MultiJob *J)
 {
 	for (int s = 0; s < J->S; ++s) {
 		hipSetDevice(J->sdev[s]);
-		for (int x = 0; x < 2; ++x) { if (!J->ext_base) yakamd_dev_free(J->d_base[x][s]); yakamd_dev_free(J->d_send[x][s]); yakamd_dev_free(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
+		for (int x = 0; x < 2; ++x) { if (!J->ext_base) yk_pool_release(J->d_base[x][s]); yk_pool_release(J->d_send[x][s]); yk_pool_release(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
 		if (J->st[s]) { hipStreamDestroy(J->st[s]); J->st[s] = 0; }
 		if (J->cp[s]) { hipStreamDestroy(J->cp[s]); J->cp[s] = 0; }
 		if (J->use_rccl && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
