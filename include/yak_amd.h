@@ -123,6 +123,12 @@ int yakamd_qv_reduce_dev(yak_ch_t *h, const void *d_t_u16, const uint64_t *d_seq
  * FASTA/FASTQ(.gz) file -- sequences of >= min_len bases, each followed by '\n'.  use_fast_path = 0
  * forces the general record reader for every record.  *out is malloc()ed; returns its length or -1. */
 int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char **out);
+/* Host-only test hooks of the reader for ordinary gzip files (csrc/pgz.h; replaces gzread() behind kseq.h:80-96 for yak_count()):
+ * the compressed bytes one thread takes per batch, the smallest file the reader takes and the room it keeps in front of a batch for the
+ * record the parser carries over (0 / negative: unchanged; defaults 2 MiB, 4 MiB, 64 MiB);
+ * the inflated stream of `fn` (malloc()ed *out; -1: not taken, -2: the stream is invalid -- yakamd_last_error()). */
+void yakamd_gz_tune(int64_t chunk_bytes, int64_t min_file_bytes, int64_t front_bytes);
+int64_t yakamd_gz_inflate(const char *fn, int n_threads, char **out);
 
 /* device buffers for harnesses that do not bring their own allocator (tests; bench.py uses torch) */
 void *yakamd_dev_alloc(size_t bytes);

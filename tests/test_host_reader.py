@@ -34,10 +34,38 @@ def same(fn, oracle, k=0):
     return want
 
 
+def same_gz(fn, want, k, tmp_path, chunks=(1 << 21, 40000, 3000), threads=(2, 8, 5), fronts=(64 << 20,)):
+    """the file as ordinary gzip -- one member, several, with sync flushes -- through the parallel gzip reader (csrc/pgz.h) at chunk sizes
+    from "one thread takes it all" down to "a chunk is a fraction of a deflate block", and with hardly any room in front of a batch for
+    the record carried over: the image is the plain file's"""
+    import zlib
+    import yak_amd
+    data = open(fn, "rb").read()
+    forms = {"l6": gzip.compress(data, 6), "l1": gzip.compress(data, 1)}
+    step = max(1, len(data) // 7)
+    forms["members"] = b"".join(gzip.compress(data[i:i + step], 9) for i in range(0, len(data), step)) or gzip.compress(b"")
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    forms["flushed"] = b"".join(c.compress(data[i:i + 50000]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 50000)) + c.flush()
+    try:
+        for name, raw in forms.items():
+            gz = str(tmp_path / ("z_" + name + ".gz"))
+            open(gz, "wb").write(raw)
+            assert gzip.open(gz, "rb").read() == data
+            for i, ch in enumerate(chunks):
+                yak_amd.gz_tune(ch, 0, fronts[i % len(fronts)])
+                os.environ["YAKAMD_PARSE_THREADS"] = str(threads[i % len(threads)])
+                assert yak_amd.gz_inflate(gz, threads[i % len(threads)]) == data, (name, ch)
+                assert yak_amd.host_image(gz, k, fast=True) == want, (name, ch)
+    finally:
+        os.environ.pop("YAKAMD_PARSE_THREADS", None)
+        yak_amd.gz_tune(2 << 20, 4 << 20, 64 << 20)
+
+
 @pytest.mark.parametrize("name", ["edge.fx", "one3000.fa", "one3000x2.fa", "polya.fa"])
-def test_literal_inputs(name, oracle):
+def test_literal_inputs(name, oracle, tmp_path):
     for k in (0, 5, 31):
-        same(os.path.join(GOLD, "inputs", name), oracle, k)
+        want = same(os.path.join(GOLD, "inputs", name), oracle, k)
+        same_gz(os.path.join(GOLD, "inputs", name), want, k, tmp_path, chunks=(1 << 21, 1024))
 
 
 def test_synthetic_fastq_fasta_and_gzip(oracle, tmp_path):
@@ -46,7 +74,8 @@ def test_synthetic_fastq_fasta_and_gzip(oracle, tmp_path):
     subprocess.check_call([SYN, "-a", "-n", "40", "-l", "70000", "-g", "100000", "-s", "3", "-o", fa])  # lines longer than... one buffer holds them
     a = same(fq, oracle, 31)
     assert a.count(b"\n") == 20000
-    same(fa, oracle, 31)
+    same_gz(fq, a, 31, tmp_path)
+    same_gz(fa, same(fa, oracle, 31), 31, tmp_path, fronts=(64 << 20, 1000, 0))
     gz = str(tmp_path / "r.fq.gz")
     with gzip.open(gz, "wb") as f:
         f.write(open(fq, "rb").read())
@@ -84,7 +113,8 @@ def test_awkward_shapes(oracle, tmp_path):
         fn = str(tmp_path / "x.fx")
         open(fn, "w", newline="").write(body + tail)
         for k in (0, 31):
-            same(fn, oracle, k)
+            want = same(fn, oracle, k)
+        same_gz(fn, want, 31, tmp_path, chunks=(1 << 21, 30000), threads=(3, 8))
     assert len(body) > 3 << 20
 
 
@@ -166,4 +196,60 @@ def test_long_fasta_records_are_stripped_by_several_threads(oracle, tmp_path):
         fn = str(tmp_path / name)
         open(fn, "w", newline="").write(text)
         for k in (0, 31):
-            same(fn, oracle, k)
+            want = same(fn, oracle, k)
+        same_gz(fn, want, 31, tmp_path, chunks=(100000, 20000), threads=(4, 8), fronts=(64 << 20, 4096))   # the carried record outgrows the room in front
+
+
+def test_gzip_reader_on_streams_that_are_not_text_or_not_whole(oracle, tmp_path):
+    """the parallel gzip reader against zlib itself: bytes that are not text (no block start is ever accepted: the stitch decodes all of it),
+    stored and fixed-Huffman blocks, a header with a name and a comment, trailing garbage (ignored, as gzread ignores it), a truncated file
+    (every complete symbol is delivered, as gzread delivers it) -- and a flipped bit or a wrong CRC fail the reader instead of yielding bytes"""
+    import io
+    import zlib
+    import yak_amd
+    rnd = random.Random(3)
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGT") for _ in range(100)), "".join(chr(33 + rnd.randrange(41)) for _ in range(100))) for i in range(12000)).encode()
+    noise = bytes(rnd.getrandbits(8) for _ in range(200000))
+
+    def z(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+        return c.compress(data) + c.flush()
+    named = io.BytesIO()
+    with gzip.GzipFile(filename="reads.fq", mode="wb", fileobj=named, compresslevel=6) as f:
+        f.write(text)
+    cases = {"noise": (z(noise + text[:300000] + noise), noise + text[:300000] + noise), "stored": (z(text, 0), text), "fixed": (z(text[:500000], 6, zlib.Z_FIXED), text[:500000]),
+             "named": (named.getvalue(), text), "garbage": (z(text) + b"this is not a gzip member", text), "empty": (z(b""), b"")}
+    try:
+        for name, (raw, data) in cases.items():
+            fn = str(tmp_path / (name + ".gz"))
+            open(fn, "wb").write(raw)
+            for ch, thr in ((1 << 21, 4), (50000, 8), (2000, 3)):
+                yak_amd.gz_tune(ch, 0, -1)
+                assert yak_amd.gz_inflate(fn, thr) == data, (name, ch)
+        whole = z(text)
+        for cut in (len(whole) // 3, len(whole) - 9, len(whole) - 3, 25):
+            fn = str(tmp_path / "cut.gz")
+            open(fn, "wb").write(whole[:cut])
+            d = zlib.decompressobj(31)
+            want = d.decompress(whole[:cut])                       # what inflate() can make of it
+            for ch, thr in ((1 << 21, 4), (20000, 8)):
+                yak_amd.gz_tune(ch, 0, -1)
+                assert yak_amd.gz_inflate(fn, thr) == want, (cut, ch)
+        for at, what in ((len(whole) - 6, "CRC32"), (len(whole) - 2, "ISIZE"), (len(whole) // 2, "")):
+            bad = bytearray(whole); bad[at] ^= 0x10
+            fn = str(tmp_path / "bad.gz")
+            open(fn, "wb").write(bytes(bad))
+            for ch, thr in ((1 << 21, 4), (20000, 8)):
+                yak_amd.gz_tune(ch, 0, -1)
+                with pytest.raises(OSError) as e:
+                    yak_amd.gz_inflate(fn, thr)
+                assert what in str(e.value)
+                os.environ["YAKAMD_PARSE_THREADS"] = "4"
+                with pytest.raises(OSError):
+                    yak_amd.host_image(fn, 31, fast=True)
+        assert yak_amd.gz_inflate(str(tmp_path / "cut.gz")[:-6] + "nope.gz", 4) is None
+        open(str(tmp_path / "plain.txt"), "wb").write(text[:100000])
+        assert yak_amd.gz_inflate(str(tmp_path / "plain.txt"), 4) is None          # not gzip: the caller keeps its own path
+    finally:
+        os.environ.pop("YAKAMD_PARSE_THREADS", None)
+        yak_amd.gz_tune(2 << 20, 4 << 20, 64 << 20)

@@ -31,7 +31,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
-    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image",
+    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_gz_tune", "yakamd_gz_inflate",
     "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
     "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info",
 ]
@@ -139,6 +139,10 @@ def lib():
     L.yakamd_count_hashes_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64]
     L.yakamd_host_image.restype = C.c_int64
     L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
+    L.yakamd_gz_tune.restype = None
+    L.yakamd_gz_tune.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    L.yakamd_gz_inflate.restype = C.c_int64
+    L.yakamd_gz_inflate.argtypes = [C.c_char_p, C.c_int, P(C.c_void_p)]
     L.yak_ch_setcnt.argtypes = [P(ChT), C.c_int, C.c_int]
     L.yak_ch_restore_core.restype = P(ChT)
     L.yak_qv_solve.restype = C.c_int
@@ -319,6 +323,25 @@ def qv_counts(table_fn, seq_fn, min_len=0, min_frac=0.5, chunk=1000000000):
     L.yak_qv(C.byref(o), seq_fn.encode(), h, cnt)
     L.yak_ch_destroy(h)
     return list(cnt)
+
+
+def gz_tune(chunk_bytes=0, min_file_bytes=-1, front_bytes=-1):
+    """test hook: the gzip reader's bytes per thread and batch, the smallest file it takes, the room in front of a batch"""
+    lib().yakamd_gz_tune(chunk_bytes, min_file_bytes, front_bytes)
+
+
+def gz_inflate(fn, threads=4):
+    """the inflated stream of gzip file `fn` as the parallel reader delivers it (host only); None if it does not take the file"""
+    L = lib()
+    out = C.c_void_p()
+    n = L.yakamd_gz_inflate(fn.encode(), threads, C.byref(out))
+    if n == -1:
+        return None
+    if n < 0:
+        raise OSError("invalid gzip stream in " + fn + ": " + L.yakamd_last_error().decode())
+    data = C.string_at(out, n)
+    C.CDLL(None).free(out)
+    return data
 
 
 def host_image(fn, min_len=0, fast=True):

@@ -39,6 +39,7 @@ static int fail(const char *fmt, ...)
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char *yakamd_last_error(void) { return g_err; }
+int yk_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); fprintf(stderr, "[E::yak_amd] %s\n", g_err); return -1; }
 
 extern "C" int yakamd_device_count(void)
 {

@@ -19,6 +19,7 @@ int  yk_ctx_tighten(yakamd_ctx *c);
 int  yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other);
 int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n);
 void yk_pool_release(void *p);
+int yk_set_error(const char *fmt, ...);                      /* this thread's yakamd_last_error() text (+ a line on stderr); returns -1 */
 void *yk_pool_get(size_t bytes);
 int  yk_ctx_dump_keys(yakamd_ctx *c, u64 *out);
 void yk_ctx_gate(yakamd_ctx *c, bool on);

@@ -29,6 +29,7 @@
 #include <cmath>
 #include "engine.h"
 #include <dlfcn.h>
+#include "pgz.h"                                            /* parallel inflate of ordinary gzip files */
 #include <rccl/rccl.h>                                   /* types and prototypes only: the library is opened when a job asks for several GPUs */
 
 struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };
@@ -635,9 +636,11 @@ struct ByteSource {
 	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
 	uint64_t gen;                                                 /* identity of this source for the per-thread block cache (an address can be reused by the next job's source) */
 	const unsigned char *map; size_t map_len;                     /* a plain file, mapped: the body of a long FASTA record is stripped of its line ends by several threads straight from here */
+	bool in_memory, partial;                                      /* bytes in memory (a batch of an inflated gzip stream; map is not ours); more of the stream follows them: a record that touches their end is not finished */
 	static uint64_t next_gen() { static uint64_t g = 0; return __atomic_add_fetch(&g, 1, __ATOMIC_RELAXED); }
-	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0) {}
-	~ByteSource() { if (map) munmap((void*)map, map_len); }
+	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0), in_memory(false), partial(false) {}
+	~ByteSource() { if (map && !in_memory) munmap((void*)map, map_len); }
+	void set_memory(const unsigned char *p, size_t n, bool more_follows) { fd = -1; bgzf = false; map = p; map_len = n; size = (int64_t)n; in_memory = true; partial = more_follows; }
 	ByteSource(const ByteSource&) = delete; ByteSource &operator=(const ByteSource&) = delete;
 	void map_plain() {
 		if (bgzf || fd < 0 || size <= 0 || map || getenv("YAKAMD_NO_MMAP")) return;
@@ -708,6 +711,7 @@ struct ByteSource {
 	}
 	/* pread(2) semantics on the uncompressed stream; -1 on a corrupt block */
 	ssize_t pread_at(void *dst, size_t n, int64_t off) const {
+		if (in_memory) { if (off >= size || n == 0) return 0; const size_t take = std::min<size_t>(n, (size_t)(size - off)); memcpy(dst, map + off, take); return (ssize_t)take; }
 		if (!bgzf) return ::pread(fd, dst, n, off);
 		if (off >= size || n == 0) return 0;
 		static thread_local std::vector<unsigned char> ub, cb;
@@ -1051,11 +1055,15 @@ static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, i
 	if (sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
 	int64_t l;
 	for (;;) {
-		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = true; break; }
-		if (r.marker_pos() >= sg->end) { sg->stop = r.marker_pos(); break; }
-		if ((l = r.fast(sg->img, min_len)) == FxReader::NOT_FAST) {
-			if ((l = r.next_to(sg->img, min_len, bulk_threads)) < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
-		}
+		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = !src->partial; break; }
+		const int64_t mp = r.marker_pos();
+		if (mp >= sg->end) { sg->stop = mp; break; }
+		const size_t img0 = sg->img.size();
+		if ((l = r.fast(sg->img, min_len)) == FxReader::NOT_FAST) l = r.next_to(sg->img, min_len, bulk_threads);
+		/* more of the stream follows these bytes and the reader has used them up: the record may go on there (`last` still holds the
+		 * marker it started with, kseq.h:186-190, so it cannot tell) -- it is left, from its marker on, for the next batch */
+		if (src->partial && !r.fill()) { sg->img.resize(img0); sg->stop = mp; break; }
+		if (l < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
 		if (l >= min_len) { ++sg->n_seq; sg->sum_len += l; }
 	}
 	r.close_at();
@@ -1118,20 +1126,27 @@ static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64
 /* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
  * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
  * threads already work on the next one. */
-static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
+static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink, int64_t *stopped_at = 0, bool *stream_ended = 0)
 {
+	if (stopped_at) *stopped_at = 0;
+	if (stream_ended) *stream_ended = false;
 	const int64_t size = fd->size;
 	const int64_t WIN = (int64_t)env_threads_window();
 	std::vector<ParSeg> seg[2] = { std::vector<ParSeg>(n_thr), std::vector<ParSeg>(n_thr) };
-	int64_t pos = 0, next[2] = { 0, 0 };
+	int64_t pos = 0, next[2] = { 0, 0 }, from[2] = { 0, 0 };
 	bool done[2] = { false, false };
 	int n_ok[2] = { 0, 0 }, cur = 0;
 	if (size <= 0) return true;
 	n_ok[0] = parse_window(fd, size, 0, WIN, min_len, n_thr, seg[0], &next[0], &done[0]);
 	for (;;) {
 		pos = next[cur];
-		const bool more = !done[cur] && pos < size;
+		if (stopped_at) *stopped_at = pos;
+		if (stream_ended) *stream_ended = done[cur];
+		/* (a partial source: a window that gets nowhere stands at a record that wants the bytes still to come) */
+		const bool more = !done[cur] && pos < size && !(fd->partial && pos == from[cur]);
+		if (getenv("YAKAMD_GZ_DEBUG")) fprintf(stderr, "[gz] window from %ld: n_ok %d next %ld done %d size %ld more %d\n", (long)from[cur], n_ok[cur], (long)pos, (int)done[cur], (long)size, (int)more);
 		std::thread ahead;
+		from[cur ^ 1] = pos;
 		if (more) ahead = std::thread([&, pos]() { n_ok[cur ^ 1] = parse_window(fd, size, pos, WIN, min_len, n_thr, seg[cur ^ 1], &next[cur ^ 1], &done[cur ^ 1]); });
 		bool ok = true;
 		for (int i = 0; i < n_ok[cur] && ok; ++i) ok = sink(seg[cur][i].img.data(), seg[cur][i].img.size(), seg[cur][i].n_seq);
@@ -1141,6 +1156,32 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const s
 		done[cur] = false;
 		cur ^= 1;
 	}
+	return true;
+}
+
+/* an ordinary gzip file: batches of it are inflated by several threads (pgz.h) while the batch before is parsed, by the same window
+ * parser, from memory; the record a batch ends in is carried to the front of the next one */
+static bool gz_source(const char *fn, const FxReader &fx, int n_thr, pgz::Reader *z)
+{
+	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_PGZ")) return false;
+	return z->open(fn, n_thr);
+}
+static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
+{
+	size_t keep = 0;
+	for (bool last = false; !last; ) {
+		uint8_t *p = 0; size_t n = 0;
+		if (!z->next(keep, &p, &n, &last)) { yk_set_error("%s", z->why.c_str()); return false; }
+		ByteSource src;
+		src.set_memory(p, n, !last);
+		int64_t stop = 0; bool ended = false;
+		if (!parse_parallel(&src, min_len, n_thr, sink, &stop, &ended)) return false;
+		if (getenv("YAKAMD_GZ_DEBUG")) fprintf(stderr, "[gz] batch %zu bytes last=%d stop=%ld ended=%d\n", n, (int)last, (long)stop, (int)ended);
+		if (ended) break;                                         /* a truncated record ended the stream (count.c:93) */
+		keep = (size_t)stop;
+	}
+	if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] gzip: %d threads inflated %lu chunks from a searched block start (%lu searched starts not used, %.1f MB decoded by the stitch)\n",
+	                                      z->n_thr, (unsigned long)z->n_search_ok, (unsigned long)z->n_search_bad, z->n_gap_bits / 8e6);
 	return true;
 }
 
@@ -1416,7 +1457,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	MultiJob J;
 	bool ok = multi_open(&J, N, P, dev);
 	const int S = J.S;
-	yk_realtime();
+	const double t_job0 = yk_realtime();
 	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
 	/* the reader fills the chunks of set `cur` while a worker thread partitions, exchanges and feeds the set before it */
 	std::vector<int64_t> fill[2] = { std::vector<int64_t>(S, 0), std::vector<int64_t>(S, 0) };
@@ -1491,8 +1532,10 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
-	const bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
+	bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
+	pgz::Reader gz;
 	if (ok && par) ok = parse_parallel(&psrc, opt->k, n_thr, take_piece) && ok;
+	else if (ok && gz_source(fn, fx, n_thr, &gz)) { par = true; ok = parse_gz(&gz, opt->k, n_thr, take_piece) && ok; }
 	else if (ok) {
 		std::vector<char> piece;
 		int64_t l, ns = 0;
@@ -1508,7 +1551,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	}
 	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
 	wait_worker();
-	const double t_fed = yk_realtime();
+	const double t_fed = yk_realtime() - t_job0;
 	for (int i = 0; i < 2; ++i) { if (stg_busy[i]) (void)hipEventSynchronize(stg_ev[i]); if (stg_ev[i]) (void)hipEventDestroy(stg_ev[i]); if (stg[i]) (void)hipHostFree(stg[i]); }
 	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
 	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
@@ -1525,7 +1568,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	multi_tot(h);
 	if (getenv("YAKAMD_VERBOSE") && atoi(getenv("YAKAMD_VERBOSE")) > 0) {
 		fprintf(stderr, "[yak_amd] %d ranks: input read, dealt and fed by %.3f s (%d parser threads; %.3f s inside the sink that copies the pieces to the devices, %.3f s of it waiting for copies and the round before), the ranks' passes finished by %.3f s\n",
-		        N, t_fed, n_thr, t_sink, t_round_wait, yk_realtime());
+		        N, t_fed, n_thr, t_sink, t_round_wait, yk_realtime() - t_job0);
 		for (int s = 0; s < S; ++s) { hipSetDevice(J.sdev[s]); yk_pool_report("the job"); }
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
@@ -1676,7 +1719,10 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	/* a plain regular file is mapped and parsed by several threads; anything else (gzip, a pipe) streams through the reader */
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
-	const int64_t par_size = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd) ? psrc.size : -1;   /* plain or block-gzipped regular file */
+	int64_t par_size = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd) ? psrc.size : -1;   /* plain or block-gzipped regular file */
+	pgz::Reader gz;
+	const bool use_gz = par_size < 0 && gz_source(fn, fx, n_thr, &gz);   /* an ordinary gzip file */
+	if (use_gz) par_size = 0;
 	int ok = 0;
 	auto open_table = [&]() {                                /* a new table: runtime start-up, the filter's 2^bf_shift bits, the pass */
 		if (!h0) h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
@@ -1691,14 +1737,15 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	uint64_t t0 = 0;
 	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
 	if (par_size >= 0) {
-		const bool parsed = parse_parallel(&psrc, opt->k, n_thr, [&](const char *img, size_t img_n, int64_t ns) {
+		const std::function<bool(const char*, size_t, int64_t)> sink = [&](const char *img, size_t img_n, int64_t ns) {
 			if (opener.joinable()) opener.join();
 			if (!ok) return false;
 			bool good = img_n == 0 || yakamd_feed_bases_host(h, img, (int64_t)img_n, t0) == 0;
 			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
 			return good;
-		});
+		};
+		const bool parsed = use_gz ? parse_gz(&gz, opt->k, n_thr, sink) : parse_parallel(&psrc, opt->k, n_thr, sink);
 		if (opener.joinable()) opener.join();
 		if (h == 0) { if (psrc_fd >= 0) ::close(psrc_fd); fx.close_file(); return 0; }
 		ok = ok && parsed;
@@ -1760,9 +1807,13 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 	const int n_thr = use_fast_path ? parse_threads(1) : 1;    /* tests set YAKAMD_PARSE_THREADS */
 	{
 		ByteSource psrc; int psrc_fd = -1;
-		if (parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd)) {
+		pgz::Reader gz;
+		const bool plain = parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd);
+		if (plain || gz_source(fn, fx, n_thr, &gz)) {
 			size_t total = 0;
-			parse_parallel(&psrc, min_len, n_thr, [&](const char *part, size_t part_n, int64_t) { total += part_n; img.insert(img.end(), part, part + part_n); return true; });
+			const std::function<bool(const char*, size_t, int64_t)> sink = [&](const char *part, size_t part_n, int64_t) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
+			if (plain) parse_parallel(&psrc, min_len, n_thr, sink);
+			else if (!parse_gz(&gz, min_len, n_thr, sink)) { fx.close_file(); return -1; }
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
 			if (psrc_fd >= 0) ::close(psrc_fd);
 			fx.close_file();
@@ -1782,6 +1833,32 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 	*out = (char*)malloc(img.size() + 1);
 	memcpy(*out, img.data(), img.size());
 	return (int64_t)img.size();
+}
+
+/* host-only hooks for tests of the gzip reader: its chunk size, the smallest file it takes and the room in front of a batch (0 / < 0: as is); the whole inflated stream of
+ * `fn` through the batch interface, every batch handing a tail back as the parser does (-1: not a file the reader takes; -2: it failed) */
+void yakamd_gz_tune(int64_t chunk_bytes, int64_t min_file_bytes, int64_t front_bytes)
+{
+	if (chunk_bytes > 0) pgz::tune().chunk = (size_t)chunk_bytes;
+	if (min_file_bytes >= 0) pgz::tune().min_size = (size_t)min_file_bytes;
+	if (front_bytes >= 0) pgz::tune().front = (size_t)front_bytes;
+}
+int64_t yakamd_gz_inflate(const char *fn, int n_threads, char **out)
+{
+	pgz::Reader z;
+	*out = 0;
+	if (!z.open(fn, n_threads, true)) return -1;
+	std::vector<char> all;
+	size_t keep = 0;
+	for (bool last = false; !last; ) {
+		uint8_t *p = 0; size_t n = 0;
+		if (!z.next(keep, &p, &n, &last)) { yk_set_error("%s", z.why.c_str()); return -2; }
+		keep = last ? n : n - std::min<size_t>(n, (all.size() * 7 + 13) % 5000);
+		all.insert(all.end(), (const char*)p, (const char*)p + keep);
+	}
+	*out = (char*)malloc(all.size() + 1);
+	memcpy(*out, all.data(), all.size());
+	return (int64_t)all.size();
 }
 
 /* reference qv.c:137-144 */
