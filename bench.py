@@ -698,11 +698,18 @@ def main():
                     "step_frac": 32.0 * st_nb["n_instances"] / (ms_nb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "phase_ms": {k: round(v, 3) for k, v in st_nb.items() if k.startswith("ms_") and k != "ms_bloom"}}
 
-    # the rate with the base image handed over from HOST memory in both passes (yakamd_feed_bases_host, what
+    # the rate with the base image handed over from HOST memory in both passes (packed by the host: yakamd_feed_packed_host, what
     # yak_count() does after parsing) and the whole `yak-amd count` command on the same reads as a FASTQ file
     # (process start, parsing, PCIe, counting, writing the .yak) -- side figures, never `value`
-    pcie_ms = e2e = None
+    pcie_ms = e2e = host_pack = None
     if not a.no_pcie and not sharded:
+        # the parser's share, outside the timed region like the parsing itself: the image packed to 0.375 B per base (yakamd_pack_bases_host,
+        # what yak_count()'s parser threads do with what they parsed) in page-locked memory
+        h_packed = HostBuf(L, L.yakamd_packed_bytes(n_bytes))
+        tpk = time.perf_counter()
+        L.yakamd_pack_bases_host(h_reads.data_ptr(), n_bytes, h_packed.data_ptr())
+        host_pack = {"bytes_over_the_bus": L.yakamd_packed_bytes(n_bytes), "ascii_bytes": n_bytes, "one_thread_gb_per_s": n_bytes / (time.perf_counter() - tpk) / 1e9}
+
         def host_protocol():
             t = yak_amd.Table(K, PRE, N_HASH, a.bf_shift)
             if a.bf_shift > 0 and not a.no_retain:
@@ -711,7 +718,7 @@ def main():
                 if L.yakamd_pass_begin(t.h, create_new) != 0:
                     raise RuntimeError(yak_amd._err())
                 kept = L.yakamd_count_retained(t.h) if (not create_new and not a.no_retain) else 1
-                if kept < 0 or (kept and L.yakamd_feed_bases_host(t.h, h_reads.data_ptr(), n_bytes, 0) != 0):
+                if kept < 0 or (kept and L.yakamd_feed_packed_host(t.h, h_packed.data_ptr(), n_bytes, 0) != 0):
                     raise RuntimeError(yak_amd._err())
                 n_ins = L.yakamd_pass_end(t.h)
                 t.h.contents.tot += n_ins
@@ -886,7 +893,7 @@ def main():
         "verify": verify,
         "job_yak_md5": job_md5,
         "qv_lookup_probe": qv_probe,
-        "packed_input": packed_probe, "pcie_inclusive_ms": pcie_ms, "pcie_inclusive_value": (tot_all / (pcie_ms * 1e-3)) if pcie_ms else None,
+        "packed_input": packed_probe, "pcie_inclusive_ms": pcie_ms, "pcie_inclusive_host_pack": host_pack, "pcie_inclusive_value": (tot_all / (pcie_ms * 1e-3)) if pcie_ms else None,
         "e2e_cli": e2e,
         "replay_doublings_parallel_vs_serial_fallback": list(dbgc),
     }

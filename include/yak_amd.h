@@ -47,6 +47,12 @@ int yakamd_feed_bases_host(yak_ch_t *h, const void *h_bases, int64_t n_bytes, ui
  * Both device pointers, the codes 16-byte aligned; words past n_bases are not read beyond the last partial one.  The counting
  * passes then read 0.375 B per position instead of 1 */
 int yakamd_feed_packed_dev(yak_ch_t *h, const void *d_codes, const void *d_valid, int64_t n_bases, uint64_t t0);
+/* the packed image from host memory: `h_packed` = yakamd_packed_bytes(n_bases) bytes, the code words followed (at the next multiple of 16
+ * bytes) by the validity words -- what yakamd_pack_bases_host() writes (any thread; yak_count()'s parser threads pack what they parsed,
+ * so the stream crosses the bus at 0.375 B per base, count.c:88-110's reader loop being the host side of this) */
+int64_t yakamd_packed_bytes(int64_t n_bases);
+void yakamd_pack_bases_host(const void *ascii, int64_t n_bases, void *h_packed);
+int yakamd_feed_packed_host(yak_ch_t *h, const void *h_packed, int64_t n_bases, uint64_t t0);
 /* device-side packer: ASCII image -> d_codes ((n + 31) / 32 * 8 bytes) and d_valid ((n + 31) / 32 * 4 bytes); `stream` = a hipStream_t or 0 */
 int yakamd_pack_bases_dev(const void *d_ascii, int64_t n, void *d_codes, void *d_valid, void *stream);
 /* already hashed k-mers (yak_hash64 output) with their stream positions t0 + t[i], t[i] < t_span;
@@ -123,9 +129,13 @@ int yakamd_qv_reduce_dev(yak_ch_t *h, const void *d_t_u16, const uint64_t *d_seq
  * FASTA/FASTQ(.gz) file -- sequences of >= min_len bases, each followed by '\n'.  use_fast_path = 0
  * forces the general record reader for every record.  *out is malloc()ed; returns its length or -1. */
 int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char **out);
+/* the same stream as yak_count() really hands it over: packed by the parser threads, one image per window -- here unpacked again, a base as
+ * 'A' 'C' 'G' 'T', any other position (N, the end of a record, the positions that pad a parsed segment to a multiple of 32) as '\n'.
+ * -1 if the file is not one the parallel parser takes (a pipe, a file read by one thread). */
+int64_t yakamd_host_image_packed(const char *fn, int min_len, char **out);
 /* Host-only test hooks of the reader for ordinary gzip files (csrc/pgz.h; replaces gzread() behind kseq.h:80-96 for yak_count()):
  * the compressed bytes one thread takes per batch, the smallest file the reader takes and the room it keeps in front of a batch for the
- * record the parser carries over (0 / negative: unchanged; defaults 2 MiB, 4 MiB, 64 MiB);
+ * record the parser carries over (0 / negative: unchanged; defaults 1 MiB, 4 MiB, 64 MiB);
  * the inflated stream of `fn` (malloc()ed *out; -1: not taken, -2: the stream is invalid -- yakamd_last_error()). */
 void yakamd_gz_tune(int64_t chunk_bytes, int64_t min_file_bytes, int64_t front_bytes);
 int64_t yakamd_gz_inflate(const char *fn, int n_threads, char **out);

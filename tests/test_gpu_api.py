@@ -498,7 +498,16 @@ def test_packed_image_feed_equals_ascii_feed(k, bf, ya, oracle, synth):
         tp.destroy_bf(); tp.clear(); tp.count_pass_packed(0, [(d_c, d_v, n, 0)])
         O.yko_ch_destroy_bf(o); O.yko_ch_clear(o); O.yko_count_mem(img, n, C.byref(oc), o)
         assert tp.dump_bytes() == oracle.dump_bytes(o)
-    tp.close(); ta.close(); O.yko_ch_destroy(o)
+    # the packer of the host side (yak_count()'s parser threads) writes the same words, and its image fed from host memory -- in three pieces, as
+    # parsed segments arrive, each packed on its own -- counts to the same bytes
+    pk = ya.pack_bases_host(img)
+    cb = (8 * nw + 15) & ~15
+    assert pk[:8 * nw] == bytes(codes) and pk[cb:cb + 4 * nw] == bytes(valid)
+    th = ya.Table(k, 10, 4, bf)
+    cuts = [0, img.index(b"\n", n // 3) + 1, img.index(b"\n", 2 * n // 3) + 1, n]
+    th.count_pass_packed_host(1, [(img[a:b], a) for a, b in zip(cuts, cuts[1:])])
+    assert th.dump_bytes() == ta.dump_bytes() and th.tot == ta.tot
+    tp.close(); ta.close(); th.close(); O.yko_ch_destroy(o)
     for d in (d_a, d_c, d_v):
         L.yakamd_dev_free(d)
 

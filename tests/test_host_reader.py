@@ -14,6 +14,12 @@ from conftest import GOLD, ROOT
 SYN = os.path.join(ROOT, "tools", "yaksynth")
 
 
+def bases_runs(img):
+    """the maximal runs of bases of an image, in stream order: all that count.c:28-43 sees of it (a position that is no base only ends a run)"""
+    import re
+    return re.sub(rb"[^ACGT]+", b"\n", img.upper().replace(b"U", b"T").replace(b"\0", b"A").replace(b"\1", b"C").replace(b"\2", b"G").replace(b"\3", b"T")).strip(b"\n")
+
+
 def same(fn, oracle, k=0):
     """general reader, in-buffer fast path, and the speculative parallel parser (several thread counts,
     windows small enough that guesses fall into every kind of line) all give the oracle's image"""
@@ -21,6 +27,7 @@ def same(fn, oracle, k=0):
     want = oracle.read_image(fn, k)
     assert yak_amd.host_image(fn, k, fast=True) == want
     assert yak_amd.host_image(fn, k, fast=False) == want
+    runs = bases_runs(want)
     try:
         for thr, win in ((2, 0), (3, 70001), (8, 0), (5, 1 << 20), (7, 333 if os.path.getsize(fn) < 300000 else 40009)):
             os.environ["YAKAMD_PARSE_THREADS"] = str(thr)
@@ -29,6 +36,8 @@ def same(fn, oracle, k=0):
             else:
                 os.environ.pop("YAKAMD_PARSE_WINDOW", None)
             assert yak_amd.host_image(fn, k, fast=True) == want, (thr, win)
+            pk = yak_amd.host_image_packed(fn, k)                  # what yak_count() really feeds: the windows packed by the parser threads
+            assert pk is None or bases_runs(pk) == runs, (thr, win)
     finally:
         os.environ.pop("YAKAMD_PARSE_THREADS", None); os.environ.pop("YAKAMD_PARSE_WINDOW", None)
     return want
@@ -56,9 +65,10 @@ def same_gz(fn, want, k, tmp_path, chunks=(1 << 21, 40000, 3000), threads=(2, 8,
                 os.environ["YAKAMD_PARSE_THREADS"] = str(threads[i % len(threads)])
                 assert yak_amd.gz_inflate(gz, threads[i % len(threads)]) == data, (name, ch)
                 assert yak_amd.host_image(gz, k, fast=True) == want, (name, ch)
+                assert bases_runs(yak_amd.host_image_packed(gz, k)) == bases_runs(want), (name, ch)
     finally:
         os.environ.pop("YAKAMD_PARSE_THREADS", None)
-        yak_amd.gz_tune(2 << 20, 4 << 20, 64 << 20)
+        yak_amd.gz_tune(1 << 20, 4 << 20, 64 << 20)
 
 
 @pytest.mark.parametrize("name", ["edge.fx", "one3000.fa", "one3000x2.fa", "polya.fa"])
@@ -252,4 +262,43 @@ def test_gzip_reader_on_streams_that_are_not_text_or_not_whole(oracle, tmp_path)
         assert yak_amd.gz_inflate(str(tmp_path / "plain.txt"), 4) is None          # not gzip: the caller keeps its own path
     finally:
         os.environ.pop("YAKAMD_PARSE_THREADS", None)
-        yak_amd.gz_tune(2 << 20, 4 << 20, 64 << 20)
+        yak_amd.gz_tune(1 << 20, 4 << 20, 64 << 20)
+
+
+@pytest.mark.parametrize("wide", [True, False], ids=["avx2_if_present", "table_only"])
+def test_host_packer_follows_the_packed_image_format(wide, tmp_path):
+    """yakamd_pack_bases_host (what yak_count()'s parser threads run on what they parsed) against the format include/yak_amd.h states for
+    yakamd_feed_packed_dev: base j at bits 2 (j % 16) of code word j / 16 by seq_nt4_table (ACGT, acgt, U / u = T, raw 0..3), one validity bit
+    per base, zero codes where the bit is zero -- on reads with Ns and record separators, on every byte value, at lengths around the 32-base
+    words (the process is a fresh one: the packer picks its AVX2 path once)"""
+    import sys
+    code = r"""
+import sys, random
+sys.path.insert(0, %r)
+import yak_amd
+nt4 = {65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3, 85: 3, 117: 3, 0: 0, 1: 1, 2: 2, 3: 3}
+rnd = random.Random(2)
+def want(b):
+    n = len(b); nw = (n + 31) // 32
+    codes = [0] * (2 * nw); valid = [0] * nw
+    for j, x in enumerate(b):
+        c = nt4.get(x)
+        if c is not None:
+            valid[j >> 5] |= 1 << (j & 31); codes[j >> 4] |= c << (2 * (j & 15))
+    cb = (8 * nw + 15) & ~15
+    out = b"".join(w.to_bytes(4, "little") for w in codes) + bytes(cb - 8 * nw) + b"".join(w.to_bytes(4, "little") for w in valid)
+    return out
+cases = [b"", b"A", b"ACGTN\nacgtn\nUu\x00\x01\x02\x03\x04", bytes(range(256)) * 3]
+for n in (31, 32, 33, 63, 64, 65, 1000, 4099):
+    cases.append(bytes(rnd.choice(b"ACGTACGTACGTACGTNacgt\n") for _ in range(n)))
+cases.append(bytes(rnd.choice(b"ACGT") for _ in range(70000)))
+cases.append(bytes(rnd.getrandbits(8) for _ in range(50000)))
+for b in cases:
+    got = yak_amd.pack_bases_host(b)
+    assert len(got) == yak_amd.lib().yakamd_packed_bytes(len(b)) and got == want(b), len(b)
+print("ok")
+""" % ROOT
+    env = dict(os.environ)
+    if not wide:
+        env["YAKAMD_NO_AVX2"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, check=True, stdout=subprocess.PIPE).stdout.strip() == b"ok"

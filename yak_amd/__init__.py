@@ -25,13 +25,13 @@ YAK_H_SYMBOLS = [
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
-    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_feed_hashed_dev",
+    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_packed_bytes", "yakamd_pack_bases_host", "yakamd_feed_packed_host", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
-    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_gz_tune", "yakamd_gz_inflate",
+    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_host_image_packed", "yakamd_gz_tune", "yakamd_gz_inflate",
     "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
     "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info",
 ]
@@ -102,6 +102,12 @@ def lib():
     L.yakamd_pass_begin.restype = C.c_int; L.yakamd_pass_begin.argtypes = [P(ChT), C.c_int]
     L.yakamd_feed_bases_dev.restype = C.c_int
     L.yakamd_feed_bases_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_packed_bytes.restype = C.c_int64
+    L.yakamd_packed_bytes.argtypes = [C.c_int64]
+    L.yakamd_pack_bases_host.restype = None
+    L.yakamd_pack_bases_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.yakamd_feed_packed_host.restype = C.c_int
+    L.yakamd_feed_packed_host.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
     L.yakamd_feed_packed_dev.restype = C.c_int
     L.yakamd_feed_packed_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64]
     L.yakamd_pack_bases_dev.restype = C.c_int
@@ -139,6 +145,8 @@ def lib():
     L.yakamd_count_hashes_dev.argtypes = [P(ChT), C.c_void_p, C.c_int64]
     L.yakamd_host_image.restype = C.c_int64
     L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
+    L.yakamd_host_image_packed.restype = C.c_int64
+    L.yakamd_host_image_packed.argtypes = [C.c_char_p, C.c_int, P(C.c_void_p)]
     L.yakamd_gz_tune.restype = None
     L.yakamd_gz_tune.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     L.yakamd_gz_inflate.restype = C.c_int64
@@ -215,6 +223,20 @@ class Table:
             raise RuntimeError(_err())
         for codes, valid, n, t0 in (feeds if r else ()):
             if self.L.yakamd_feed_packed_dev(self.h, codes, valid, n, t0) != 0:
+                raise RuntimeError(_err())
+        n_ins = self.L.yakamd_pass_end(self.h)
+        if n_ins < 0:
+            raise RuntimeError(_err())
+        self.h.contents.tot += n_ins
+        return n_ins
+
+    def count_pass_packed_host(self, create_new, pieces):
+        """one pass over pieces of the stream, each packed on the host (pack_bases_host) and fed from host memory: pieces = iterable of (ascii bytes, t0)"""
+        if self.L.yakamd_pass_begin(self.h, create_new) != 0:
+            raise RuntimeError(_err())
+        for buf, t0 in pieces:
+            pk = pack_bases_host(buf)
+            if self.L.yakamd_feed_packed_host(self.h, pk, len(buf), t0) != 0:
                 raise RuntimeError(_err())
         n_ins = self.L.yakamd_pass_end(self.h)
         if n_ins < 0:
@@ -325,6 +347,16 @@ def qv_counts(table_fn, seq_fn, min_len=0, min_frac=0.5, chunk=1000000000):
     return list(cnt)
 
 
+def pack_bases_host(buf):
+    """the packed image of an ASCII base image (host only): code words, then -- 16-byte aligned -- validity words"""
+    L = lib()
+    n = len(buf)
+    out = C.create_string_buffer(max(16, L.yakamd_packed_bytes(n)))
+    src = (C.c_char * max(1, n)).from_buffer_copy(buf if n else b"\0")
+    L.yakamd_pack_bases_host(src, n, out)
+    return out.raw[:L.yakamd_packed_bytes(n)]
+
+
 def gz_tune(chunk_bytes=0, min_file_bytes=-1, front_bytes=-1):
     """test hook: the gzip reader's bytes per thread and batch, the smallest file it takes, the room in front of a batch"""
     lib().yakamd_gz_tune(chunk_bytes, min_file_bytes, front_bytes)
@@ -339,6 +371,18 @@ def gz_inflate(fn, threads=4):
         return None
     if n < 0:
         raise OSError("invalid gzip stream in " + fn + ": " + L.yakamd_last_error().decode())
+    data = C.string_at(out, n)
+    C.CDLL(None).free(out)
+    return data
+
+
+def host_image_packed(fn, min_len=0):
+    """the stream yak_count() feeds for `fn` when its parser threads pack, unpacked again (host only); None if the parallel parser does not take the file"""
+    L = lib()
+    out = C.c_void_p()
+    n = L.yakamd_host_image_packed(fn.encode(), min_len, C.byref(out))
+    if n < 0:
+        return None
     data = C.string_at(out, n)
     C.CDLL(None).free(out)
     return data

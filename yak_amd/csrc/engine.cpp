@@ -1002,6 +1002,25 @@ extern "C" int yakamd_feed_bases_host(yak_ch_t *h, const void *h_bases, int64_t 
 	return yakamd_feed_bases_dev(h, c->d_stage, n_bytes, t0);
 }
 
+/* the packed image made on the host (yakamd_pack_bases_host: the code words, then -- 16-byte aligned -- the validity words): one copy of
+ * 0.375 bytes per base over the bus, then the packed feed */
+extern "C" int64_t yakamd_packed_bytes(int64_t n_bases) { const int64_t nw = (n_bases + 31) / 32; return ((nw * 8 + 15) & ~(int64_t)15) + nw * 4; }
+extern "C" int yakamd_feed_packed_host(yak_ch_t *h, const void *h_packed, int64_t n_bases, uint64_t t0)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	if (n_bases <= 0) return 0;
+	HIPCK(hipSetDevice(c->dev));
+	const int64_t need = yakamd_packed_bytes(n_bases), valid_at = need - (n_bases + 31) / 32 * 4;
+	if (need > c->stage_cap) {
+		dfree(c->d_stage);
+		c->stage_cap = need + (need >> 3) + 4096;
+		if (dmalloc(&c->d_stage, (size_t)c->stage_cap)) { c->stage_cap = 0; return -1; }
+	}
+	HIPCK(hipMemcpyAsync(c->d_stage, h_packed, (size_t)need, hipMemcpyHostToDevice, c->st));
+	return yakamd_feed_packed_dev(h, c->d_stage, c->d_stage + valid_at, n_bases, t0);
+}
+
 extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const void *d_t, int64_t n, uint64_t t0, uint64_t t_span)
 {
 	yakamd_ctx *c = ctx_of(h);
@@ -2340,22 +2359,31 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 void yk_pool_release(void *p) { if (p) pool_free(p); }
 void *yk_pool_get(size_t bytes) { return pool_alloc(bytes ? bytes : 1); }   /* the current device's pool (multi-GPU chunk and exchange buffers: a job's second call finds the first one's) */
 
-/* the stored keys of every sub-table in ascending slot order, packed (what a .yak file holds, htab.c:385-389), copied
- * to `out` (room for the sum of the sub-table sizes): the dump moves 8 bytes per key instead of the whole slot arrays */
-int yk_ctx_dump_keys(yakamd_ctx *c, u64 *out)
+/* the .yak bytes of sub-tables [lo, hi) -- per sub-table capacity and size (4 bytes each) and the stored keys in ascending slot order,
+ * htab.c:385-389 -- put together on the device: *d_img (pool memory: yk_pool_release) holds *n_words 8-byte words, ready on the table's stream */
+int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_words)
 {
 	HIPCK(hipSetDevice(c->dev));
-	const int P = c->P;
-	std::vector<u64> seg_off(P + 1, 0);
-	for (int p = 0; p < P; ++p) seg_off[p + 1] = seg_off[p] + c->h_count[p];
-	if (seg_off[P] == 0) return 0;
-	u64 *d_segoff = 0, *d_kc = 0;
-	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segoff); dfree(d_kc); } };
-	if (dmalloc(&d_segoff, P + 1) || dmalloc(&d_kc, seg_off[P])) return -1;
+	const int P = c->P, n = hi - lo;
+	*d_img = 0; *n_words = 0;
+	if (lo < 0 || hi > P || n <= 0) return fail("yk_ctx_dump_image_dev: sub-tables [%d, %d) of %d", lo, hi, P);
+	std::vector<u64> seg_off(P + 1, 0), head(2 * (size_t)n);
+	u64 at = 0;
+	for (int p = lo; p < hi; ++p) {
+		head[p - lo] = at;
+		head[n + p - lo] = (u64)(c->h_bits[p] == YK_NOCAP ? 0 : 1u << c->h_bits[p]) | (u64)c->h_count[p] << 32;
+		seg_off[p] = ++at;
+		at += c->h_count[p];
+	}
+	u64 *d_segoff = 0, *d_head = 0, *img = 0;
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segoff); dfree(d_head); } };
+	if (dmalloc(&d_segoff, P + 1) || dmalloc(&d_head, 2 * (size_t)n) || dmalloc(&img, at)) { dfree(img); return -1; }
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	yk_launch_shrink_scatter(img_view(c), P, 0, 1023, 0, img_view(c), d_segoff, d_kc, c->st);
-	HIPCK(hipMemcpyAsync(out, d_kc, seg_off[P] * 8, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
+	HIPCK(hipMemcpyAsync(d_head, head.data(), head.size() * 8, hipMemcpyHostToDevice, c->st));
+	yk_launch_shrink_scatter(img_view(c), P, 0, 1023, 0, img_view(c), d_segoff, img, c->st);   /* (a shard holds nothing outside its own range) */
+	yk_launch_put_u64(d_head, d_head + n, (u32)n, img, c->st);
+	HIPCK(hipStreamSynchronize(c->st));                            /* (the two small host arrays and the offsets go away with this call) */
+	*d_img = img; *n_words = at;
 	return 0;
 }
 void yk_ctx_gate(yakamd_ctx *c, bool on) { c->gate_off = !on; }

@@ -21,7 +21,7 @@ int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d
 void yk_pool_release(void *p);
 int yk_set_error(const char *fmt, ...);                      /* this thread's yakamd_last_error() text (+ a line on stderr); returns -1 */
 void *yk_pool_get(size_t bytes);
-int  yk_ctx_dump_keys(yakamd_ctx *c, u64 *out);
+int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_words);   /* the .yak bytes of sub-tables [lo, hi), in pool memory */
 void yk_ctx_gate(yakamd_ctx *c, bool on);
 void yk_ctx_or_mode(yakamd_ctx *c, int mode);   /* 0 counting; 1 flag loads; 2 saved-count loads (yk_device.h FastParams.or_mode) */
 void yk_ctx_lock(yakamd_ctx *c);

@@ -410,7 +410,7 @@ struct Piece {
 	std::vector<uint32_t> crc;                                 /* of the stretches the marks cut the piece into (marks.size() + 1 of them) */
 };
 
-struct Tune { size_t chunk, min_size, front; Tune() : chunk((size_t)2 << 20), min_size((size_t)4 << 20), front((size_t)64 << 20) {} };   /* compressed bytes per thread and batch; smallest file taken; room kept in front of a batch for what the consumer carries over */
+struct Tune { size_t chunk, min_size, front; Tune() : chunk((size_t)1 << 20), min_size((size_t)4 << 20), front((size_t)64 << 20) {} };   /* compressed bytes per thread and batch; smallest file taken; room kept in front of a batch for what the consumer carries over */
 static Tune &tune() { static Tune t; return t; }
 
 struct Reader {

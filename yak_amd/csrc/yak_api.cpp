@@ -29,6 +29,7 @@
 #include <cmath>
 #include "engine.h"
 #include <dlfcn.h>
+#include <immintrin.h>
 #include "pgz.h"                                            /* parallel inflate of ordinary gzip files */
 #include <rccl/rccl.h>                                   /* types and prototypes only: the library is opened when a job asks for several GPUs */
 
@@ -446,56 +447,121 @@ yak_knt_t *yak_ch_getseq(const yak_ch_t *h, int w, uint32_t *n) /* reference hta
 }
 
 /* ---- .yak serialisation (reference htab.c:373-394): header, then per sub-table capacity, size and
- * the keys in ascending slot order ---- */
-int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out)
+ * the keys in ascending slot order.  Every shard puts the bytes of its own sub-tables together on its device
+ * (yk_ctx_dump_image_dev); they come back in one copy (yakamd_dump_mem), or go to the file in 8 MiB pieces through a
+ * few page-locked buffers that writer threads pwrite() while the next pieces are on the bus (yak_ch_dump) ---- */
+struct DumpSink {
+	uint8_t *mem; int fd;                                      /* one of the two */
+	bool put(int dev, hipStream_t st, const uint8_t *d_src, size_t bytes, size_t off);
+};
+bool DumpSink::put(int dev, hipStream_t st, const uint8_t *d_src, size_t bytes, size_t off)
 {
-	*out = 0;
+	if (bytes == 0) return true;
+	if (mem) return hipMemcpyAsync(mem + off, d_src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+	enum { NB = 6, W = 3 };
+	const size_t CH = (size_t)8 << 20, n_ch = (bytes + CH - 1) / CH;
+	static std::mutex mu;                                         /* the staging buffers are the process's: one dump at a time uses them */
+	static void *stage[NB] = { 0 };
+	std::lock_guard<std::mutex> lk(mu);
+	for (int i = 0; i < NB; ++i) if (!stage[i] && hipHostMalloc(&stage[i], CH, hipHostMallocPortable) != hipSuccess) { stage[i] = 0; return false; }
+	hipEvent_t ev[NB];
+	for (int i = 0; i < NB; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+	std::vector<int> issued_v(n_ch, 0), written_v(n_ch, 0);
+	volatile int *issued = issued_v.data(), *written = written_v.data();
+	bool good = true;
+	std::vector<std::thread> th;
+	for (int w = 0; w < W; ++w) th.emplace_back([&, w]() {
+		(void)hipSetDevice(dev);
+		for (size_t j = (size_t)w; j < n_ch; j += W) {
+			while (!__atomic_load_n(&issued[j], __ATOMIC_ACQUIRE)) std::this_thread::yield();
+			bool ok = __atomic_load_n(&issued[j], __ATOMIC_ACQUIRE) == 1 && hipEventSynchronize(ev[j % NB]) == hipSuccess;
+			const size_t n = std::min(CH, bytes - j * CH);
+			for (size_t done = 0; ok && done < n; ) {
+				const ssize_t r = ::pwrite(fd, (const char*)stage[j % NB] + done, n - done, (off_t)(off + j * CH + done));
+				if (r <= 0) ok = false; else done += (size_t)r;
+			}
+			if (!ok) __atomic_store_n(&good, false, __ATOMIC_RELAXED);
+			__atomic_store_n(&written[j], 1, __ATOMIC_RELEASE);
+		}
+	});
+	for (size_t i = 0; i < n_ch; ++i) {
+		if (i >= NB) while (!__atomic_load_n(&written[i - NB], __ATOMIC_ACQUIRE)) std::this_thread::yield();
+		const size_t n = std::min(CH, bytes - i * CH);
+		const bool ok = hipMemcpyAsync(stage[i % NB], d_src + i * CH, n, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[i % NB], st) == hipSuccess;
+		__atomic_store_n(&issued[i], ok ? 1 : 2, __ATOMIC_RELEASE);
+	}
+	for (auto &t : th) t.join();
+	(void)hipStreamSynchronize(st);
+	for (int i = 0; i < NB; ++i) (void)hipEventDestroy(ev[i]);
+	return good;
+}
+
+/* the whole .yak image through `sink`; its size, or -1 */
+static int64_t dump_through(yak_ch_t *h, DumpSink *sink, bool size_only)
+{
 	yak_ch_ext *e = (yak_ch_ext*)h;
 	const int P = 1 << h->pre, n_sub = YK_MULTI(e) ? e->n_sub : 1;
-	/* capacities and sizes are host knowledge; the keys come packed from the device(s), 8 bytes per stored key */
-	std::vector<uint32_t> cap(P), cnt(P);
 	size_t sz = 16 + (size_t)8 * P;
+	uint32_t cap, cnt;
 	for (int r = 0; r < n_sub; ++r) {
 		yak_ch_t *hs = YK_MULTI(e) ? e->sub[r] : h;
 		const int lo = YK_MULTI(e) ? (int)(((int64_t)r << h->pre) / n_sub) : 0, hi = YK_MULTI(e) ? (int)(((int64_t)(r + 1) << h->pre) / n_sub) : P;
-		for (int p = lo; p < hi; ++p) { if (yakamd_subtable(hs, p, &cap[p], &cnt[p]) != 0) return -1; sz += (size_t)8 * cnt[p]; }
+		for (int p = lo; p < hi; ++p) { if (yakamd_subtable(hs, p, &cap, &cnt) != 0) return -1; sz += (size_t)8 * cnt; }
 	}
-	uint8_t *o = (uint8_t*)malloc(sz);
-	if (!o) return -1;
-	uint32_t t[3] = { (uint32_t)h->k, (uint32_t)h->pre, YAK_COUNTER_BITS };
-	memcpy(o, YAK_MAGIC, 4); memcpy(o + 4, t, 12);
-	std::vector<uint64_t> keys;
+	if (size_only) return (int64_t)sz;
+	uint8_t head[16];
+	const uint32_t t[3] = { (uint32_t)h->k, (uint32_t)h->pre, YAK_COUNTER_BITS };
+	memcpy(head, YAK_MAGIC, 4); memcpy(head + 4, t, 12);
+	if (sink->mem) memcpy(sink->mem, head, 16);
+	else if (::pwrite(sink->fd, head, 16, 0) != 16) return -1;
 	size_t off = 16;
 	for (int r = 0; r < n_sub; ++r) {
 		yak_ch_t *hs = YK_MULTI(e) ? e->sub[r] : h;
 		const int lo = YK_MULTI(e) ? (int)(((int64_t)r << h->pre) / n_sub) : 0, hi = YK_MULTI(e) ? (int)(((int64_t)(r + 1) << h->pre) / n_sub) : P;
-		size_t all = 0, own_before = 0;
-		uint32_t c2, n2;
-		for (int p = 0; p < P; ++p) { yakamd_subtable(hs, p, &c2, &n2); if (p < lo) own_before += n2; all += n2; }   /* a shard holds nothing outside [lo, hi) */
-		keys.resize(all ? all : 1);
-		if (yk_ctx_dump_keys(((yak_ch_ext*)hs)->ctx, (u64*)keys.data()) != 0) { free(o); return -1; }
-		const uint64_t *src = keys.data() + own_before;
-		for (int p = lo; p < hi; ++p) {
-			t[0] = cap[p]; t[1] = cnt[p];
-			memcpy(o + off, t, 8); off += 8;
-			memcpy(o + off, src, (size_t)8 * cnt[p]); off += (size_t)8 * cnt[p]; src += cnt[p];
-		}
+		yakamd_ctx *c = ((yak_ch_ext*)hs)->ctx;
+		u64 *d_img = 0, n_words = 0;
+		if (yk_ctx_dump_image_dev(c, lo, hi, &d_img, &n_words) != 0) return -1;
+		const bool ok = sink->put(yk_ctx_device(c), yk_ctx_stream(c), (const uint8_t*)d_img, (size_t)n_words * 8, off);
+		(void)hipSetDevice(yk_ctx_device(c));
+		yk_pool_release(d_img);
+		if (!ok) return -1;
+		off += (size_t)n_words * 8;
 	}
-	*out = o;
-	return (int64_t)sz;
+	return off == sz ? (int64_t)sz : -1;
+}
+
+int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out)
+{
+	*out = 0;
+	const int64_t sz = dump_through(h, 0, true);
+	if (sz < 0) return -1;
+	DumpSink sink; sink.mem = (uint8_t*)malloc((size_t)sz); sink.fd = -1;
+	if (!sink.mem) return -1;
+	if (dump_through(h, &sink, false) != sz) { free(sink.mem); return -1; }
+	*out = sink.mem;
+	return sz;
 }
 
 int yak_ch_dump(const yak_ch_t *h, const char *fn)
 {
-	FILE *fp = strcmp(fn, "-") ? fopen(fn, "wb") : stdout;
-	if (fp == 0) return -1;
-	uint8_t *buf = 0;
-	const int64_t sz = yakamd_dump_mem((yak_ch_t*)h, &buf);
-	if (sz < 0) { if (fp != stdout) fclose(fp); return -1; }
-	fwrite(buf, 1, (size_t)sz, fp);
-	free(buf);
+	if (strcmp(fn, "-") == 0) {                                  /* a pipe takes the image in one piece */
+		uint8_t *buf = 0;
+		const int64_t sz = yakamd_dump_mem((yak_ch_t*)h, &buf);
+		if (sz < 0) return -1;
+		const bool ok = fwrite(buf, 1, (size_t)sz, stdout) == (size_t)sz;
+		free(buf);
+		fflush(stdout);
+		if (!ok) return -1;
+	} else {
+		const double t0 = yk_realtime();
+		DumpSink sink; sink.mem = 0;
+		sink.fd = ::open(fn, O_WRONLY | O_CREAT | O_TRUNC, 0666);   /* (fopen(fn, "wb"), htab.c:377) */
+		if (sink.fd < 0) return -1;
+		const int64_t sz = dump_through((yak_ch_t*)h, &sink, false);
+		if (::close(sink.fd) != 0 || sz < 0) return -1;
+		if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] dump: %.1f MB in %.3f s\n", sz / 1e6, yk_realtime() - t0);
+	}
 	fprintf(stderr, "[M::%s] dumpped the hash table to file '%s'.\n", __func__, fn);
-	if (fp != stdout) fclose(fp); else fflush(fp);
 	return 0;
 }
 
@@ -636,9 +702,10 @@ struct ByteSource {
 	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
 	uint64_t gen;                                                 /* identity of this source for the per-thread block cache (an address can be reused by the next job's source) */
 	const unsigned char *map; size_t map_len;                     /* a plain file, mapped: the body of a long FASTA record is stripped of its line ends by several threads straight from here */
+	bool pack;                                                    /* the parser threads also pack what they parsed (yakamd_pack_bases_host) */
 	bool in_memory, partial;                                      /* bytes in memory (a batch of an inflated gzip stream; map is not ours); more of the stream follows them: a record that touches their end is not finished */
 	static uint64_t next_gen() { static uint64_t g = 0; return __atomic_add_fetch(&g, 1, __ATOMIC_RELAXED); }
-	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0), in_memory(false), partial(false) {}
+	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0), pack(false), in_memory(false), partial(false) {}
 	~ByteSource() { if (map && !in_memory) munmap((void*)map, map_len); }
 	void set_memory(const unsigned char *p, size_t n, bool more_follows) { fd = -1; bgzf = false; map = p; map_len = n; size = (int64_t)n; in_memory = true; partial = more_follows; }
 	ByteSource(const ByteSource&) = delete; ByteSource &operator=(const ByteSource&) = delete;
@@ -992,7 +1059,7 @@ struct FxReader {
  * what the single reader would have produced; the next window starts where the last accepted
  * segment stopped.  A wrong guess costs time, never correctness.
  * ------------------------------------------------------------------------------------------ */
-static int64_t env_threads_window() { const char *e = getenv("YAKAMD_PARSE_WINDOW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)1 << 30; }
+static int64_t env_threads_window() { const char *e = getenv("YAKAMD_PARSE_WINDOW"); return e && atoll(e) > 0 ? atoll(e) : 0; }
 static int parse_threads(int n_thread)
 {
 	const char *e = getenv("YAKAMD_PARSE_THREADS");
@@ -1023,7 +1090,84 @@ template <class T> struct PinAlloc {
 typedef std::vector<char, PinAlloc<char> > PinVec;
 } /* extern "C++" */
 
+/* ---- the base image packed on the host (include/yak_amd.h: yakamd_feed_packed_dev's format): 2-bit codes, 16 bases per 32-bit word, and one
+ * validity bit per base, by the table the kernels use (seq_nt4_table, reference yak.h / count.c:28-31: ACGT, acgt, U, u and the bytes 0..3 are
+ * bases, everything else -- N, the '\n' between two records -- is not) ---- */
+static const uint8_t yk_nt4[256] = {
+#define R4(v) v, v, v, v
+#define R16(v) R4(v), R4(v), R4(v), R4(v)
+	0, 1, 2, 3, R4(4), R4(4), R4(4),
+	R16(4), R16(4), R16(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
+	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
+	R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4)
+#undef R16
+#undef R4
+};
+static inline void pack32_scalar(const uint8_t *a, int64_t left, uint32_t *c0, uint32_t *c1, uint32_t *v)
+{
+	uint32_t x0 = 0, x1 = 0, m = 0;
+	const int n = left < 32 ? (int)left : 32;
+	for (int j = 0; j < n; ++j) {
+		const uint32_t c = yk_nt4[a[j]];
+		if (c < 4) { m |= 1u << j; if (j < 16) x0 |= c << (2 * j); else x1 |= c << (2 * (j - 16)); }
+	}
+	*c0 = x0; *c1 = x1; *v = m;
+}
+/* 32 bases per step with AVX2 + BMI2: A / C / G / T of either case by four compares (the validity word is their movemask), the code of such a
+ * byte is bits 1..2 of it with bit 1 flipped when bit 2 is set (A 0x41 -> 0, C 0x43 -> 1, G 0x47 -> 2, T 0x54 -> 3), gathered by pext; a group
+ * that holds one of the rare other bases (U, u, a raw 0..3) goes through the table */
+__attribute__((target("avx2,bmi2")))
+static void pack_words_avx2(const uint8_t *a, int64_t n_words, uint32_t *codes, uint32_t *valid)
+{
+	const __m256i up = _mm256_set1_epi8((char)0xDF), A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'), G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T'),
+	              U = _mm256_set1_epi8('U'), four = _mm256_set1_epi8(4), b4 = _mm256_set1_epi8(0x04);
+	for (int64_t w = 0; w < n_words; ++w, a += 32) {
+		const __m256i x = _mm256_loadu_si256((const __m256i*)a), u = _mm256_and_si256(x, up);
+		const __m256i acgt = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, A), _mm256_cmpeq_epi8(u, C)), _mm256_or_si256(_mm256_cmpeq_epi8(u, G), _mm256_cmpeq_epi8(u, T)));
+		const __m256i rare = _mm256_or_si256(_mm256_cmpeq_epi8(u, U), _mm256_cmpeq_epi8(_mm256_min_epu8(x, four), x) /* x <= 4 */);
+		const __m256i rare4 = _mm256_andnot_si256(_mm256_cmpeq_epi8(x, four), rare);   /* x < 4, or U / u */
+		if (_mm256_movemask_epi8(rare4)) { pack32_scalar(a, 32, &codes[2 * w], &codes[2 * w + 1], &valid[w]); continue; }
+		const uint32_t m = (uint32_t)_mm256_movemask_epi8(acgt);
+		const __m256i y = _mm256_xor_si256(x, _mm256_srli_epi16(_mm256_and_si256(x, b4), 1));
+		uint64_t q[4];
+		_mm256_storeu_si256((__m256i*)q, y);
+		const uint64_t sel = 0x0606060606060606ull;
+		const uint64_t code = _pext_u64(q[0], sel) | _pext_u64(q[1], sel) << 16 | _pext_u64(q[2], sel) << 32 | _pext_u64(q[3], sel) << 48;
+		const uint64_t keep = _pdep_u64((uint64_t)m, 0x5555555555555555ull) * 3;
+		const uint64_t cv = code & keep;
+		codes[2 * w] = (uint32_t)cv; codes[2 * w + 1] = (uint32_t)(cv >> 32); valid[w] = m;
+	}
+}
+/* n bases -> (n + 31) / 32 words of validity bits and twice as many of codes; the bits behind base n - 1 in the last words are zero */
+static void pack_into(const uint8_t *a, int64_t n, uint32_t *codes, uint32_t *valid)
+{
+	const int64_t nw = (n + 31) / 32, whole = n / 32;
+	static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("YAKAMD_NO_AVX2");
+	int64_t w = 0;
+	if (wide) { pack_words_avx2(a, whole, codes, valid); w = whole; }
+	for (; w < nw; ++w) pack32_scalar(a + 32 * w, n - 32 * w, &codes[2 * w], &codes[2 * w + 1], &valid[w]);
+}
+void yakamd_pack_bases_host(const void *ascii, int64_t n, void *h_packed)
+{
+	if (n <= 0) return;
+	const int64_t nw = (n + 31) / 32;
+	uint32_t *codes = (uint32_t*)h_packed, *valid = (uint32_t*)((char*)h_packed + ((nw * 8 + 15) & ~(int64_t)15));
+	pack_into((const uint8_t*)ascii, n, codes, valid);
+	const int64_t pad = (((nw * 8 + 15) & ~(int64_t)15) - nw * 8) / 4;
+	for (int64_t i = 0; i < pad; ++i) codes[2 * nw + i] = 0;
+}
+
 struct ParSeg { int64_t start, end, stop; PinVec img; int64_t n_seq, sum_len; bool hard_end; };
+/* a window's accepted segments as ONE packed image: every segment's image is taken to start at a multiple of 32 stream positions (the up to 31
+ * positions in between are no bases -- stream positions only order the k-mers, a few of them unused change nothing), so the threads pack their
+ * own segments straight to their places and the device gets one copy and one feed per window instead of one per segment */
+struct WinPack { PinVec packed; int64_t n_pos, n_seq; WinPack() : n_pos(0), n_seq(0) {} };
+/* what takes the parsed pieces, in stream order: the base image (sequences, each followed by '\n'), its bytes, its sequences, and -- when the
+ * source asked for it (ByteSource::pack) -- no ASCII image but the packed image of a whole window (n = its stream positions), else 0 */
+typedef std::function<bool(const char*, size_t, int64_t, const char*)> ImgSink;
 
 static int64_t guess_record_start(const ByteSource *src, int64_t from, int64_t limit)
 {
@@ -1071,7 +1215,7 @@ static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, i
 
 /* one window: cut [pos, wend) into segments, parse them on n_thr threads, accept the verified prefix.  Returns the
  * number of accepted segments; *next = where the following window starts; *done = the stream has ended */
-static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done)
+static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done, WinPack *wp)
 {
 	const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
 	int n_seg = 0;
@@ -1099,6 +1243,27 @@ static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t
 		if (seg[i].hard_end) { *done = true; break; }
 	}
 	*next = at;
+	if (fd->pack) {                                              /* the accepted segments, packed by as many threads to their places in one image */
+		std::vector<int64_t> at_pos(n_ok + 1, 0);
+		wp->n_seq = 0;
+		for (int i = 0; i < n_ok; ++i) { at_pos[i + 1] = at_pos[i] + (((int64_t)seg[i].img.size() + 31) & ~(int64_t)31); wp->n_seq += seg[i].n_seq; }
+		wp->n_pos = at_pos[n_ok];
+		wp->packed.clear();
+		if (wp->n_pos > 0) {
+			wp->packed.resize((size_t)yakamd_packed_bytes(wp->n_pos));
+			uint32_t *codes = (uint32_t*)&wp->packed[0], *valid = (uint32_t*)(&wp->packed[0] + (wp->packed.size() - (size_t)(wp->n_pos / 32 * 4)));
+			auto pack_seg = [&](int i) {
+				const int64_t w0 = at_pos[i] / 32, nw = (at_pos[i + 1] - at_pos[i]) / 32, n = (int64_t)seg[i].img.size();
+				if (n > 0) pack_into((const uint8_t*)seg[i].img.data(), n, codes + 2 * w0, valid + w0);
+				(void)nw;
+			};
+			th.clear();
+			for (int i = 1; i < n_ok; ++i) th.emplace_back(pack_seg, i);
+			if (n_ok > 0) pack_seg(0);
+			for (auto &t : th) t.join();
+			for (char *p = (char*)(codes + 2 * (wp->n_pos / 32)); p < (char*)valid; ++p) *p = 0;   /* (the gap that aligns the validity words) */
+		}
+	}
 	return n_ok;
 }
 
@@ -1126,30 +1291,37 @@ static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64
 /* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
  * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
  * threads already work on the next one. */
-static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink, int64_t *stopped_at = 0, bool *stream_ended = 0)
+static double g_t_parse_windows = 0, g_t_first_window = 0;    /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one */
+static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const ImgSink &sink, int64_t *stopped_at = 0, bool *stream_ended = 0)
 {
 	if (stopped_at) *stopped_at = 0;
 	if (stream_ended) *stream_ended = false;
 	const int64_t size = fd->size;
-	const int64_t WIN = (int64_t)env_threads_window();
+	/* the windows grow from 128 MiB to 1 GiB: the device has its first piece after an eighth of the time a full window takes to parse */
+	const int64_t win_set = env_threads_window();
+	int n_win = 0;
+	auto next_win = [&]() { const int64_t w = win_set ? win_set : std::min<int64_t>((int64_t)1 << 30, (int64_t)128 << 20 << std::min(n_win, 3)); ++n_win; return w; };
+	int64_t WIN = next_win();
 	std::vector<ParSeg> seg[2] = { std::vector<ParSeg>(n_thr), std::vector<ParSeg>(n_thr) };
+	WinPack wpk[2];
 	int64_t pos = 0, next[2] = { 0, 0 }, from[2] = { 0, 0 };
 	bool done[2] = { false, false };
 	int n_ok[2] = { 0, 0 }, cur = 0;
 	if (size <= 0) return true;
-	n_ok[0] = parse_window(fd, size, 0, WIN, min_len, n_thr, seg[0], &next[0], &done[0]);
+	{ const double t = yk_realtime(); n_ok[0] = parse_window(fd, size, 0, WIN, min_len, n_thr, seg[0], &next[0], &done[0], &wpk[0]); g_t_first_window = yk_realtime() - t; g_t_parse_windows += g_t_first_window; }
 	for (;;) {
 		pos = next[cur];
 		if (stopped_at) *stopped_at = pos;
 		if (stream_ended) *stream_ended = done[cur];
 		/* (a partial source: a window that gets nowhere stands at a record that wants the bytes still to come) */
 		const bool more = !done[cur] && pos < size && !(fd->partial && pos == from[cur]);
-		if (getenv("YAKAMD_GZ_DEBUG")) fprintf(stderr, "[gz] window from %ld: n_ok %d next %ld done %d size %ld more %d\n", (long)from[cur], n_ok[cur], (long)pos, (int)done[cur], (long)size, (int)more);
 		std::thread ahead;
 		from[cur ^ 1] = pos;
-		if (more) ahead = std::thread([&, pos]() { n_ok[cur ^ 1] = parse_window(fd, size, pos, WIN, min_len, n_thr, seg[cur ^ 1], &next[cur ^ 1], &done[cur ^ 1]); });
+		WIN = next_win();
+		if (more) ahead = std::thread([&, pos, WIN]() { const double t = yk_realtime(); n_ok[cur ^ 1] = parse_window(fd, size, pos, WIN, min_len, n_thr, seg[cur ^ 1], &next[cur ^ 1], &done[cur ^ 1], &wpk[cur ^ 1]); g_t_parse_windows += yk_realtime() - t; });
 		bool ok = true;
-		for (int i = 0; i < n_ok[cur] && ok; ++i) ok = sink(seg[cur][i].img.data(), seg[cur][i].img.size(), seg[cur][i].n_seq);
+		if (fd->pack) { if (n_ok[cur] > 0) ok = sink(0, (size_t)wpk[cur].n_pos, wpk[cur].n_seq, wpk[cur].n_pos ? wpk[cur].packed.data() : 0); }
+		else for (int i = 0; i < n_ok[cur] && ok; ++i) ok = sink(seg[cur][i].img.data(), seg[cur][i].img.size(), seg[cur][i].n_seq, 0);
 		if (ahead.joinable()) ahead.join();
 		if (!ok) return false;
 		if (!more) break;
@@ -1164,9 +1336,10 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const s
 static bool gz_source(const char *fn, const FxReader &fx, int n_thr, pgz::Reader *z)
 {
 	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_PGZ")) return false;
+	if (getenv("YAKAMD_GZ_CHUNK")) pgz::tune().chunk = (size_t)atoll(getenv("YAKAMD_GZ_CHUNK"));
 	return z->open(fn, n_thr);
 }
-static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const std::function<bool(const char*, size_t, int64_t)> &sink)
+static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const ImgSink &sink, bool pack = false)
 {
 	size_t keep = 0;
 	for (bool last = false; !last; ) {
@@ -1174,9 +1347,9 @@ static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const std::function
 		if (!z->next(keep, &p, &n, &last)) { yk_set_error("%s", z->why.c_str()); return false; }
 		ByteSource src;
 		src.set_memory(p, n, !last);
+		src.pack = pack;
 		int64_t stop = 0; bool ended = false;
 		if (!parse_parallel(&src, min_len, n_thr, sink, &stop, &ended)) return false;
-		if (getenv("YAKAMD_GZ_DEBUG")) fprintf(stderr, "[gz] batch %zu bytes last=%d stop=%ld ended=%d\n", n, (int)last, (long)stop, (int)ended);
 		if (ended) break;                                         /* a truncated record ended the stream (count.c:93) */
 		keep = (size_t)stop;
 	}
@@ -1529,7 +1702,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		}
 		return ok;
 	};
-	auto take_piece = [&](const char *img, size_t n, int64_t ns) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
+	auto take_piece = [&](const char *img, size_t n, int64_t ns, const char*) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
 	bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
@@ -1545,9 +1718,9 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 				if (l >= opt->k) { piece.insert(piece.end(), fx.seq.begin(), fx.seq.end()); piece.push_back('\n'); }
 			}
 			if (l >= opt->k) ++ns;
-			if (piece.size() >= ((size_t)1 << 24)) { if (!take_piece(piece.data(), piece.size(), ns)) break; piece.clear(); ns = 0; }
+			if (piece.size() >= ((size_t)1 << 24)) { if (!take_piece(piece.data(), piece.size(), ns, 0)) break; piece.clear(); ns = 0; }
 		}
-		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns);
+		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns, 0);
 	}
 	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
 	wait_worker();
@@ -1737,15 +1910,24 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	uint64_t t0 = 0;
 	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
 	if (par_size >= 0) {
-		const std::function<bool(const char*, size_t, int64_t)> sink = [&](const char *img, size_t img_n, int64_t ns) {
-			if (opener.joinable()) opener.join();
+		const bool pack = !getenv("YAKAMD_NO_HOST_PACK");          /* the stream crosses the bus at 0.375 B per base, packed by the threads that parsed it */
+		psrc.pack = pack;
+		double t_sink = 0, t_open_wait = 0;
+		g_t_parse_windows = 0;
+		const ImgSink sink = [&](const char *img, size_t img_n, int64_t ns, const char *packed) {
+			const double ts0 = yk_realtime();
+			if (opener.joinable()) { opener.join(); t_open_wait = yk_realtime() - ts0; }
 			if (!ok) return false;
-			bool good = img_n == 0 || yakamd_feed_bases_host(h, img, (int64_t)img_n, t0) == 0;
+			bool good = img_n == 0 || (pack ? yakamd_feed_packed_host(h, packed, (int64_t)img_n, t0) : yakamd_feed_bases_host(h, img, (int64_t)img_n, t0)) == 0;
+			t_sink += yk_realtime() - ts0;
 			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
 			return good;
 		};
-		const bool parsed = use_gz ? parse_gz(&gz, opt->k, n_thr, sink) : parse_parallel(&psrc, opt->k, n_thr, sink);
+		const double tp0 = yk_realtime();
+		const bool parsed = use_gz ? parse_gz(&gz, opt->k, n_thr, sink, pack) : parse_parallel(&psrc, opt->k, n_thr, sink);
+		if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] reader: %.3f s from the first window to the last piece fed; the windows took %.3f s to parse (the first %.3f s), the feeds %.3f s (%.3f s of it waiting for the new table)\n",
+		                                      yk_realtime() - tp0, g_t_parse_windows, g_t_first_window, t_sink, t_open_wait);
 		if (opener.joinable()) opener.join();
 		if (h == 0) { if (psrc_fd >= 0) ::close(psrc_fd); fx.close_file(); return 0; }
 		ok = ok && parsed;
@@ -1774,6 +1956,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table\n", "yak_count",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot);
+	if (getenv("YAKAMD_VERBOSE") && h) { (void)hipSetDevice(yk_ctx_device(((yak_ch_ext*)h)->ctx)); yk_pool_report("the pass"); }
 	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { if (!h0) yak_ch_destroy(h); return 0; }
@@ -1811,7 +1994,7 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 		const bool plain = parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd);
 		if (plain || gz_source(fn, fx, n_thr, &gz)) {
 			size_t total = 0;
-			const std::function<bool(const char*, size_t, int64_t)> sink = [&](const char *part, size_t part_n, int64_t) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
+			const ImgSink sink = [&](const char *part, size_t part_n, int64_t, const char*) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
 			if (plain) parse_parallel(&psrc, min_len, n_thr, sink);
 			else if (!parse_gz(&gz, min_len, n_thr, sink)) { fx.close_file(); return -1; }
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
@@ -1830,6 +2013,34 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 	}
 	if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s in the reader loop\n", yk_realtime() - t_);
 	fx.close_file();
+	*out = (char*)malloc(img.size() + 1);
+	memcpy(*out, img.data(), img.size());
+	return (int64_t)img.size();
+}
+
+/* host-only hook for tests: what yak_count() hands to the device when its parser threads pack (one packed image per window), unpacked again --
+ * 'A' 'C' 'G' 'T' for a base, '\n' for a position that is none (N, a record's end, the positions that pad a segment to a multiple of 32) */
+int64_t yakamd_host_image_packed(const char *fn, int min_len, char **out)
+{
+	FxReader fx;
+	*out = 0;
+	if (!fx.open_file(fn)) return -1;
+	const int n_thr = parse_threads(1);
+	std::vector<char> img;
+	ByteSource psrc; int psrc_fd = -1;
+	pgz::Reader gz;
+	const ImgSink sink = [&](const char*, size_t n, int64_t, const char *packed) {
+		const uint32_t *codes = (const uint32_t*)packed, *valid = (const uint32_t*)(packed + (yakamd_packed_bytes((int64_t)n) - (int64_t)(n + 31) / 32 * 4));
+		for (size_t j = 0; j < n; ++j) img.push_back((valid[j >> 5] >> (j & 31) & 1) ? "ACGT"[codes[j >> 4] >> (2 * (j & 15)) & 3] : '\n');
+		return true;
+	};
+	bool ok = true;
+	if (parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd)) { psrc.pack = true; ok = parse_parallel(&psrc, min_len, n_thr, sink); }
+	else if (gz_source(fn, fx, n_thr, &gz)) ok = parse_gz(&gz, min_len, n_thr, sink, true);
+	else ok = false;
+	if (psrc_fd >= 0) ::close(psrc_fd);
+	fx.close_file();
+	if (!ok) return -1;
 	*out = (char*)malloc(img.size() + 1);
 	memcpy(*out, img.data(), img.size());
 	return (int64_t)img.size();
