@@ -53,6 +53,11 @@ int yakamd_feed_packed_dev(yak_ch_t *h, const void *d_codes, const void *d_valid
 int64_t yakamd_packed_bytes(int64_t n_bases);
 void yakamd_pack_bases_host(const void *ascii, int64_t n_bases, void *h_packed);
 int yakamd_feed_packed_host(yak_ch_t *h, const void *h_packed, int64_t n_bases, uint64_t t0);
+/* ... or as pieces, each a whole number of 32-position words (n_words[i] validity words at valid[i], twice as many code words at codes[i]; a
+ * piece whose bases end inside its last word leaves the rest of it invalid): laid one behind the other on the device, fed as ONE image of
+ * 32 * sum(n_words) stream positions.  yak_count() hands over a window of its parser's segments this way (stream positions only order the
+ * k-mers: the up to 31 unused ones behind a segment change nothing) */
+int yakamd_feed_packed_pieces_host(yak_ch_t *h, int n_pieces, const void *const *codes, const void *const *valid, const int64_t *n_words, uint64_t t0);
 /* device-side packer: ASCII image -> d_codes ((n + 31) / 32 * 8 bytes) and d_valid ((n + 31) / 32 * 4 bytes); `stream` = a hipStream_t or 0 */
 int yakamd_pack_bases_dev(const void *d_ascii, int64_t n, void *d_codes, void *d_valid, void *stream);
 /* already hashed k-mers (yak_hash64 output) with their stream positions t0 + t[i], t[i] < t_span;

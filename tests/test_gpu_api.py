@@ -507,7 +507,11 @@ def test_packed_image_feed_equals_ascii_feed(k, bf, ya, oracle, synth):
     cuts = [0, img.index(b"\n", n // 3) + 1, img.index(b"\n", 2 * n // 3) + 1, n]
     th.count_pass_packed_host(1, [(img[a:b], a) for a, b in zip(cuts, cuts[1:])])
     assert th.dump_bytes() == ta.dump_bytes() and th.tot == ta.tot
-    tp.close(); ta.close(); th.close(); O.yko_ch_destroy(o)
+    # ... and the way yak_count() hands a window over: the pieces (an empty one among them) in one feed, each ending at a multiple of 32 positions
+    tw = ya.Table(k, 10, 4, bf)
+    tw.count_pass_packed_host(1, [(img[a:b], 0) for a, b in zip(cuts, cuts[1:])][:1] + [(b"", 0)] + [(img[a:b], 0) for a, b in zip(cuts, cuts[1:])][1:], as_one=True)
+    assert tw.dump_bytes() == ta.dump_bytes() and tw.tot == ta.tot
+    tp.close(); ta.close(); th.close(); tw.close(); O.yko_ch_destroy(o)
     for d in (d_a, d_c, d_v):
         L.yakamd_dev_free(d)
 

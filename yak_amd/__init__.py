@@ -25,7 +25,7 @@ YAK_H_SYMBOLS = [
 ]
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
-    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_packed_bytes", "yakamd_pack_bases_host", "yakamd_feed_packed_host", "yakamd_feed_hashed_dev",
+    "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_packed_bytes", "yakamd_pack_bases_host", "yakamd_feed_packed_host", "yakamd_feed_packed_pieces_host", "yakamd_feed_hashed_dev",
     "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
     "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
@@ -108,6 +108,8 @@ def lib():
     L.yakamd_pack_bases_host.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.yakamd_feed_packed_host.restype = C.c_int
     L.yakamd_feed_packed_host.argtypes = [P(ChT), C.c_void_p, C.c_int64, C.c_uint64]
+    L.yakamd_feed_packed_pieces_host.restype = C.c_int
+    L.yakamd_feed_packed_pieces_host.argtypes = [P(ChT), C.c_int, P(C.c_void_p), P(C.c_void_p), P(C.c_int64), C.c_uint64]
     L.yakamd_feed_packed_dev.restype = C.c_int
     L.yakamd_feed_packed_dev.argtypes = [P(ChT), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64]
     L.yakamd_pack_bases_dev.restype = C.c_int
@@ -230,10 +232,21 @@ class Table:
         self.h.contents.tot += n_ins
         return n_ins
 
-    def count_pass_packed_host(self, create_new, pieces):
-        """one pass over pieces of the stream, each packed on the host (pack_bases_host) and fed from host memory: pieces = iterable of (ascii bytes, t0)"""
+    def count_pass_packed_host(self, create_new, pieces, as_one=False):
+        """one pass over pieces of the stream, each packed on the host (pack_bases_host) and fed from host memory: pieces = iterable of (ascii bytes, t0);
+        as_one: all of them in ONE feed (yakamd_feed_packed_pieces_host), every piece taken to end at a multiple of 32 positions"""
         if self.L.yakamd_pass_begin(self.h, create_new) != 0:
             raise RuntimeError(_err())
+        if as_one:
+            pieces = list(pieces)
+            pk = [pack_bases_host(buf) for buf, _ in pieces]
+            nw = [(len(buf) + 31) // 32 for buf, _ in pieces]
+            keep = [C.create_string_buffer(x, len(x)) for x in pk]
+            codes = (C.c_void_p * len(pk))(*[C.addressof(k) for k in keep])
+            valid = (C.c_void_p * len(pk))(*[C.addressof(k) + ((8 * w + 15) & ~15) for k, w in zip(keep, nw)])
+            if self.L.yakamd_feed_packed_pieces_host(self.h, len(pk), codes, valid, (C.c_int64 * len(pk))(*nw), pieces[0][1] if pieces else 0) != 0:
+                raise RuntimeError(_err())
+            pieces = ()
         for buf, t0 in pieces:
             pk = pack_bases_host(buf)
             if self.L.yakamd_feed_packed_host(self.h, pk, len(buf), t0) != 0:

@@ -1021,6 +1021,32 @@ extern "C" int yakamd_feed_packed_host(yak_ch_t *h, const void *h_packed, int64_
 	return yakamd_feed_packed_dev(h, c->d_stage, c->d_stage + valid_at, n_bases, t0);
 }
 
+/* packed pieces of the stream, each a whole number of 32-position words (its code words and its validity words apart), laid one behind the
+ * other on the device -- two copies per piece -- and fed as one image: what yak_count() does with the segments its parser threads packed */
+extern "C" int yakamd_feed_packed_pieces_host(yak_ch_t *h, int n_pieces, const void *const *codes, const void *const *valid, const int64_t *n_words, uint64_t t0)
+{
+	yakamd_ctx *c = ctx_of(h);
+	if (!c || !c->in_pass) return fail("feed outside a pass");
+	int64_t nw = 0;
+	for (int i = 0; i < n_pieces; ++i) { if (n_words[i] < 0) return fail("packed piece of negative length"); nw += n_words[i]; }
+	if (nw == 0) return 0;
+	HIPCK(hipSetDevice(c->dev));
+	const int64_t n_bases = nw * 32, need = yakamd_packed_bytes(n_bases), valid_at = need - nw * 4;
+	if (need > c->stage_cap) {
+		dfree(c->d_stage);
+		c->stage_cap = need + (need >> 3) + 4096;
+		if (dmalloc(&c->d_stage, (size_t)c->stage_cap)) { c->stage_cap = 0; return -1; }
+	}
+	int64_t w = 0;
+	for (int i = 0; i < n_pieces; ++i) {
+		if (n_words[i] == 0) continue;
+		HIPCK(hipMemcpyAsync(c->d_stage + w * 8, codes[i], (size_t)n_words[i] * 8, hipMemcpyHostToDevice, c->st));
+		HIPCK(hipMemcpyAsync(c->d_stage + valid_at + w * 4, valid[i], (size_t)n_words[i] * 4, hipMemcpyHostToDevice, c->st));
+		w += n_words[i];
+	}
+	return yakamd_feed_packed_dev(h, c->d_stage, c->d_stage + valid_at, n_bases, t0);
+}
+
 extern "C" int yakamd_feed_hashed_dev(yak_ch_t *h, const void *d_hash, const void *d_t, int64_t n, uint64_t t0, uint64_t t_span)
 {
 	yakamd_ctx *c = ctx_of(h);

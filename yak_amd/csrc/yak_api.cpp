@@ -1167,14 +1167,17 @@ void yakamd_pack_bases_host(const void *ascii, int64_t n, void *h_packed)
 	for (int64_t i = 0; i < pad; ++i) codes[2 * nw + i] = 0;
 }
 
-struct ParSeg { int64_t start, end, stop; PinVec img; int64_t n_seq, sum_len; bool hard_end; };
-/* a window's accepted segments as ONE packed image: every segment's image is taken to start at a multiple of 32 stream positions (the up to 31
- * positions in between are no bases -- stream positions only order the k-mers, a few of them unused change nothing), so the threads pack their
- * own segments straight to their places and the device gets one copy and one feed per window instead of one per segment */
-struct WinPack { PinVec packed; int64_t n_pos, n_seq; WinPack() : n_pos(0), n_seq(0) {} };
+typedef std::vector<uint32_t, PinAlloc<uint32_t> > PinWords;
+/* a parsed segment: its base image -- or, when the source asks for packed pieces, that image packed as it grows (the ASCII bytes then only pass
+ * through a buffer of ~1 MB that stays in the thread's cache): code words, validity words, 32 stream positions per validity word.  The image
+ * of a segment is taken to end at a multiple of 32 positions: the up to 31 positions behind it are no bases (stream positions only order the
+ * k-mers; a few of them unused change nothing), so a window's segments can be laid one behind the other word by word */
+struct ParSeg { int64_t start, end, stop; PinVec img; PinWords codes, valid; int64_t n_seq, sum_len; bool hard_end; };
+/* the accepted segments of a window as packed pieces, in stream order (yakamd_feed_packed_pieces_host lays them out on the device: one feed) */
+struct WinPack { std::vector<const void*> codes, valid; std::vector<int64_t> n_words; int64_t n_pos, n_seq; WinPack() : n_pos(0), n_seq(0) {} };
 /* what takes the parsed pieces, in stream order: the base image (sequences, each followed by '\n'), its bytes, its sequences, and -- when the
- * source asked for it (ByteSource::pack) -- no ASCII image but the packed image of a whole window (n = its stream positions), else 0 */
-typedef std::function<bool(const char*, size_t, int64_t, const char*)> ImgSink;
+ * source asked for it (ByteSource::pack) -- no ASCII image but the packed pieces of a whole window (n = its stream positions), else 0 */
+typedef std::function<bool(const char*, size_t, int64_t, const WinPack*)> ImgSink;
 
 static int64_t guess_record_start(const ByteSource *src, int64_t from, int64_t limit)
 {
@@ -1202,10 +1205,23 @@ static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, i
 	FxReader r;
 	r.open_at(src, sg->start);
 	sg->n_seq = sg->sum_len = 0; sg->hard_end = false;
-	sg->img.clear();
-	if (sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
+	sg->img.clear(); sg->codes.clear(); sg->valid.clear();
+	const bool pack = src->pack;
+	if (!pack && sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
+	if (pack) { const size_t w = (size_t)(sg->end - sg->start) / 32 + 64; if (sg->valid.capacity() < w) { sg->valid.reserve(w); sg->codes.reserve(2 * w); } }
+	auto flush = [&](bool all) {                                  /* whole words of the staged bases go to the packed image; at the end the rest too, padded */
+		const size_t n = all ? sg->img.size() : sg->img.size() & ~(size_t)31;
+		if (n == 0) return;
+		const size_t w0 = sg->valid.size(), nw = (n + 31) / 32;
+		sg->valid.resize(w0 + nw); sg->codes.resize(2 * (w0 + nw));
+		pack_into((const uint8_t*)sg->img.data(), (int64_t)n, &sg->codes[2 * w0], &sg->valid[w0]);
+		const size_t rest = sg->img.size() - n;
+		if (rest) memmove(&sg->img[0], &sg->img[n], rest);
+		sg->img.resize(rest);
+	};
 	int64_t l;
 	for (;;) {
+		if (pack && sg->img.size() >= ((size_t)1 << 20)) flush(false);
 		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = !src->partial; break; }
 		const int64_t mp = r.marker_pos();
 		if (mp >= sg->end) { sg->stop = mp; break; }
@@ -1218,6 +1234,7 @@ static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, i
 		if (l >= min_len) { ++sg->n_seq; sg->sum_len += l; }
 	}
 	r.close_at();
+	if (pack) flush(true);
 }
 
 /* one window: cut [pos, wend) into segments, parse them on n_thr threads, accept the verified prefix.  Returns the
@@ -1250,25 +1267,13 @@ static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t
 		if (seg[i].hard_end) { *done = true; break; }
 	}
 	*next = at;
-	if (fd->pack) {                                              /* the accepted segments, packed by as many threads to their places in one image */
-		std::vector<int64_t> at_pos(n_ok + 1, 0);
-		wp->n_seq = 0;
-		for (int i = 0; i < n_ok; ++i) { at_pos[i + 1] = at_pos[i] + (((int64_t)seg[i].img.size() + 31) & ~(int64_t)31); wp->n_seq += seg[i].n_seq; }
-		wp->n_pos = at_pos[n_ok];
-		wp->packed.clear();
-		if (wp->n_pos > 0) {
-			wp->packed.resize((size_t)yakamd_packed_bytes(wp->n_pos));
-			uint32_t *codes = (uint32_t*)&wp->packed[0], *valid = (uint32_t*)(&wp->packed[0] + (wp->packed.size() - (size_t)(wp->n_pos / 32 * 4)));
-			auto pack_seg = [&](int i) {
-				const int64_t w0 = at_pos[i] / 32, nw = (at_pos[i + 1] - at_pos[i]) / 32, n = (int64_t)seg[i].img.size();
-				if (n > 0) pack_into((const uint8_t*)seg[i].img.data(), n, codes + 2 * w0, valid + w0);
-				(void)nw;
-			};
-			th.clear();
-			for (int i = 1; i < n_ok; ++i) th.emplace_back(pack_seg, i);
-			if (n_ok > 0) pack_seg(0);
-			for (auto &t : th) t.join();
-			for (char *p = (char*)(codes + 2 * (wp->n_pos / 32)); p < (char*)valid; ++p) *p = 0;   /* (the gap that aligns the validity words) */
+	if (fd->pack) {
+		wp->codes.clear(); wp->valid.clear(); wp->n_words.clear(); wp->n_pos = wp->n_seq = 0;
+		for (int i = 0; i < n_ok; ++i) {
+			wp->n_seq += seg[i].n_seq;
+			if (seg[i].valid.empty()) continue;
+			wp->codes.push_back(seg[i].codes.data()); wp->valid.push_back(seg[i].valid.data()); wp->n_words.push_back((int64_t)seg[i].valid.size());
+			wp->n_pos += 32 * (int64_t)seg[i].valid.size();
 		}
 	}
 	return n_ok;
@@ -1345,7 +1350,7 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const I
 		WinSet &w = ring[k % NSET];
 		if (stopped_at) *stopped_at = w.next;
 		if (stream_ended) *stream_ended = w.done;
-		if (fd->pack) { if (w.n_ok > 0) ok = sink(0, (size_t)w.wp.n_pos, w.wp.n_seq, w.wp.n_pos ? w.wp.packed.data() : 0); }
+		if (fd->pack) { if (w.n_ok > 0) ok = sink(0, (size_t)w.wp.n_pos, w.wp.n_seq, &w.wp); }
 		else for (int i = 0; i < w.n_ok && ok; ++i) ok = sink(w.seg[i].img.data(), w.seg[i].img.size(), w.seg[i].n_seq, 0);
 		{ std::lock_guard<std::mutex> lk(mu); ++consumed; if (!ok) abort = true; }
 		cv.notify_all();
@@ -1727,7 +1732,7 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 		}
 		return ok;
 	};
-	auto take_piece = [&](const char *img, size_t n, int64_t ns, const char*) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
+	auto take_piece = [&](const char *img, size_t n, int64_t ns, const WinPack*) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
 	const int n_thr = parse_threads(opt->n_thread);
 	ByteSource psrc; int psrc_fd = -1;
 	bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
@@ -1941,11 +1946,12 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		psrc.pack = pack;
 		double t_sink = 0, t_open_wait = 0;
 		g_t_parse_windows = 0;
-		const ImgSink sink = [&](const char *img, size_t img_n, int64_t ns, const char *packed) {
+		const ImgSink sink = [&](const char *img, size_t img_n, int64_t ns, const WinPack *packed) {
 			const double ts0 = yk_realtime();
 			if (opener.joinable()) { opener.join(); t_open_wait = yk_realtime() - ts0; }
 			if (!ok) return false;
-			bool good = img_n == 0 || (pack ? yakamd_feed_packed_host(h, packed, (int64_t)img_n, t0) : yakamd_feed_bases_host(h, img, (int64_t)img_n, t0)) == 0;
+			bool good = img_n == 0 || (pack ? yakamd_feed_packed_pieces_host(h, (int)packed->n_words.size(), packed->codes.data(), packed->valid.data(), packed->n_words.data(), t0)
+			                                : yakamd_feed_bases_host(h, img, (int64_t)img_n, t0)) == 0;
 			t_sink += yk_realtime() - ts0;
 			t0 += img_n; n_seq_tot += ns;
 			fprintf(stderr, "[M::%s::%.3f*%.2f] processed %ld sequences\n", "yak_count", yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)ns);
@@ -2021,7 +2027,7 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 		const bool plain = parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd);
 		if (plain || gz_source(fn, fx, n_thr, &gz)) {
 			size_t total = 0;
-			const ImgSink sink = [&](const char *part, size_t part_n, int64_t, const char*) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
+			const ImgSink sink = [&](const char *part, size_t part_n, int64_t, const WinPack*) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
 			if (plain) parse_parallel(&psrc, min_len, n_thr, sink);
 			else if (!parse_gz(&gz, min_len, n_thr, sink)) { fx.close_file(); return -1; }
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
@@ -2056,9 +2062,11 @@ int64_t yakamd_host_image_packed(const char *fn, int min_len, char **out)
 	std::vector<char> img;
 	ByteSource psrc; int psrc_fd = -1;
 	pgz::Reader gz;
-	const ImgSink sink = [&](const char*, size_t n, int64_t, const char *packed) {
-		const uint32_t *codes = (const uint32_t*)packed, *valid = (const uint32_t*)(packed + (yakamd_packed_bytes((int64_t)n) - (int64_t)(n + 31) / 32 * 4));
-		for (size_t j = 0; j < n; ++j) img.push_back((valid[j >> 5] >> (j & 31) & 1) ? "ACGT"[codes[j >> 4] >> (2 * (j & 15)) & 3] : '\n');
+	const ImgSink sink = [&](const char*, size_t, int64_t, const WinPack *wp) {
+		for (size_t p = 0; p < wp->n_words.size(); ++p) {
+			const uint32_t *codes = (const uint32_t*)wp->codes[p], *valid = (const uint32_t*)wp->valid[p];
+			for (size_t j = 0; j < (size_t)wp->n_words[p] * 32; ++j) img.push_back((valid[j >> 5] >> (j & 31) & 1) ? "ACGT"[codes[j >> 4] >> (2 * (j & 15)) & 3] : '\n');
+		}
 		return true;
 	};
 	bool ok = true;
