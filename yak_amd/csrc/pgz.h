@@ -33,11 +33,11 @@
 #include <thread>
 #include <mutex>
 #include <algorithm>
-#include <time.h>
+#include <immintrin.h>
 
 namespace pgz {
 
-enum { WSIZE = 32768, LT_BITS = 11, DT_BITS = 8, LT_SIZE = (1 << LT_BITS) + 288 * 16, DT_SIZE = (1 << DT_BITS) + 32 * 128 };
+enum { WSIZE = 32768, LT_BITS = 10, DT_BITS = 8, LT_SIZE = (1 << LT_BITS) + 288 * 32, DT_SIZE = (1 << DT_BITS) + 32 * 128 };   /* (zlib closes a block every 16 K symbols: the tables are built thousands of times per 100 MB -- a first level of 2^10 entries costs half of what 2^11 does) */
 enum { E_INVALID = 0x8000, E_LINK = 0x4000, E_EOB = 0x2000, E_BASE = 0x1000 };   /* entry = value << 16 | kind | extra or sub-table bits << 8 | bits to drop */
 enum { D_OK = 0, D_ROOM = 1, D_DATA = -1, D_TRUNC = -2, D_TEXT = -3 };
 
@@ -68,15 +68,23 @@ static const uint8_t DIST_XTRA[30] = { 0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9
  * most significant bit first, so by the reversed code), longer codes through a second-level table.  kind: 0 literal/length,
  * 1 distance, 2 code lengths.  Returns 0, or -1 for the sets zlib's inflate_table() rejects: over-subscribed, or
  * incomplete (an incomplete set is allowed only as ONE code of one bit in a literal/length or distance code) */
-static int build_table(const uint8_t *lens, int n, int TB, int kind, uint32_t *tab, int cap)
+static const uint8_t *text_table();
+static inline const uint8_t *rev8()
 {
+	static uint8_t t[256]; static std::once_flag once;
+	std::call_once(once, []() { for (int i = 0; i < 256; ++i) { int r = 0; for (int b = 0; b < 8; ++b) r |= (i >> b & 1) << (7 - b); t[i] = (uint8_t)r; } });
+	return t;
+}
+static int build_table(const uint8_t *lens, int n, int TB, int kind, uint32_t *tab, int cap, bool text_only = false)
+{
+	const uint8_t *is_text = text_only ? text_table() : 0;
 	int count[16] = { 0 }, maxl = 0;
 	for (int i = 0; i < n; ++i) { ++count[lens[i]]; if (lens[i] > maxl) maxl = lens[i]; }
-	for (int i = 0; i < (1 << TB); ++i) tab[i] = E_INVALID | 1;
-	if (maxl == 0) return 0;                                   /* no code at all: every look-up is invalid (zlib allows the set) */
+	if (maxl == 0) { for (int i = 0; i < (1 << TB); ++i) tab[i] = E_INVALID | 1; return 0; }   /* no code at all: every look-up is invalid (zlib allows the set) */
 	int left = 1;
 	for (int l = 1; l <= 15; ++l) { left = (left << 1) - count[l]; if (left < 0) return -1; }
 	if (left > 0 && (kind == 2 || maxl != 1)) return -1;
+	if (left > 0) for (int i = 0; i < (1 << TB); ++i) tab[i] = E_INVALID | 1;   /* (a complete code writes every entry below) */
 	uint16_t next[16]; next[0] = 0; next[1] = 0;
 	for (int l = 1; l < 15; ++l) next[l + 1] = (uint16_t)((next[l] + count[l]) << 1);
 	uint8_t sub_bits[1 << LT_BITS];
@@ -85,8 +93,8 @@ static int build_table(const uint8_t *lens, int n, int TB, int kind, uint32_t *t
 	for (int s = 0; s < n; ++s) {
 		const int l = lens[s];
 		if (!l) continue;
-		unsigned c = next[l]++, r = 0;
-		for (int i = 0; i < l; ++i) { r = (r << 1) | (c & 1); c >>= 1; }
+		const unsigned c = next[l]++;
+		const unsigned r = (unsigned)(rev8()[c & 255] << 8 | rev8()[c >> 8]) >> (16 - l);
 		code_of[s] = (uint16_t)r;
 		if (l > TB) { uint8_t &sb = sub_bits[r & ((1u << TB) - 1)]; if (l - TB > sb) sb = (uint8_t)(l - TB); }
 	}
@@ -104,7 +112,7 @@ static int build_table(const uint8_t *lens, int n, int TB, int kind, uint32_t *t
 		uint32_t e;
 		if (kind == 2) e = (uint32_t)s << 16;
 		else if (kind == 1) e = s < 30 ? (uint32_t)DIST_BASE[s] << 16 | E_BASE | (uint32_t)DIST_XTRA[s] << 8 : (uint32_t)E_INVALID;
-		else if (s < 256) e = (uint32_t)s << 16;
+		else if (s < 256) e = is_text && !is_text[s] ? (uint32_t)E_INVALID : (uint32_t)s << 16;   /* (a searched start: a literal that is no text ends the attempt) */
 		else if (s == 256) e = E_EOB;
 		else e = s < 286 ? (uint32_t)LEN_BASE[s - 257] << 16 | E_BASE | (uint32_t)LEN_XTRA[s - 257] << 8 : (uint32_t)E_INVALID;
 		const unsigned r = code_of[s];
@@ -119,7 +127,24 @@ static int build_table(const uint8_t *lens, int n, int TB, int kind, uint32_t *t
 	return 0;
 }
 
-struct Tables { uint32_t lt[LT_SIZE], dt[DT_SIZE]; };
+/* lt: literal / length look-up; an entry of its first 2^LT_BITS that decodes a literal and finds a second whole literal code in the bits left of
+ * its index holds both (bit 8 set, the two bytes in the value, the bits of both codes to drop): sequence and quality lines are runs of literals
+ * with codes of 2..5 bits, and the look-up -> shift -> look-up chain is what bounds a table-driven decoder.  lt1: the same first level with one
+ * symbol per entry, for the last bytes of the input where every symbol must be checked against the bits that are really there */
+struct Tables { uint32_t lt[LT_SIZE], dt[DT_SIZE], lt1[1 << LT_BITS]; };
+static void pair_literals(Tables &T)
+{
+	memcpy(T.lt1, T.lt, sizeof(T.lt1));
+	for (unsigned i = 0; i < (1u << LT_BITS); ++i) {
+		const uint32_t e1 = T.lt1[i];
+		if (e1 & 0xf000) continue;
+		const unsigned l1 = e1 & 255;
+		if (l1 >= LT_BITS) continue;
+		const uint32_t e2 = T.lt1[i >> l1];
+		if ((e2 & 0xf000) || (e2 & 255) > LT_BITS - l1) continue;
+		T.lt[i] = ((e1 >> 16 & 255) | (e2 >> 16 & 255) << 8) << 16 | 0x100 | (l1 + (e2 & 255));
+	}
+}
 
 static const Tables &fixed_tables()
 {
@@ -132,6 +157,7 @@ static const Tables &fixed_tables()
 		build_table(l, 288, LT_BITS, 0, T->lt, LT_SIZE);
 		for (int i = 0; i < 32; ++i) l[i] = 5;
 		build_table(l, 32, DT_BITS, 1, T->dt, DT_SIZE);
+		pair_literals(*T);
 	});
 	return *T;
 }
@@ -139,7 +165,7 @@ static const Tables &fixed_tables()
 /* the header of a dynamic block behind its three type bits (RFC 1951 3.2.7), with zlib's checks (inflate.c: "too many length or distance
  * symbols", "invalid code lengths set", "invalid bit length repeat", "missing end-of-block", "invalid literal/lengths set", "invalid
  * distances set") */
-static int read_dynamic(BitIn &in, Tables &T)
+static int read_dynamic(BitIn &in, Tables &T, bool text_only = false)
 {
 	static const uint8_t order[19] = { 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 };
 	in.refill();
@@ -170,8 +196,9 @@ static int read_dynamic(BitIn &in, Tables &T)
 		if (in.bc < 0) return D_TRUNC;
 	}
 	if (lens[256] == 0) return D_DATA;
-	if (build_table(lens, hlit, LT_BITS, 0, T.lt, LT_SIZE) != 0) return D_DATA;
+	if (build_table(lens, hlit, LT_BITS, 0, T.lt, LT_SIZE, text_only) != 0) return D_DATA;
 	if (build_table(lens + hlit, hdist, DT_BITS, 1, T.dt, DT_SIZE) != 0) return D_DATA;
+	pair_literals(T);
 	return D_OK;
 }
 
@@ -183,21 +210,34 @@ static const uint8_t *text_table()
 }
 
 /* the symbols of one Huffman-coded block up to its end-of-block.  out[-hist .. at) is what a distance may reach; D_ROOM: `at` came
- * within 258 of `cap`, call again with more room (the stream stands between two symbols) */
-template <class T, bool TEXT>
-static int decode_symbols(BitIn &in, const Tables &tb, T *out, size_t &at, size_t cap, size_t hist)
+ * within 272 of `cap`, call again with more room (the stream stands between two symbols).
+ * decode_tail: one symbol per step, each checked against the bits the input really holds -- the last 16 bytes of the input.
+ * decode_symbols: while more input than that lies ahead a refill always yields 56 true bits: up to three look-ups of literals (each one or
+ * two of them) per refill, no checks; a match is copied eight bytes at a time when its distance allows (it may write up to 7 bytes past its
+ * end: the room is there) */
+template <class T> static inline void copy_match(T *q, size_t dist, unsigned len)
 {
-	const uint8_t *is_text = text_table();
+	const T *sp = q - dist;
+	if (dist * sizeof(T) >= 8) {
+		T *const qe = q + len;
+		do { memcpy(q, sp, 8); q += 8 / sizeof(T); sp += 8 / sizeof(T); } while (q < qe);
+	} else if (dist == 1) {
+		const T v = *sp;
+		for (unsigned i = 0; i < len; ++i) q[i] = v;
+	} else for (unsigned i = 0; i < len; ++i) q[i] = sp[i];
+}
+template <class T>
+static int decode_tail(BitIn &in, const Tables &tb, T *out, size_t &at, size_t cap, size_t hist)
+{
 	size_t o = at;
 	for (;;) {
-		if (o + 258 > cap) { at = o; return D_ROOM; }
+		if (o + 272 > cap) { at = o; return D_ROOM; }
 		in.refill();
-		uint32_t e = tb.lt[in.bb & ((1u << LT_BITS) - 1)];
+		uint32_t e = tb.lt1[in.bb & ((1u << LT_BITS) - 1)];
 		if (e & E_LINK) { in.drop(LT_BITS); e = tb.lt[(e >> 16) + (in.bb & ((1u << ((e >> 8) & 15)) - 1))]; }
 		in.drop((int)(e & 255));
-		if ((e & 0xf000) == 0) {                                 /* a literal */
+		if ((e & 0xf000) == 0) {
 			if (in.bc < 0) { at = o; return D_TRUNC; }
-			if (TEXT && !is_text[e >> 16]) { at = o; return D_TEXT; }
 			out[o++] = (T)(e >> 16);
 			continue;
 		}
@@ -215,11 +255,114 @@ static int decode_symbols(BitIn &in, const Tables &tb, T *out, size_t &at, size_
 		in.drop((int)dx);
 		if (in.bc < 0) { at = o; return D_TRUNC; }
 		if (dist > o + hist) { at = o; return D_DATA; }           /* zlib: "invalid distance too far back" */
-		T *q = out + o; const T *s = q - dist;
-		if (dist >= len) memcpy(q, s, len * sizeof(T));
-		else for (unsigned i = 0; i < len; ++i) q[i] = s[i];
+		copy_match(out + o, dist, len);
 		o += len;
 	}
+}
+template <class T> static inline void put_literals(T *q, uint32_t e)
+{
+	if (sizeof(T) == 1) { const uint16_t v = (uint16_t)(e >> 16); memcpy(q, &v, 2); }   /* (the second byte is only kept when the entry holds two) */
+	else { q[0] = (T)(e >> 16 & 255); q[1] = (T)(e >> 24); }
+}
+template <class T>
+static int decode_symbols(BitIn &in, const Tables &tb, T *out, size_t &at, size_t cap, size_t hist)
+{
+	const uint32_t LM = (1u << LT_BITS) - 1;
+	size_t o = at;
+	for (;;) {
+		if (o + 272 > cap) { at = o; return D_ROOM; }
+		if (in.end - in.p < 16) { at = o; return decode_tail<T>(in, tb, out, at, cap, hist); }
+		in.refill();
+		uint32_t e = tb.lt[in.bb & LM];
+		if ((e & 0xf000) == 0) {                                 /* literals: the common case in sequence and quality lines */
+			in.drop((int)(e & 255)); put_literals(out + o, e); o += 1 + (e >> 8 & 1);
+			e = tb.lt[in.bb & LM];
+			if ((e & 0xf000) == 0) {
+				in.drop((int)(e & 255)); put_literals(out + o, e); o += 1 + (e >> 8 & 1);
+				e = tb.lt[in.bb & LM];
+				if ((e & 0xf000) == 0) {
+					in.drop((int)(e & 255)); put_literals(out + o, e); o += 1 + (e >> 8 & 1);
+					continue;
+				}
+			}
+			in.refill();                                          /* what follows may take 48 bits */
+			e = tb.lt[in.bb & LM];
+		}
+		if (e & E_LINK) { in.drop(LT_BITS); e = tb.lt[(e >> 16) + (in.bb & ((1u << ((e >> 8) & 15)) - 1))]; }
+		in.drop((int)(e & 255));
+		if ((e & 0xf000) == 0) { out[o++] = (T)(e >> 16); continue; }   /* (a literal with a long code) */
+		if (e & E_EOB) { at = o; return D_OK; }
+		if (e & (E_INVALID | E_LINK)) { at = o; return D_DATA; }
+		const unsigned lx = (e >> 8) & 15;
+		const unsigned len = (e >> 16) + (unsigned)(in.bb & ((1u << lx) - 1));
+		in.drop((int)lx);
+		uint32_t d = tb.dt[in.bb & ((1u << DT_BITS) - 1)];
+		if (d & E_LINK) { in.drop(DT_BITS); d = tb.dt[(d >> 16) + (in.bb & ((1u << ((d >> 8) & 15)) - 1))]; }
+		in.drop((int)(d & 255));
+		if (d & (E_INVALID | E_LINK)) { at = o; return D_DATA; }
+		const unsigned dx = (d >> 8) & 15;
+		const size_t dist = (d >> 16) + (size_t)(in.bb & ((1u << dx) - 1));
+		in.drop((int)dx);
+		if (dist > o + hist) { at = o; return D_DATA; }           /* zlib: "invalid distance too far back" */
+		copy_match(out + o, dist, len);
+		o += len;
+	}
+}
+
+/* CRC-32 of gzip (the reflected polynomial 0xEDB88320) by carry-less multiplication: four 128-bit lanes folded 64 bytes at a time, then folded
+ * to one lane, to 64 bits, and reduced (Barrett) -- V. Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction",
+ * with the constants of that paper for this polynomial.  zlib 1.2.11's table-driven crc32() does ~1 GB/s, this ~10; the bytes before the first
+ * and behind the last whole 16 go through zlib's */
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc32_fold(uint32_t crc, const uint8_t *p, size_t n)   /* n a multiple of 16, >= 64; crc: the running register (not inverted) */
+{
+	const __m128i R2R1 = _mm_set_epi64x(0x00000001c6e41596ll, 0x0000000154442bd4ll), R4R3 = _mm_set_epi64x(0x00000000ccaa009ell, 0x00000001751997d0ll);
+	const __m128i R5 = _mm_set_epi64x(0, 0x0000000163cd6124ll), RU = _mm_set_epi64x(0x00000001F7011641ll, 0x00000001DB710641ll), M32 = _mm_set_epi32(0, 0, 0, -1);
+	__m128i x1 = _mm_loadu_si128((const __m128i*)p), x2 = _mm_loadu_si128((const __m128i*)(p + 16)), x3 = _mm_loadu_si128((const __m128i*)(p + 32)), x4 = _mm_loadu_si128((const __m128i*)(p + 48));
+	x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+	p += 64; n -= 64;
+	while (n >= 64) {
+		__m128i t1 = _mm_clmulepi64_si128(x1, R2R1, 0x11), t2 = _mm_clmulepi64_si128(x2, R2R1, 0x11), t3 = _mm_clmulepi64_si128(x3, R2R1, 0x11), t4 = _mm_clmulepi64_si128(x4, R2R1, 0x11);
+		x1 = _mm_clmulepi64_si128(x1, R2R1, 0x00); x2 = _mm_clmulepi64_si128(x2, R2R1, 0x00); x3 = _mm_clmulepi64_si128(x3, R2R1, 0x00); x4 = _mm_clmulepi64_si128(x4, R2R1, 0x00);
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, t1), _mm_loadu_si128((const __m128i*)p));
+		x2 = _mm_xor_si128(_mm_xor_si128(x2, t2), _mm_loadu_si128((const __m128i*)(p + 16)));
+		x3 = _mm_xor_si128(_mm_xor_si128(x3, t3), _mm_loadu_si128((const __m128i*)(p + 32)));
+		x4 = _mm_xor_si128(_mm_xor_si128(x4, t4), _mm_loadu_si128((const __m128i*)(p + 48)));
+		p += 64; n -= 64;
+	}
+	__m128i t;
+	t = _mm_clmulepi64_si128(x1, R4R3, 0x11); x1 = _mm_clmulepi64_si128(x1, R4R3, 0x00); x1 = _mm_xor_si128(_mm_xor_si128(x1, t), x2);
+	t = _mm_clmulepi64_si128(x1, R4R3, 0x11); x1 = _mm_clmulepi64_si128(x1, R4R3, 0x00); x1 = _mm_xor_si128(_mm_xor_si128(x1, t), x3);
+	t = _mm_clmulepi64_si128(x1, R4R3, 0x11); x1 = _mm_clmulepi64_si128(x1, R4R3, 0x00); x1 = _mm_xor_si128(_mm_xor_si128(x1, t), x4);
+	while (n >= 16) {
+		t = _mm_clmulepi64_si128(x1, R4R3, 0x11); x1 = _mm_clmulepi64_si128(x1, R4R3, 0x00);
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, t), _mm_loadu_si128((const __m128i*)p));
+		p += 16; n -= 16;
+	}
+	t = _mm_clmulepi64_si128(R4R3, x1, 0x01);                      /* 128 -> 64 bits: R4 x the low half */
+	x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+	__m128i x2b = _mm_srli_si128(x1, 4);                            /* 64 -> 32 */
+	x1 = _mm_and_si128(x1, M32);
+	x1 = _mm_clmulepi64_si128(x1, R5, 0x00);
+	x1 = _mm_xor_si128(x1, x2b);
+	x2b = x1;                                                       /* Barrett */
+	x1 = _mm_and_si128(x1, M32);
+	x1 = _mm_clmulepi64_si128(x1, RU, 0x10);
+	x1 = _mm_and_si128(x1, M32);
+	x1 = _mm_clmulepi64_si128(x1, RU, 0x00);
+	x1 = _mm_xor_si128(x1, x2b);
+	return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static uint32_t crc32_bytes(uint32_t crc, const uint8_t *p, size_t n)   /* zlib's crc32(crc, p, n) */
+{
+	static const bool fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("YAKAMD_NO_AVX2");
+	if (fast && n >= 256) {
+		const size_t body = n & ~(size_t)15;
+		crc = ~crc32_fold(~crc, p, body);
+		p += body; n -= body;
+	}
+	while (n) { const size_t step = std::min<size_t>(n, (size_t)1 << 30); crc = (uint32_t)crc32(crc, p, (uInt)step); p += step; n -= step; }
+	return crc;
 }
 
 /* one member's end or the stream's: what follows a final block */
@@ -303,7 +446,7 @@ static void decode_run(const uint8_t *inp, size_t n, uint64_t bit, uint64_t limi
 				else {
 					p += 4;
 					const size_t take = std::min<size_t>(len, n - p);
-					O.room(O.n + take + 258);
+					O.room(O.n + take + 272);
 					T *o = O.data() + O.n;
 					for (size_t i = 0; i < take; ++i) o[i] = (T)inp[p + i];
 					O.n += take;
@@ -313,10 +456,10 @@ static void decode_run(const uint8_t *inp, size_t n, uint64_t bit, uint64_t limi
 			}
 		} else if (rc == D_OK) {
 			const Tables *tb = &fixed_tables();
-			if (btype == 2) { rc = read_dynamic(in, T_); tb = &T_; }
+			if (btype == 2) { rc = read_dynamic(in, T_, TEXT); tb = &T_; }
 			while (rc == D_OK) {
 				O.room(O.n + (1 << 16));
-				rc = decode_symbols<T, TEXT>(in, *tb, O.data(), O.n, O.v.size() - WSIZE, O.hist);
+				rc = decode_symbols<T>(in, *tb, O.data(), O.n, O.v.size() - WSIZE, O.hist);
 				if (rc == D_ROOM) { rc = D_OK; continue; }
 				break;
 			}
@@ -365,13 +508,13 @@ struct Searcher {
 			}
 			if (left != 0) continue;                               /* the code-length code must be complete */
 			BitIn bi; bi.init(in, n, p + 3);
-			if (read_dynamic(bi, T) != D_OK) continue;
+			if (read_dynamic(bi, T, true) != D_OK) continue;
 			/* the block itself: text only, every distance inside the (unknown) window */
 			probe.n = 0; probe.hist = WSIZE;
 			int rc;
 			for (;;) {
 				probe.room(probe.n + (1 << 16));
-				rc = decode_symbols<uint16_t, true>(bi, T, probe.data(), probe.n, probe.v.size() - WSIZE, WSIZE);
+				rc = decode_symbols<uint16_t>(bi, T, probe.data(), probe.n, probe.v.size() - WSIZE, WSIZE);
 				if (rc != D_ROOM) break;
 			}
 			if (rc != D_OK || probe.n < 32) continue;
@@ -428,10 +571,6 @@ struct Reader {
 	std::thread producer;
 	int k_made, k_taken;                                       /* batches produced (or being produced) / handed out */
 	uint8_t *cur_ptr; size_t cur_len;                          /* the batch handed out last, carry included */
-	double t_decode = 0, t_stitch = 0, t_emit = 0, t_search = 0;
-	static double cpu() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-	double c_search[64] = {0}, c_decode[64] = {0}, c_emit = 0; std::mutex c_mu;
-	static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 	uint64_t n_search_ok, n_search_bad, n_gap_bits;             /* statistics: chunks accepted, chunks decoded again, bits the stitch decoded itself */
 
 	Reader() : fd(-1), in(0), n(0), n_thr(1), pos(0), stream_end(false), failed(false), m_crc(0), m_len(0), R(tune().front), k_made(0), k_taken(0),
@@ -522,27 +661,21 @@ struct Reader {
 		std::vector<std::thread> th;
 		auto work = [&](int c) {
 			Worker &w = *wk[c];
-			if (c == 0) { const double c1 = cpu(); decode_run<uint8_t, false>(in, n, pos, cut(1), w.bytes, w.T, w.run); c_decode[0] += cpu() - c1; w.found = true; return; }
+			if (c == 0) { decode_run<uint8_t, false>(in, n, pos, cut(1), w.bytes, w.T, w.run); w.found = true; return; }
 			w.found = false;
-			const double c0 = cpu();
 			const uint64_t s = w.se.find(in, n, cut(c), cut(c + 1));
-			c_search[c] += cpu() - c0;
 			if (s == ~0ull) return;
 			w.sym.room(CH * 4);
 			uint16_t *v = w.sym.v.data();
 			for (int i = 0; i < WSIZE; ++i) v[i] = (uint16_t)(256 + i);
 			w.sym.n = 0; w.sym.hist = WSIZE;
-			const double c1 = cpu();
 			decode_run<uint16_t, true>(in, n, s, cut(c + 1), w.sym, w.T, w.run);
-			c_decode[c] += cpu() - c1;
 			w.found = w.run.end > w.run.start;
 		};
-		const double tA = now();
 		for (int c = 1; c < Tn; ++c) th.emplace_back(work, c);
 		work(0);
 		for (auto &t : th) t.join();
 		th.clear();
-		const double tB = now();
 		/* 2. the stitch */
 		std::vector<Piece> pieces;
 		size_t n_gap = 0;
@@ -604,14 +737,12 @@ struct Reader {
 			if (w.run.stream_end) ended = true;
 		}
 		if (!ended && !fill_gap(batch_end)) return;
-		const double tC = now();
 		/* 3. translate + CRC32, every piece on a thread of its own */
 		size_t total = 0;
 		for (Piece &pc : pieces) { pc.dst = total; total += pc.len; }
 		if (b.cap < R + total + 64) { free(b.p); b.cap = R + total + (total >> 3) + 64; b.p = (uint8_t*)malloc(b.cap); if (!b.p) { b.cap = 0; fail("out of memory"); return; } }
 		uint8_t *dst = b.p + R;
 		auto emit = [&](size_t i) {
-			const double c0 = cpu();
 			Piece &pc = pieces[i];
 			uint8_t *o = dst + pc.dst;
 			if (pc.kind == 1) {
@@ -619,17 +750,21 @@ struct Reader {
 				std::vector<uint8_t> lut(256 + WSIZE);
 				for (int j = 0; j < 256; ++j) lut[j] = (uint8_t)j;
 				memcpy(lut.data() + 256, pc.win.data(), WSIZE);
-				for (size_t j = 0; j < pc.len; ++j) o[j] = lut[s[j]];
+				size_t j = 0;
+				const __m128i zero = _mm_setzero_si128();
+				for (; j + 16 <= pc.len; j += 16) {                 /* sixteen symbols that are all literals are just narrowed */
+					const __m128i a = _mm_loadu_si128((const __m128i*)(s + j)), b2 = _mm_loadu_si128((const __m128i*)(s + j + 8));
+					if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_srli_epi16(_mm_or_si128(a, b2), 8), zero)) == 0xFFFF) _mm_storeu_si128((__m128i*)(o + j), _mm_packus_epi16(a, b2));
+					else for (int q = 0; q < 16; ++q) o[j + q] = lut[s[j + q]];
+				}
+				for (; j < pc.len; ++j) o[j] = lut[s[j]];
 			} else memcpy(o, pc.kind == 0 ? wk[pc.src]->bytes.data() : gaps[pc.src]->data(), pc.len);
 			size_t at = 0;
 			for (size_t m = 0; m <= pc.marks.size(); ++m) {
 				const size_t e = m < pc.marks.size() ? pc.marks[m].out_at : pc.len;
-				uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-				for (size_t q = at; q < e; ) { const size_t step = std::min<size_t>(e - q, (size_t)1 << 30); c = (uint32_t)crc32(c, o + q, (uInt)step); q += step; }
-				pc.crc.push_back(c);
+				pc.crc.push_back(crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o + at, e - at));
 				at = e;
 			}
-			{ std::lock_guard<std::mutex> g(c_mu); c_emit += cpu() - c0; }
 		};
 		{
 			size_t next_i = 0; std::mutex mu;
@@ -648,10 +783,15 @@ struct Reader {
 				at = e;
 			}
 		}
-		t_decode += tB - tA; t_stitch += tC - tB; t_emit += now() - tC;
 		b.len = total;
 		b.last = ended || (pos >> 3) >= n;
 		stream_end = b.last;
+		if (b.last) {                                              /* the decoders' buffers go back now, while the consumer still parses and counts */
+			for (auto *w : wk) delete w;
+			wk.clear();
+			for (auto *g : gaps) delete g;
+			gaps.clear();
+		}
 	}
 };
 

@@ -1366,7 +1366,6 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const I
 static bool gz_source(const char *fn, const FxReader &fx, int n_thr, pgz::Reader *z)
 {
 	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_PGZ")) return false;
-	if (getenv("YAKAMD_GZ_CHUNK")) pgz::tune().chunk = (size_t)atoll(getenv("YAKAMD_GZ_CHUNK"));
 	return z->open(fn, n_thr);
 }
 static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const ImgSink &sink, bool pack = false)
