@@ -348,6 +348,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="a test switch of the library (yakamd_test_set); tests force code paths with it")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
     ap.add_argument("--exchange16", action="store_true", help="N > 1: exchange 16-byte {hash, position} records instead of 8-byte tagged ones")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not queue the pass-2 exchange behind pass 1's computation")
@@ -365,6 +366,11 @@ def main():
     a.batch_reads_given = any(x == "--batch-reads" or x.startswith("--batch-reads=") for x in sys.argv[1:])
     a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
+    if a.knob:                                                    # the library is loaded once per process: one place serves every mode below
+        import yak_amd
+        for kv in a.knob:
+            name, _, val = kv.partition("=")
+            yak_amd.lib().yakamd_test_set(name.encode(), int(val))
     if a.gpus > 1 and a.driver == "c" and a.config == "cfg2" and not a.force_exchange:
         return run_multi_c(a)
     if a.config == "nofilter":

@@ -142,6 +142,10 @@ int64_t yakamd_host_image_packed(const char *fn, int min_len, char **out);
  * the compressed bytes one thread takes per batch, the smallest file the reader takes and the room it keeps in front of a batch for the
  * record the parser carries over (0 / negative: unchanged; defaults 1 MiB, 4 MiB, 64 MiB);
  * the inflated stream of `fn` (malloc()ed *out; -1: not taken, -2: the stream is invalid -- yakamd_last_error()). */
+/* Test switches: names that force a code path which the size or shape of the input would otherwise select (INTEGRATION.md section 4 lists
+ * them).  No environment variable reaches them; a value set here also overrides the environment for the public knobs.  reset: forget all. */
+void yakamd_test_set(const char *name, int64_t value);
+void yakamd_test_reset(void);
 void yakamd_gz_tune(int64_t chunk_bytes, int64_t min_file_bytes, int64_t front_bytes);
 int64_t yakamd_gz_inflate(const char *fn, int n_threads, char **out);
 

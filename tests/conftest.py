@@ -20,6 +20,25 @@ def _ensure(path, target):
         subprocess.check_call(["make", "-s", "-C", ROOT, target])
 
 
+# the settings the environment reaches; every other YAKAMD_ name is a test switch that only yakamd_test_set() reaches
+PUBLIC_KNOBS = ['YAKAMD_VERBOSE', 'YAKAMD_DEVICE', 'YAKAMD_GPUS', 'YAKAMD_GPU_LIST', 'YAKAMD_AUTO_SWEEP_GB', 'YAKAMD_MGPU_CHUNK', 'YAKAMD_MGPU_NO_RCCL', 'YAKAMD_BATCH', 'YAKAMD_FAST_BUDGET', 'YAKAMD_NO_RETAIN', 'YAKAMD_RETAIN_GB', 'YAKAMD_PARSE_THREADS', 'YAKAMD_PARSE_WINDOW', 'YAKAMD_NO_LIBDEFLATE', 'YAKAMD_NO_PGZ', 'YAKAMD_NO_HOST_PACK']
+
+
+@pytest.fixture
+def knob(monkeypatch):
+    """knob(name, value): a public knob goes into the environment, a test switch through the library's hook; both are undone after the test"""
+    import yak_amd
+    L = yak_amd.lib()
+
+    def set_(name, value):
+        if name in PUBLIC_KNOBS:
+            monkeypatch.setenv(name, str(value))
+        else:
+            L.yakamd_test_set(name.encode(), int(value))
+    yield set_
+    L.yakamd_test_reset()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """the CPU restatement (oracle/liboracle.so) -- the checker, never the product"""

@@ -409,7 +409,7 @@ def test_subtract_and_isec_protocols_equal_reference_cli(cmd, ya, oracle, synth,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["triobin", "sexchr", "triobin_sliced", "sexchr_sliced", "load_all_into_existing", "load_all_into_existing_sliced"])
-def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_path, monkeypatch):
+def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_path, monkeypatch, knob):
     """yak_ch_restore_core modes 2-6 (htab.c:396-476): flag sets of several .yak files ORed into one
     table -- the loads of `yak triobin` (main.c) and `yak sexchr`; bytes against the oracle (itself pinned
     on the reference's library, tests/test_oracle_vs_ref.py)"""
@@ -424,7 +424,7 @@ def test_restore_core_flag_modes_on_the_device(family, ya, oracle, synth, tmp_pa
     assert O.yko_ch_dump(hc, fc.encode()) == 0
     O.yko_ch_destroy(hc)
     if family.endswith("_sliced"):                           # several passes per file, as files with >= 2^28 (2^22) selected k-mers need
-        monkeypatch.setenv("YAKAMD_LOAD_SLICE", "777")
+        knob("YAKAMD_LOAD_SLICE", "777")
     # YAK_LOAD_ALL into a table that already holds keys (htab.c:436-448): present keys stay as they are, new ones keep their saved count
     steps = [(2, fa), (3, fb)] if family.startswith("triobin") else [(4, fa), (5, fb), (6, fc)] if family.startswith("sexchr") else [(1, fa), (1, fb), (1, fc), (1, fa)]
     h, ho = None, None
@@ -517,12 +517,12 @@ def test_packed_image_feed_equals_ascii_feed(k, bf, ya, oracle, synth):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_BF_DEFER="0")], ids=["filter_rebuilt_from_retained_records", "filter_written_by_the_pass"])
-def test_filter_survives_a_pass_that_kept_it_in_lds(env, ya, oracle, synth, monkeypatch):
+def test_filter_survives_a_pass_that_kept_it_in_lds(env, ya, oracle, synth, monkeypatch, knob):
     """a filtered pass that retains its records does not write its 2^bf_shift filter bits back (yak_ch_destroy_bf usually follows, main.c:55); a later
     create_new call on the same table -- yak_ch_insert_list here (htab.c:51-78 consults the filter, htab.c:63-65) -- must still meet exactly the bits
     every instance of the pass set (bbf.c:34-40): the filter is rebuilt from the retained records before they are dropped"""
     for k_, v in env.items():
-        monkeypatch.setenv(k_, v)
+        knob(k_, v)
     L, O = ya.lib(), oracle.lib()
     img = synth(6000, g=30000, s=77)
     t = ya.Table(31, 10, 4, 22)

@@ -47,11 +47,7 @@ def test_30m_reads_equal_reference():
 
 def test_30m_reads_sliced_pass_equals_reference():
     """the same with {hash, position} records, whose 32-bit positions force two slices: state carries over exactly as between the reference's chunks"""
-    os.environ["YAKAMD_REC8"] = "0"
-    try:
-        d = bench_line("--reads", "30000000")
-    finally:
-        del os.environ["YAKAMD_REC8"]
+    d = bench_line("--reads", "30000000", "--knob", "YAKAMD_REC8=0")
     assert d["verify"]["equals_reference"] is True
 
 

@@ -109,13 +109,13 @@ def test_grow_on_existing_key(ya, oracle, manifest):
 @pytest.mark.parametrize("env", [dict(YAKAMD_BATCH="4096"), dict(YAKAMD_BATCH="8192", YAKAMD_LASTPUT_TAIL="100"),
                                  dict(YAKAMD_BATCH="65536", YAKAMD_LASTPUT_TAIL="1"), dict(YAKAMD_MULTI_BITS="10")],
                          ids=["batch4k", "batch8k_tail100", "batch64k_tail1", "multi10"])
-def test_device_batching_is_invisible(env, ya, oracle, synth, monkeypatch):
+def test_device_batching_is_invisible(env, ya, oracle, synth, monkeypatch, knob):
     """cutting the stream into many device batches (accumulator growth + rehash, per-batch bloom
     phases, last-put fallback scan, tiny `multi` filter) must not change a byte -- the reference's
     independence of -K/-t"""
     img = synth(3000, g=15000, s=12)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knob(k, v)
     for opt in (dict(k=31), dict(k=31, bf_shift=20), dict(k=31, bf_shift=24)):
         assert ya.count_protocol_host(img, **opt)[0] == oracle.count_protocol_mem(img, **opt)[0]
 
@@ -150,7 +150,7 @@ def test_cli_drop_in(ya, oracle, tmp_path):
                               "subbucket_records_big_lds_table", "subbucket_records_small_lds_table_overfull", "subbucket_records_small_lds_table",
                               "subbucket_records_flat_gather", "subbucket_records_level2_two_sweeps"])
 @pytest.mark.parametrize("opt", [dict(k=31, bf_shift=24), dict(k=21, bf_shift=20), dict(k=31, bf_shift=22, n_hash=7)], ids=["k31b24", "k21b20", "k31b22H7"])
-def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch):
+def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, oracle, synth, monkeypatch, knob):
     """main.c:53-57: both passes read the same input.  With yakamd_retain_input the create_new pass keeps its hashed k-mers on the
     device -- grouped by sub-bucket together with the keys every sub-bucket put into the table (k_cnt2) when the pass was one slice into
     an empty table, else grouped by prefix (k_img_count_own) -- and the count pass counts those (yakamd_count_retained), or reports
@@ -162,7 +162,7 @@ def test_second_pass_counts_the_records_the_first_pass_retained(opt, env, ya, or
     if big and opt["k"] != 31:
         pytest.skip("one size is enough")
     for k_, v in env.items():
-        monkeypatch.setenv(k_, v)
+        knob(k_, v)
     img = synth(40000, g=400000, s=23) if big else synth(9000, g=40000, s=19)
     want, wtot = oracle.count_protocol_mem(img, **opt)
     d = L.yakamd_dev_alloc(len(img) + 64)
@@ -338,12 +338,12 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "level2_two_sweeps_16k_sub_buckets", "flat_gather", "flat_gather_multibatch", "one_workgroup_per_sub_table_gather",
                               "sort_stable_radix_passes", "sort_bitmap_ranks", "sort_one_bin_per_sub_table", "sort_8_bins_plain_scatter", "sort_64_bins_multibatch", "sort_4096_bins_in_segments",
                               "sort_bins_joined_by_8", "sort_joined_bins_beyond_the_stage", "sort_one_bin_in_windows"])
-def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
+def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch, knob):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""
     img = synth(20000, g=90000, s=21)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knob(k, v)
     for opt in (dict(k=31), dict(k=31, bf_shift=22), dict(k=31, bf_shift=28), dict(k=21, bf_shift=20)):
         got, tot = ya.count_protocol_host(img, **opt)
         want, wtot = oracle.count_protocol_mem(img, **opt)
@@ -351,7 +351,7 @@ def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_S2_BITS="5"), dict(YAKAMD_S2_BITS="8", YAKAMD_BATCH="65536")], ids=["auto", "s2_5", "s2_8_multibatch"])
-def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
+def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch, knob):
     """homopolymer and short-period reads put thousands of consecutive k-mers into ONE partition
     bucket: the write-combining stacks overflow and the single-record path at the end of each run
     is taken; mixed with ordinary reads so the aligned groups and the singles share runs"""
@@ -363,7 +363,7 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
     img = synth(6000, g=40000, s=33)
     mixed = img[:len(img) // 2] + b"N" + b"N".join(parts) + b"N" + img[len(img) // 2:] + b"N" + b"N".join(parts[:50])
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knob(k, v)
     for opt in (dict(k=31), dict(k=31, bf_shift=28), dict(k=15, bf_shift=27), dict(k=33)):
         got, tot = ya.count_protocol_host(mixed, **opt)
         want, wtot = oracle.count_protocol_mem(mixed, **opt)
@@ -379,13 +379,13 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch):
                               "streaming_replay_2k_slot_segments", "streaming_replay_from_512_slots_1k_slot_segments", "k_replay_for_16k_slots",
                               "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "pass2_key_owning_ranges_plain_hashes", "replay_prefix_32", "lds_keys_for_small_stages",
                               "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
-def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch):
+def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch, knob):
     """~7 M distinct k-mers (1x coverage): every sub-table grows to 16 Ki slots, so the layout replay
     goes through LDS-resident keys, 32- and 16-bit LDS owner ranks, global ranks, and the parallel
     doubling with its LDS base phase -- each variant must give the reference bytes"""
     img = synth(50000, g=8_000_000, s=77, e=0.0, N=0.0)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knob(k, v)
     dbg0 = (C.c_uint32 * 4)(); dbg1 = (C.c_uint32 * 4)()
     ya.lib().yakamd_debug_counters(dbg0)
     for opt in (dict(k=31), dict(k=27, bf_shift=30)):
@@ -400,7 +400,7 @@ def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch)
 
 
 @pytest.mark.parametrize("seed", range(32))
-def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
+def test_randomised_differential(seed, ya, oracle, synth, monkeypatch, knob):
     """seeded random points of the option space (k, prefix length, filter size, number of probes, read
     length, error and N rates, coverage) and of the engine's knobs: the protocol's bytes against the oracle"""
     import random
@@ -420,7 +420,7 @@ def test_randomised_differential(seed, ya, oracle, synth, monkeypatch):
                       ("YAKAMD_RNG_LOG", [None, "5", "8"]), ("YAKAMD_FAST", [None, None, None, "0"])):
         v = rnd.choice(vals)
         if v is not None:
-            monkeypatch.setenv(key, v)
+            knob(key, v)
     got, tot = ya.count_protocol_host(img, k=k, pre=pre, n_hash=n_hash, bf_shift=bf)
     want, wtot = oracle.count_protocol_mem(img, k=k, pre=pre, n_hash=n_hash, bf_shift=bf)
     assert (got == want, tot) == (True, wtot), dict(k=k, pre=pre, bf=bf, n_hash=n_hash, n=n, L=L_, g=g)

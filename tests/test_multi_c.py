@@ -40,15 +40,15 @@ def test_multi_gpu_count_equals_single(n_gpu, chunk, args, inp, reads):
     assert open(got, "rb").read() == open(want, "rb").read()
 
 
-@pytest.mark.parametrize("args,extra", [(["-k31", "-b24"], {"YAKAMD_MGPU_REC16": "1"}), (["-k41", "-b24"], {}), (["-k31", "-b24"], {"YAKAMD_FAST": "0"})],
+@pytest.mark.parametrize("args,extra", [(["-k31", "-b24"], ["-X", "YAKAMD_MGPU_REC16=1"]), (["-k41", "-b24"], []), (["-k31", "-b24"], ["-X", "YAKAMD_FAST=0"])],
                          ids=["rec16_exchange", "k41_no_tagged_records", "general_path_refuses_tagged_uses_rec16"])
 def test_multi_gpu_exchange_formats(args, extra, reads):
     """the exchange moves 8-byte tagged records where k / pre / the pass allow them; the 16-byte {hash, position} format
     must stay exact: forced, for k >= 32, and when the owners' passes are not on the exclusive-ownership path"""
     want, got = os.path.join(reads["dir"], "one2.yak"), os.path.join(reads["dir"], "multi2.yak")
     subprocess.run([YKO, "count"] + args + ["-o", want, reads["fq"]], check=True, stderr=subprocess.DEVNULL)
-    env = dict(os.environ, YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="300000", **extra)
-    subprocess.run([YAM, "count"] + args + ["-o", got, reads["fq"]], check=True, env=env, stderr=subprocess.PIPE)
+    env = dict(os.environ, YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="300000")
+    subprocess.run([YAM] + extra + ["count"] + args + ["-o", got, reads["fq"]], check=True, env=env, stderr=subprocess.PIPE)   # -X: a test switch of the library
     assert open(got, "rb").read() == open(want, "rb").read()
 
 

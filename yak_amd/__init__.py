@@ -31,7 +31,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
-    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_host_image_packed", "yakamd_gz_tune", "yakamd_gz_inflate",
+    "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_host_image_packed", "yakamd_gz_tune", "yakamd_gz_inflate", "yakamd_test_set", "yakamd_test_reset",
     "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
     "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info",
 ]
@@ -149,6 +149,10 @@ def lib():
     L.yakamd_host_image.argtypes = [C.c_char_p, C.c_int, C.c_int, P(C.c_void_p)]
     L.yakamd_host_image_packed.restype = C.c_int64
     L.yakamd_host_image_packed.argtypes = [C.c_char_p, C.c_int, P(C.c_void_p)]
+    L.yakamd_test_set.restype = None
+    L.yakamd_test_set.argtypes = [C.c_char_p, C.c_int64]
+    L.yakamd_test_reset.restype = None
+    L.yakamd_test_reset.argtypes = []
     L.yakamd_gz_tune.restype = None
     L.yakamd_gz_tune.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     L.yakamd_gz_inflate.restype = C.c_int64

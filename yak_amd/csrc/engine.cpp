@@ -18,6 +18,9 @@
 #include <string.h>
 #include <stdarg.h>
 #include <vector>
+#include <map>
+#include <string>
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <functional>
@@ -58,11 +61,32 @@ static double now_ms()
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static int64_t env_i64(const char *name, int64_t dflt)
+/* Run-time settings.  The environment reaches the few a user has a reason to touch; every other name is a test
+ * switch -- it forces a code path that sizes or shapes of input would otherwise select -- and only yakamd_test_set() (tests/conftest.py's
+ * `knobs`, `yak-amd -X name=value`, `bench.py --knob name=value`) reaches those.  A value set through the hook wins over the environment. */
+static std::mutex g_knob_mu;
+static std::map<std::string, int64_t> g_knob;
+static bool knob_is_public(const char *name)
 {
+	static const char *const pub[] = { "YAKAMD_VERBOSE", "YAKAMD_DEVICE", "YAKAMD_GPUS", "YAKAMD_GPU_LIST", "YAKAMD_AUTO_SWEEP_GB", "YAKAMD_MGPU_CHUNK", "YAKAMD_MGPU_NO_RCCL",
+	                                   "YAKAMD_BATCH", "YAKAMD_FAST_BUDGET", "YAKAMD_NO_RETAIN", "YAKAMD_RETAIN_GB", "YAKAMD_PARSE_THREADS", "YAKAMD_PARSE_WINDOW",
+	                                   "YAKAMD_NO_LIBDEFLATE", "YAKAMD_NO_PGZ", "YAKAMD_NO_HOST_PACK" };
+	for (const char *q : pub) if (strcmp(q, name) == 0) return true;
+	return false;
+}
+int64_t yk_knob(const char *name, int64_t dflt)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_knob_mu);
+		if (!g_knob.empty()) { auto it = g_knob.find(name); if (it != g_knob.end()) return it->second; }
+	}
+	if (!knob_is_public(name)) return dflt;
 	const char *s = getenv(name);
 	return s && *s ? atoll(s) : dflt;
 }
+extern "C" void yakamd_test_set(const char *name, int64_t value) { std::lock_guard<std::mutex> lk(g_knob_mu); g_knob[name] = value; }
+extern "C" void yakamd_test_reset(void) { std::lock_guard<std::mutex> lk(g_knob_mu); g_knob.clear(); }
+static inline int64_t env_i64(const char *name, int64_t dflt) { return yk_knob(name, dflt); }
 
 static inline int ceil_log2_u64(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
 
@@ -146,7 +170,7 @@ static void pool_trim(DevPool &P) { ++P.n_trim; pool_release(P, 0); }
 
 static void *pool_alloc(size_t bytes)
 {
-	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
+	static const bool on = true;
 	DevPool &P = pool_here();
 	const size_t gran = bytes >= (1u << 20) ? (2u << 20) : 256;
 	bytes = (bytes + gran - 1) / gran * gran;
@@ -180,7 +204,7 @@ static void *pool_alloc(size_t bytes)
 
 static void pool_free(void *p)
 {
-	static const bool on = env_i64("YAKAMD_POOL", 1) != 0;
+	static const bool on = true;
 	/* idle bytes kept per device: three quarters of the HBM.  A step of the larger configurations
 	 * (1 Gb assembly, 30 M reads) turns over > 100 GB; a cap below the turnover makes every step pay the driver for its buffers again
 	 * (measured with 96 GB: 2.3 s instead of 0.27 s per cfg4 pass).  An allocation that fails drops the whole cache and retries */
@@ -897,7 +921,7 @@ static int fast_admit(yakamd_ctx *c, u64 t, u64 n_pos, u64 n_cap, Rec **out, Rec
 		 * sub-tables, 9 G records of 600 M reads) reaches it every ~700 M records -- the 2^32-position limit used to cut there by accident */
 		u64 kept_n = 0;
 		for (auto &k : c->kept) kept_n += k.n;
-		const u64 per_sb = (u64)env_i64("YAKAMD_SB_INST", c->bloom_mode ? 1800 : 600);
+		const u64 per_sb = (u64)(c->bloom_mode ? 1800 : 600);
 		if (kept_n + n_cap > (u64)(c->phi - c->plo) * (u64)env_i64("YAKAMD_SLICE_SB", env_i64("YAKAMD_P3_MIN", 13) < 18 ? (int64_t)1 << 18 : 8192) * per_sb) fits = false;
 	}
 	if (!c->kept.empty() && c->kept.back().fmt != fmt) fits = false;   /* tagged records carry ranks, Rec records stream positions: never in one slice */
@@ -1210,7 +1234,7 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 	yakamd_ctx *c = ctx_of(h);
 	if (!c || !c->in_pass || c->create_new) return fail("yakamd_count_retained needs an open create_new = 0 pass");
 	HIPCK(hipSetDevice(c->dev));
-	if (c->ret2.valid && !c->retain_broken && env_i64("YAKAMD_RETAIN", 1) != 0) {
+	if (c->ret2.valid && !c->retain_broken) {
 		u32 *d_kcnt = 0;
 		if (dmalloc(&d_kcnt, c->ret2.n_keys)) return -1;
 		HIPCK(hipMemsetAsync(c->d_nmissing, 0, 4, c->st));          /* (a spare word of the context: "some instance went through the pending counts") */
@@ -1227,7 +1251,7 @@ extern "C" int yakamd_count_retained(yak_ch_t *h)
 		retained_drop(c);
 		return bad ? fail("the count over the retained sub-bucket records failed") : 0;
 	}
-	if (c->retained.empty() || c->retain_broken || env_i64("YAKAMD_RETAIN", 1) == 0) { retained_drop(c); return 1; }
+	if (c->retained.empty() || c->retain_broken) { retained_drop(c); return 1; }
 	{
 		int rl, rb; u32 km;
 		if (count_own_plan(c, &rl, &rb, &km) != 0) { retained_drop(c); return 1; }   /* tables beyond the key-owning count kernel: the general count path wants plain hashes */
@@ -1464,7 +1488,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	 * two buffers the doublings alternate between are then laid out exactly like the arena, and whichever holds most of the final tables BECOMES the
 	 * table image -- the others' tables are copied over, nothing else is (the copy of every slot into a third array was 12 ms and 34 GB beside a
 	 * 2 Gb assembly).  k_replay's side arena is then all that `nk` / `nu` hold; they are addressed from `tot` on like its scratch */
-	bool inplace = only_side && env_i64("YAKAMD_R2_INPLACE", 1) != 0;
+	bool inplace = only_side;
 	for (int p = 0; p < P && inplace; ++p) if (large[p] && (1ull << bitsF[p]) != std::max<u64>(32, capm[p])) inplace = false;
 	const u64 nk_lo = inplace ? tot : 0;
 	u64 *nk_al = 0; u32 *nu_al = 0, *img_u = 0;                  /* what was allocated: nk / nu below are shifted by nk_lo; img_u: the image's bitmap when a buffer becomes the image */
@@ -1544,8 +1568,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		for (int p = 0; p < P; ++p) if (large[p]) (pub[p].src ? in1 : in0) += 1ull << bitsF[p];
 		img_is1 = in1 > in0;
 		if (dmalloc(&img_u, tot / 32 + 1)) return -1;
-		if (env_i64("YAKAMD_R2_BITS_IN_PLACE", 1) != 0)
-			for (int p = 0; p < P; ++p) {
+		for (int p = 0; p < P; ++p) {
 				if (!large[p] || sched[p].empty() || sched[p].back().kind != 1 || (pub[p].src != 0) != img_is1) continue;
 				acts[(sched[p].size() - 1) * P + p].pad0 = 1;
 				pub_needed[p] = 0;
@@ -1747,7 +1770,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	 * k-mers far below the table's 624 (30 x coverage: ~100 distinct per 560 instances), and 2048 sub-buckets per sub-table are what the
 	 * level-2 scatter takes in one sweep -- 30 M reads: 13 -> 11 bits, its partition 124 -> ~40 ms.  A sub-bucket that does overflow goes to
 	 * the tiers behind k_lc2, as always */
-	const u64 per_sb = (u64)env_i64("YAKAMD_SB_INST", c->bloom_mode ? 1800 : 600);
+	const u64 per_sb = (u64)(c->bloom_mode ? 1800 : 600);
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
 	if (c->bloom_mode && s2 < c->nb - 9 - 7 && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - 7;   /* k_lc2 stages at most 128 bloom blocks per sub-bucket */
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);

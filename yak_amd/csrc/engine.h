@@ -20,6 +20,7 @@ int  yk_ctx_merge_presize(yakamd_ctx *c, yakamd_ctx *other);
 int  yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_t, u64 *n);
 void yk_pool_release(void *p);
 int yk_set_error(const char *fmt, ...);                      /* this thread's yakamd_last_error() text (+ a line on stderr); returns -1 */
+int64_t yk_knob(const char *name, int64_t dflt);             /* a run-time setting: the test hook's value, else (public names only) the environment's, else dflt */
 void *yk_pool_get(size_t bytes);
 int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_words);   /* the .yak bytes of sub-tables [lo, hi), in pool memory */
 void yk_ctx_gate(yakamd_ctx *c, bool on);

@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
 #include "yak.h"
+void yakamd_test_set(const char *name, int64_t value);        /* include/yak_amd.h: the one entry point beyond yak.h this driver knows, for -X */
 
 /* ---- a table-driven option scanner: "-x", "-xVALUE" and "-x VALUE"; stops at the first non-option ---- */
 enum arg_kind { ARG_FLAG, ARG_I32, ARG_SIZE, ARG_I64SIZE, ARG_F64, ARG_TEXT };
@@ -156,6 +158,15 @@ int main(int argc, char **argv)
 		{ "count", cmd_count, "count k-mers on the GPU, write a .yak table" },
 		{ "qv", cmd_qv, "look the k-mers of sequences up in a .yak table" },
 	};
+	/* -X name=value (anywhere on the line, any number of times): a test switch of the library (yakamd_test_set) -- tests force code paths with it */
+	for (int i = 1; i + 1 < argc; ) {
+		char *eq = strcmp(argv[i], "-X") == 0 ? strchr(argv[i + 1], '=') : 0;
+		if (!eq) { ++i; continue; }
+		*eq = 0;
+		yakamd_test_set(argv[i + 1], atoll(eq + 1));
+		memmove(argv + i, argv + i + 2, (size_t)(argc - i - 2) * sizeof(char*));
+		argc -= 2;
+	}
 	if (argc >= 2)
 		for (size_t i = 0; i < sizeof(cmds) / sizeof(cmds[0]); ++i)
 			if (strcmp(argv[1], cmds[i].name) == 0) return cmds[i].run(argc - 1, argv + 1);

@@ -41,6 +41,9 @@ enum { WSIZE = 32768, LT_BITS = 10, DT_BITS = 8, LT_SIZE = (1 << LT_BITS) + 288 
 enum { E_INVALID = 0x8000, E_LINK = 0x4000, E_EOB = 0x2000, E_BASE = 0x1000 };   /* entry = value << 16 | kind | extra or sub-table bits << 8 | bits to drop */
 enum { D_OK = 0, D_ROOM = 1, D_DATA = -1, D_TRUNC = -2, D_TEXT = -3 };
 
+struct Tune { size_t chunk, min_size, front; bool no_simd; Tune() : chunk((size_t)1 << 20), min_size((size_t)4 << 20), front((size_t)64 << 20), no_simd(false) {} };   /* compressed bytes per thread and batch; smallest file taken; room kept in front of a batch for what the consumer carries over; no CLMUL / SSE paths (tests) */
+static Tune &tune() { static Tune t; return t; }
+
 static inline uint64_t ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
 struct BitIn {
@@ -355,7 +358,7 @@ static uint32_t crc32_fold(uint32_t crc, const uint8_t *p, size_t n)   /* n a mu
 }
 static uint32_t crc32_bytes(uint32_t crc, const uint8_t *p, size_t n)   /* zlib's crc32(crc, p, n) */
 {
-	static const bool fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("YAKAMD_NO_AVX2");
+	static const bool fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !tune().no_simd;
 	if (fast && n >= 256) {
 		const size_t body = n & ~(size_t)15;
 		crc = ~crc32_fold(~crc, p, body);
@@ -553,8 +556,6 @@ struct Piece {
 	std::vector<uint32_t> crc;                                 /* of the stretches the marks cut the piece into (marks.size() + 1 of them) */
 };
 
-struct Tune { size_t chunk, min_size, front; Tune() : chunk((size_t)1 << 20), min_size((size_t)4 << 20), front((size_t)64 << 20) {} };   /* compressed bytes per thread and batch; smallest file taken; room kept in front of a batch for what the consumer carries over */
-static Tune &tune() { static Tune t; return t; }
 
 struct Reader {
 	int fd; const uint8_t *in; size_t n;

@@ -644,7 +644,7 @@ yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...)
 	const uint64_t mask = (1ULL << YAK_COUNTER_BITS) - 1;
 	const int pbits = mode == YAK_LOAD_ALL ? YAK_COUNTER_BITS : 4;
 	size_t per_pass = ((size_t)1 << (32 - pbits)) - 16;
-	if (getenv("YAKAMD_LOAD_SLICE")) per_pass = std::min<size_t>(per_pass, std::max<long long>(1, atoll(getenv("YAKAMD_LOAD_SLICE"))));   /* tests */
+	if (yk_knob("YAKAMD_LOAD_SLICE", 0) > 0) per_pass = std::min<size_t>(per_pass, (size_t)yk_knob("YAKAMD_LOAD_SLICE", 0));   /* tests */
 	std::vector<uint64_t> hashes;
 	std::vector<uint32_t> times;
 	long n_tot = 0, n_new = 0;
@@ -717,7 +717,7 @@ struct ByteSource {
 	void set_memory(const unsigned char *p, size_t n, bool more_follows) { fd = -1; bgzf = false; map = p; map_len = n; size = (int64_t)n; in_memory = true; partial = more_follows; }
 	ByteSource(const ByteSource&) = delete; ByteSource &operator=(const ByteSource&) = delete;
 	void map_plain() {
-		if (bgzf || fd < 0 || size <= 0 || map || getenv("YAKAMD_NO_MMAP")) return;
+		if (bgzf || fd < 0 || size <= 0 || map) return;
 		void *m = mmap(0, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
 		if (m != MAP_FAILED) { map = (const unsigned char*)m; map_len = (size_t)size; (void)madvise(m, map_len, MADV_SEQUENTIAL); }
 	}
@@ -725,7 +725,7 @@ struct ByteSource {
 	static void ld_api(ld_alloc_t *al, ld_dec_t *de, ld_free_t *fr = 0) {
 		static ld_alloc_t a = 0; static ld_dec_t d = 0; static ld_free_t f = 0; static bool tried = false;
 		if (!tried) {                                              /* benign race: every thread resolves the same pointers */
-			void *l = getenv("YAKAMD_NO_LIBDEFLATE") ? 0 : dlopen("libdeflate.so.0", RTLD_NOW);
+			void *l = yk_knob("YAKAMD_NO_LIBDEFLATE", 0) ? 0 : dlopen("libdeflate.so.0", RTLD_NOW);
 			if (l) { a = (ld_alloc_t)dlsym(l, "libdeflate_alloc_decompressor"); d = (ld_dec_t)dlsym(l, "libdeflate_deflate_decompress"); f = (ld_free_t)dlsym(l, "libdeflate_free_decompressor"); }
 			if (!a || !d) { a = 0; d = 0; f = 0; }
 			tried = true;
@@ -1066,7 +1066,7 @@ struct FxReader {
  * what the single reader would have produced; the next window starts where the last accepted
  * segment stopped.  A wrong guess costs time, never correctness.
  * ------------------------------------------------------------------------------------------ */
-static int64_t env_threads_window() { const char *e = getenv("YAKAMD_PARSE_WINDOW"); return e && atoll(e) > 0 ? atoll(e) : 0; }
+static int64_t env_threads_window() { const int64_t w = yk_knob("YAKAMD_PARSE_WINDOW", 0); return w > 0 ? w : 0; }
 static int parse_threads(int n_thread)
 {
 	const char *e = getenv("YAKAMD_PARSE_THREADS");
@@ -1152,7 +1152,7 @@ static void pack_words_avx2(const uint8_t *a, int64_t n_words, uint32_t *codes, 
 static void pack_into(const uint8_t *a, int64_t n, uint32_t *codes, uint32_t *valid)
 {
 	const int64_t nw = (n + 31) / 32, whole = n / 32;
-	static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("YAKAMD_NO_AVX2");
+	static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !yk_knob("YAKAMD_NO_AVX2", 0);
 	int64_t w = 0;
 	if (wide) { pack_words_avx2(a, whole, codes, valid); w = whole; }
 	for (; w < nw; ++w) pack32_scalar(a + 32 * w, n - 32 * w, &codes[2 * w], &codes[2 * w + 1], &valid[w]);
@@ -1292,7 +1292,7 @@ static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64
 		src->map_plain();
 		return true;
 	}
-	if (fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_BGZF")) return false;
+	if (fn == 0 || strcmp(fn, "-") == 0) return false;
 	const int f = ::open(fn, O_RDONLY);
 	if (f < 0) return false;
 	if (!src->index_bgzf(f) || src->size <= min_size) { ::close(f); src->fd = -1; src->bgzf = false; return false; }
@@ -1365,7 +1365,8 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const I
  * parser, from memory; the record a batch ends in is carried to the front of the next one */
 static bool gz_source(const char *fn, const FxReader &fx, int n_thr, pgz::Reader *z)
 {
-	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || getenv("YAKAMD_NO_PGZ")) return false;
+	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || yk_knob("YAKAMD_NO_PGZ", 0)) return false;
+	pgz::tune().no_simd = yk_knob("YAKAMD_NO_AVX2", 0) != 0;
 	return z->open(fn, n_thr);
 }
 static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const ImgSink &sink, bool pack = false)
@@ -1398,7 +1399,7 @@ static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const ImgSink &sink
  * feeds the slices in chunk order, which is the stream order of the file, so the N-GPU bytes are the
  * 1-GPU bytes.  librccl is opened only when a job asks for several distinct GPUs.
  * ------------------------------------------------------------------------------------------ */
-static bool env_fast_default() { const char *f = getenv("YAKAMD_FAST"); return !(f && atoi(f) == 0); }   /* the exclusive-ownership path (the only one that takes tagged records) is on */
+static bool env_fast_default() { return yk_knob("YAKAMD_FAST", 1) != 0; }   /* the exclusive-ownership path (the only one that takes tagged records) is on */
 
 struct RcclApi {
 	void *lib;
@@ -1512,7 +1513,7 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, i
 	int most = 0;
 	for (int s = 0; s < S; ++s) { int n_here = 0; for (int r = 0; r < N; ++r) n_here += J->slot_of[r] == s; most = std::max(most, n_here); }
 	J->recv_words = S > 1 ? (int64_t)((double)J->send_words * (S - 1) * most / N * 1.5) + 4096 * N : 0;
-	J->use_rccl = S > 1 && !(getenv("YAKAMD_MGPU_NO_RCCL") && atoi(getenv("YAKAMD_MGPU_NO_RCCL")));
+	J->use_rccl = S > 1 && !yk_knob("YAKAMD_MGPU_NO_RCCL", 0);
 	if (S < N) fprintf(stderr, "[M::yak_count] %d ranks on %d device%s: ranks that share a device share its chunks and take turns (their slices are fed where they lie)%s\n",
 	                   N, S, S > 1 ? "s" : "", S == 1 ? "; nothing is exchanged" : "");
 	if (J->use_rccl) {
@@ -1552,7 +1553,7 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 {
 	std::mutex why_mu;
 	auto note = [&]() { std::lock_guard<std::mutex> lk(why_mu); if (why && why->empty()) *why = yakamd_last_error(); };   /* called on the thread that failed */
-	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !getenv("YAKAMD_MGPU_REC16");   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
+	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !yk_knob("YAKAMD_MGPU_REC16", 0);   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
 	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
 	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
 	for (int s = 0; s < S; ++s) if (fill[s] * W > J->send_words) { fprintf(stderr, "[E::yak_count] a chunk of %lld positions does not fit the send buffer (%lld words): 16-byte records were not planned for\n", (long long)fill[s], (long long)J->send_words); return false; }
@@ -1833,7 +1834,7 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 		for (int i = 0; i < n_rounds * (int)sd.size(); ++i) cmax = std::max<int64_t>(cmax, n_bytes[i]);
 	}
 	if (cmax > ((int64_t)1 << 31) - 4096) { fprintf(stderr, "[E::yakamd_count_multi_dev] a chunk holds at most 2^31 - 4096 stream positions\n"); if (!h0) yak_ch_destroy(h); return 0; }
-	const bool tagged_only = create_new && yakamd_tagged_ok(opt->k, opt->pre) && !getenv("YAKAMD_MGPU_REC16") && env_fast_default();
+	const bool tagged_only = create_new && yakamd_tagged_ok(opt->k, opt->pre) && !yk_knob("YAKAMD_MGPU_REC16", 0) && env_fast_default();
 	bool ok = multi_open(&J, N, P, dev, cmax, tagged_only || !create_new);
 	const int S = J.S;
 	yk_realtime();
@@ -1887,7 +1888,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	bool have_sid = false;
 	{
 		struct stat sb;
-		if (fn && strcmp(fn, "-") != 0 && stat(fn, &sb) == 0 && S_ISREG(sb.st_mode) && !getenv("YAKAMD_NO_RETAIN")) {
+		if (fn && strcmp(fn, "-") != 0 && stat(fn, &sb) == 0 && S_ISREG(sb.st_mode) && !yk_knob("YAKAMD_NO_RETAIN", 0)) {
 			sid[0] = (uint64_t)sb.st_dev; sid[1] = (uint64_t)sb.st_ino; sid[2] = (uint64_t)sb.st_size;
 			sid[3] = (uint64_t)sb.st_mtim.tv_sec * 1000000000ull + (uint64_t)sb.st_mtim.tv_nsec;
 			have_sid = true;
@@ -1941,7 +1942,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	uint64_t t0 = 0;
 	int64_t l, sum_len = 0, n_seq = 0, n_seq_tot = 0;
 	if (par_size >= 0) {
-		const bool pack = !getenv("YAKAMD_NO_HOST_PACK");          /* the stream crosses the bus at 0.375 B per base, packed by the threads that parsed it */
+		const bool pack = !yk_knob("YAKAMD_NO_HOST_PACK", 0);          /* the stream crosses the bus at 0.375 B per base, packed by the threads that parsed it */
 		psrc.pack = pack;
 		double t_sink = 0, t_open_wait = 0;
 		g_t_parse_windows = 0;
@@ -2092,6 +2093,7 @@ int64_t yakamd_gz_inflate(const char *fn, int n_threads, char **out)
 {
 	pgz::Reader z;
 	*out = 0;
+	pgz::tune().no_simd = yk_knob("YAKAMD_NO_AVX2", 0) != 0;
 	if (!z.open(fn, n_threads, true)) return -1;
 	std::vector<char> all;
 	size_t keep = 0;

@@ -126,6 +126,7 @@ void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, int which,
 struct ResizeTask { u32 old_bits, new_bits, rehash, pad; u64 old_off, new_off; };
 void yk_launch_resize(const ResizeTask *tasks, int P, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used, u32 *scr_used, hipStream_t st);
 void yk_launch_keys_to_hashes(const u64 *kc, const u64 *seg_off, int P, int pre, u64 *hash, u32 *t, hipStream_t st);
+long yk_knob(const char *name, long dflt);                   /* engine.cpp: run-time settings (test switches come through yakamd_test_set only) */
 void yk_launch_fill_u64(u64 *p, u64 v, u64 n, hipStream_t st);
 void yk_launch_put_u64(const u64 *pos, const u64 *val, u32 n, u64 *out, hipStream_t st);
 
