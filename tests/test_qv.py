@@ -90,6 +90,52 @@ def test_yak_qv_through_the_c_abi(opt, k, bf, ya, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_yak_qv_reads_large_files_through_the_parallel_reader(ya, oracle, tmp_path, monkeypatch):
+    """without -p / -E yak_qv needs nothing of a record but its bases: a file of more than 1 MB -- plain, ordinary gzip, wrapped FASTA with short
+    and empty records among the long ones -- goes through the parallel reader (threads x windows), and the histogram is the one-thread reader's
+    and the oracle's"""
+    import gzip
+    import random
+    fq, fa, tab = str(tmp_path / "r.fq"), str(tmp_path / "a.fa"), str(tmp_path / "t.yak")
+    subprocess.check_call([SYN, "-n", "20000", "-l", "150", "-g", "100000", "-s", "13", "-o", fq])
+    subprocess.check_call([SYN, "-a", "-n", "700", "-l", "4000", "-g", "100000", "-s", "13", "-e", "0.004", "-N", "0.0005", "-o", fa])
+    rnd = random.Random(4)
+    recs = open(fa).read().split(">")[1:]
+    wrapped = []
+    for i, r in enumerate(recs):                                # wrap some records, put empty and short ones in between
+        name, seq = r.split("\n", 1)
+        seq = seq.replace("\n", "")
+        if i % 3 == 0:
+            seq = "\n".join(seq[j:j + 70] for j in range(0, len(seq), 70))
+        wrapped.append(">" + name + "\n" + seq + "\n")
+        if i % 50 == 7:
+            wrapped.append(">empty%d\n\n>short%d\nACGTACGT\n" % (i, i))
+    fa2 = str(tmp_path / "b.fa")
+    open(fa2, "w").write("".join(wrapped))
+    gz = str(tmp_path / "b.fa.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(open(fa2, "rb").read())
+    assert os.path.getsize(fa2) > (2 << 20)
+    subprocess.run([YKO, "count", "-k27", "-b24", "-o", tab, fq], check=True, stderr=subprocess.DEVNULL)
+    ya.gz_tune(100000, 0, -1)
+    try:
+        for opt in (dict(), dict(min_len=2500), dict(chunk=300000)):
+            o2 = {k_: v for k_, v in opt.items() if k_ != "chunk"}
+            want = oracle.qv_counts(tab, fa2, **o2)
+            assert sum(want) > 0
+            for thr, win in (("1", None), ("4", None), ("7", "300000")):
+                monkeypatch.setenv("YAKAMD_PARSE_THREADS", thr)
+                if win:
+                    monkeypatch.setenv("YAKAMD_PARSE_WINDOW", win)
+                else:
+                    monkeypatch.delenv("YAKAMD_PARSE_WINDOW", raising=False)
+                assert ya.qv_counts(tab, fa2, **opt) == want, (opt, thr, win)
+                assert ya.qv_counts(tab, gz, **opt) == want, (opt, thr, win, "gz")
+    finally:
+        ya.gz_tune(1 << 20, 4 << 20, 64 << 20)
+
+
+@pytest.mark.gpu
 def test_lookup_and_reduce_entry_points(ya, oracle, synth, tmp_path):
     """yakamd_lookup_dev / yakamd_qv_reduce_dev on their own: per-position counts against
     yko_ch_get on the oracle's table; ragged sequences incl. empty, shorter than k and runs of N"""

@@ -2177,7 +2177,32 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 		fprintf(stderr, "[M::%s] processed %ld sequences\n", "yak_qv", (long)ns);
 		chunk.clear(); h_off.clear(); h_len.clear(); names.clear(); sum_len = 0;
 	};
-	while (ok && (l = fx.next()) >= 0) {                     /* bseq.c:40 */
+	/* without -p / -E nothing of a record but its bases is needed: a plain, block-gzipped or gzip file then goes through the parallel reader
+	 * (every record's sequence + '\n', in order: bseq.c:40 keeps records of any length, qv.c:45 skips the short ones later) */
+	const int n_thr = parse_threads(opt->n_threads);
+	ByteSource psrc; int psrc_fd = -1;
+	pgz::Reader *gz_p = new pgz::Reader;
+	struct GzDrop { pgz::Reader *p; ~GzDrop() { pgz::Reader *q = p; std::thread([q]() { delete q; }).detach(); } } gz_drop{ gz_p };
+	bool parallel = false;
+	if (ok && !opt->print_each && !opt->print_err_kmer) {
+		const ImgSink sink = [&](const char *img, size_t n, int64_t, const WinPack*) {
+			const size_t base = chunk.size();
+			for (const char *p = img, *e = img + n; p < e; ) {
+				const char *q = (const char*)memchr(p, '\n', (size_t)(e - p));
+				if (!q) q = e;
+				h_off.push_back(base + (size_t)(p - img)); h_len.push_back((uint32_t)(q - p));
+				sum_len += q - p;
+				p = q + 1;
+			}
+			chunk.insert(chunk.end(), img, img + n);
+			if (sum_len >= opt->chunk_size || chunk.size() > ((size_t)1 << 31)) flush();   /* bseq.c:54 */
+			return ok;
+		};
+		if (parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd)) { parallel = true; ok = parse_parallel(&psrc, 0, n_thr, sink) && ok; }
+		else if (gz_source(fn, fx, n_thr, gz_p)) { parallel = true; ok = parse_gz(gz_p, 0, n_thr, sink) && ok; }
+		if (psrc_fd >= 0) ::close(psrc_fd);
+	}
+	while (ok && !parallel && (l = fx.next()) >= 0) {         /* bseq.c:40 */
 		h_off.push_back(chunk.size()); h_len.push_back((uint32_t)l);
 		if (opt->print_each || opt->print_err_kmer) names.emplace_back(fx.name.begin(), fx.name.end());
 		chunk.insert(chunk.end(), fx.seq.begin(), fx.seq.end());
