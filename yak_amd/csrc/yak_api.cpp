@@ -918,20 +918,29 @@ struct FxReader {
 	 * the span / file); out grows by the body's bytes.  `from` must be a line start */
 	template <class V> int64_t bulk_body(V &out, int64_t from, int n_thr) {
 		const unsigned char *m = psrc->map;
-		const int64_t fend = (int64_t)psrc->map_len, span_end = std::min<int64_t>(fend, from + ((int64_t)1 << 30));
 		if (n_thr > 64) n_thr = 64;
+		/* a span of 4 MB per thread: a body of 100 MB then keeps every thread busy for several spans (with one span of 1 GB cut into n_thr parts the
+		 * first three parts held the whole body and the other threads walked the records behind it for nothing) */
+		const int64_t fend = (int64_t)psrc->map_len, span_end = std::min<int64_t>(fend, from + std::max<int64_t>((int64_t)8 << 20, (int64_t)n_thr << 22));
 		const int64_t step = (span_end - from + n_thr - 1) / n_thr;
 		struct Part { int64_t a, stop, bytes; bool hit; };
 		std::vector<Part> part(n_thr);
+		int64_t first_hit = INT64_MAX;                                  /* where the body was seen to end: the threads behind it stop counting (their part is not the body's) */
 		auto walk = [&](int t, char *dst) {                             /* dst == 0: count; else copy */
 			Part &P = part[t];
 			int64_t p = P.a;
 			const int64_t lim = dst ? P.stop : std::min<int64_t>(span_end, from + (int64_t)(t + 1) * step);
 			int64_t nb = 0;
 			bool hit = false;
+			unsigned n_line = 0;
 			while (p < lim) {                                          /* p is a line start */
 				const unsigned char c = m[p];
-				if (c == '>' || c == '@' || c == '+') { hit = true; break; }
+				if (c == '>' || c == '@' || c == '+') {
+					hit = true;
+					if (!dst) { int64_t cur = __atomic_load_n(&first_hit, __ATOMIC_RELAXED); while (p < cur && !__atomic_compare_exchange_n(&first_hit, &cur, p, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
+					break;
+				}
+				if (!dst && (++n_line & 255) == 0 && P.a > __atomic_load_n(&first_hit, __ATOMIC_RELAXED)) break;
 				const unsigned char *q = (const unsigned char*)memchr(m + p, '\n', (size_t)(fend - p));
 				const int64_t e = q ? (int64_t)(q - m) : fend;
 				int64_t len = e - p;
@@ -2027,7 +2036,8 @@ int64_t yakamd_host_image(const char *fn, int min_len, int use_fast_path, char *
 		const bool plain = parallel_source(fn, fx, n_thr, 0, &psrc, &psrc_fd);
 		if (plain || gz_source(fn, fx, n_thr, &gz)) {
 			size_t total = 0;
-			const ImgSink sink = [&](const char *part, size_t part_n, int64_t, const WinPack*) { total += part_n; img.insert(img.end(), part, part + part_n); return true; };
+			const bool keep = !(use_fast_path & 2);                   /* (2: the image is only measured, for timing the reader) */
+			const ImgSink sink = [&](const char *part, size_t part_n, int64_t, const WinPack*) { total += part_n; if (keep) img.insert(img.end(), part, part + part_n); return true; };
 			if (plain) parse_parallel(&psrc, min_len, n_thr, sink);
 			else if (!parse_gz(&gz, min_len, n_thr, sink)) { fx.close_file(); return -1; }
 			if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] host_image: %.3f s, %d threads, %zu bytes%s\n", yk_realtime() - t_, n_thr, total, psrc.bgzf ? " (BGZF blocks inflated by the parser threads)" : "");
