@@ -301,3 +301,54 @@ for b in cases:
 print("ok")
 """ % ROOT
     assert subprocess.run([sys.executable, "-c", code] + ([] if wide else ["table"]), check=True, stdout=subprocess.PIPE).stdout.strip() == b"ok"
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_gzip_reader_randomised(seed, tmp_path):
+    """seeded random streams -- text of random line shapes, runs, repeats at every distance, bytes that are no text, empty members, members of a few
+    bytes -- deflated at random levels, strategies, window sizes and flush points, read back with random chunk sizes, thread counts and carry
+    room: the bytes are zlib's"""
+    import zlib
+    import yak_amd
+    rnd = random.Random(7000 + seed)
+
+    def piece():
+        kind = rnd.randrange(7)
+        n = rnd.choice([0, 1, 7, 300, 5000, 70000, 400000])
+        if kind == 0:
+            return bytes(rnd.choice(b"ACGT") for _ in range(n))
+        if kind == 1:
+            return (b"@read/%d\n" % rnd.randrange(10 ** 6) + bytes(rnd.choice(b"ACGTN") for _ in range(100)) + b"\n+\n" + bytes(33 + rnd.randrange(41) for _ in range(100)) + b"\n") * (n // 200 + 1)
+        if kind == 2:
+            return bytes([rnd.choice(b"ACGT\n")]) * n                              # a run: distance 1
+        if kind == 3:
+            unit = bytes(rnd.choice(b"ACGTacgtN\n") for _ in range(rnd.choice([2, 3, 31, 258, 4000, 32768, 40000])))
+            return (unit * (n // len(unit) + 1))[:n]
+        if kind == 4:
+            return bytes(rnd.getrandbits(8) for _ in range(min(n, 30000)))        # no text: a searched start may not be accepted in here
+        if kind == 5:
+            return b"".join(b">c%d\n" % i + bytes(rnd.choice(b"ACGT") for _ in range(60)) + b"\n" for i in range(n // 70))
+        return bytes(rnd.choice(b"ACGTACGTACGT!#$%&Ixyz\t\r\n") for _ in range(n))
+    members, raw = [], []
+    for _ in range(rnd.choice([1, 1, 2, 5])):
+        data = b"".join(piece() for _ in range(rnd.randrange(1, 9)))
+        c = zlib.compressobj(rnd.choice([0, 1, 1, 4, 6, 6, 9]), zlib.DEFLATED, 16 + rnd.choice([9, 12, 15, 15]), rnd.choice([1, 8, 9]),
+                             rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        out, at = [], 0
+        while at < len(data):
+            n = rnd.choice([1, 100, 65536, 10 ** 6])
+            out.append(c.compress(data[at:at + n])); at += n
+            if rnd.random() < 0.3:
+                out.append(c.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+        out.append(c.flush())
+        members.append(b"".join(out)); raw.append(data)
+    fn = str(tmp_path / "r.gz")
+    open(fn, "wb").write(b"".join(members))
+    want = b"".join(raw)
+    assert gzip.open(fn, "rb").read() == want
+    try:
+        for _ in range(6):
+            yak_amd.gz_tune(rnd.choice([1024, 3000, 20000, 150000, 1 << 20]), 0, rnd.choice([0, 100, 64 << 20]))
+            assert yak_amd.gz_inflate(fn, rnd.choice([1, 2, 3, 8, 13])) == want
+    finally:
+        yak_amd.gz_tune(1 << 20, 4 << 20, 64 << 20)
