@@ -1363,8 +1363,8 @@ static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const I
 		WinSet &w = ring[k % NSET];
 		if (stopped_at) *stopped_at = w.next;
 		if (stream_ended) *stream_ended = w.done;
-		if (fd->pack) { if (w.n_ok > 0) ok = sink(0, (size_t)w.wp.n_pos, w.wp.n_seq, &w.wp); }
-		else for (int i = 0; i < w.n_ok && ok; ++i) ok = sink(w.seg[i].img.data(), w.seg[i].img.size(), w.seg[i].n_seq, 0);
+		if (fd->pack) { if (w.n_ok > 0 && (w.wp.n_pos > 0 || w.wp.n_seq > 0)) ok = sink(0, (size_t)w.wp.n_pos, w.wp.n_seq, &w.wp); }
+		else for (int i = 0; i < w.n_ok && ok; ++i) if (!w.seg[i].img.empty() || w.seg[i].n_seq > 0) ok = sink(w.seg[i].img.data(), w.seg[i].img.size(), w.seg[i].n_seq, 0);
 		{ std::lock_guard<std::mutex> lk(mu); ++consumed; if (!ok) abort = true; }
 		cv.notify_all();
 		if (!ok) break;
