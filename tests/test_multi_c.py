@@ -77,3 +77,11 @@ def test_a_sequence_longer_than_a_chunk_is_split_with_an_overlap(reads):
             env = dict(os.environ, YAKAMD_GPUS=str(n_gpu), YAKAMD_GPU_LIST=",".join(["0"] * n_gpu), YAKAMD_MGPU_CHUNK="16384")
             subprocess.run([YAM, "count"] + args + ["-o", got, reads["fa"]], check=True, env=env, stderr=subprocess.PIPE)
             assert open(got, "rb").read() == open(want, "rb").read()
+    # ... and with a budget that fills a rank's slice several times over: a continuation chunk (its first k - 1 positions lie before the end
+    # of the chunk in front of it) must be able to start the next slice (fast_admit compared t, not t + k - 1, with t_end)
+    for args in (["-k21"], ["-k31", "-b22"]):
+        subprocess.run([YKO, "count"] + args + ["-o", want, reads["fa"]], check=True, stderr=subprocess.DEVNULL)
+        for budget in ("400000", "150000"):
+            env = dict(os.environ, YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="16384", YAKAMD_FAST_BUDGET=budget)
+            subprocess.run([YAM, "count"] + args + ["-o", got, reads["fa"]], check=True, env=env, stderr=subprocess.PIPE)
+            assert open(got, "rb").read() == open(want, "rb").read(), (args, budget)
