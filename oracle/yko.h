@@ -89,6 +89,8 @@ yko_ch_t *yko_ch_restore_core(yko_ch_t *ch0, const char *fn, int mode, int min_c
  * count.c:133 kt_for over prefixes), so the sub-tables of the range come out exactly as in a full run -- and yko_ch_dump_range writes the bytes
  * of those sub-tables (behind the 16-byte header when lo == 0): the files of consecutive ranges, concatenated, are the full .yak file */
 void      yko_set_prefix_range(int lo, int hi);               /* lo < 0: all (the default) */
+/* want[p] != 0 for the sub-tables to count, one byte per prefix (NULL: all): yko_extract then lists the k-mers of those alone (oracle/yko_synth.c) */
+void      yko_set_prefix_mask(const unsigned char *want);
 int       yko_ch_dump_range(const yko_ch_t *h, const char *fn, int lo, int hi);
 /* serialise to memory in .yak format; caller frees *out */
 size_t    yko_ch_dump_mem(const yko_ch_t *h, uint8_t **out);

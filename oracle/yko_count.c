@@ -14,6 +14,9 @@
 #include "yko.h"
 
 /* ------------------------------------------------------------------ k-mer extraction */
+static const unsigned char *g_pmask;                         /* yko_set_prefix_mask: k-mers of unwanted sub-tables are not listed at all */
+void yko_set_prefix_mask(const unsigned char *want) { g_pmask = want; }
+
 static inline void kbuf_push(yko_kbuf_t *b, uint64_t y)      /* count.c:17-26 */
 {
 	if (b->n == b->m) {
@@ -37,7 +40,7 @@ static void extract_short(yko_kbuf_t *buf, int k, int pre, int64_t len, const ch
 		rv = rv >> 2 | (uint64_t)(3 - c) << shift;
 		if (++run >= k) {
 			uint64_t h = yko_hash64(fw < rv ? fw : rv, mask);
-			kbuf_push(&buf[h & pm], h);
+			if (g_pmask == 0 || g_pmask[h & pm]) kbuf_push(&buf[h & pm], h);
 		}
 	}
 }
@@ -58,7 +61,7 @@ static void extract_long(yko_kbuf_t *buf, int k, int pre, int64_t len, const cha
 		x[3] = x[3] >> 1 | (uint64_t)(1 - (c >> 1)) << shift;
 		if (++run >= k) {
 			uint64_t h = yko_hash_long(x);
-			kbuf_push(&buf[h & pm], h);
+			if (g_pmask == 0 || g_pmask[h & pm]) kbuf_push(&buf[h & pm], h);
 		}
 	}
 }

@@ -85,3 +85,23 @@ def test_a_sequence_longer_than_a_chunk_is_split_with_an_overlap(reads):
             env = dict(os.environ, YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="16384", YAKAMD_FAST_BUDGET=budget)
             subprocess.run([YAM, "count"] + args + ["-o", got, reads["fa"]], check=True, env=env, stderr=subprocess.PIPE)
             assert open(got, "rb").read() == open(want, "rb").read(), (args, budget)
+
+
+def test_multi_gpu_on_distinct_devices(reads):
+    """two REAL devices (the staging events of yak_count_multi belong to one device each; with ranks sharing device 0, as every
+    other test here runs them, an event made on the wrong device goes unnoticed).  Skipped on a one-GPU box."""
+    import yak_amd
+    n_dev = yak_amd.lib().yakamd_device_count()
+    if n_dev < 2:
+        pytest.skip("needs two MI355X")
+    want, got = os.path.join(reads["dir"], "one5.yak"), os.path.join(reads["dir"], "multi5.yak")
+    for args in (["-k31", "-b24"], ["-k31"]):
+        subprocess.run([YKO, "count"] + args + ["-o", want, reads["fq"]], check=True, stderr=subprocess.DEVNULL)
+        for n_gpu in sorted({2, min(n_dev, 8)}):
+            if 1024 % n_gpu:
+                continue
+            env = dict(os.environ, YAKAMD_GPUS=str(n_gpu), YAKAMD_MGPU_CHUNK="300000")
+            env.pop("YAKAMD_GPU_LIST", None)
+            r = subprocess.run([YAM, "count"] + args + ["-o", got, reads["fq"]], check=True, env=env, stderr=subprocess.PIPE)
+            assert f"{n_gpu} GPUs".encode() in r.stderr
+            assert open(got, "rb").read() == open(want, "rb").read(), (args, n_gpu)

@@ -1691,18 +1691,24 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	 * copy from pageable memory is staged by the runtime anyway, but behind a synchronise per piece) */
 	const size_t STG = (size_t)32 << 20;
 	uint8_t *stg[2] = { 0, 0 };
-	hipEvent_t stg_ev[2] = { 0, 0 };
-	bool stg_busy[2] = { false, false };
+	/* an event belongs to the device that was current when it was made and can only be recorded on a stream of that device: one per staging
+	 * buffer AND slot, made with the slot's device current; stg_on[i] = the slot whose copy stream holds buffer i's last copy (-1: idle) */
+	std::vector<hipEvent_t> stg_ev[2];
+	int stg_on[2] = { -1, -1 };
 	int stg_i = 0;
-	for (int i = 0; i < 2 && ok; ++i) ok = hipHostMalloc((void**)&stg[i], STG) == hipSuccess && hipEventCreateWithFlags(&stg_ev[i], hipEventDisableTiming) == hipSuccess;
+	for (int i = 0; i < 2 && ok; ++i) {
+		ok = hipHostMalloc((void**)&stg[i], STG) == hipSuccess;
+		stg_ev[i].assign(S, (hipEvent_t)0);
+		for (int s = 0; s < S && ok; ++s) { hipSetDevice(J.sdev[s]); ok = hipEventCreateWithFlags(&stg_ev[i][s], hipEventDisableTiming) == hipSuccess; }
+	}
 	auto to_device = [&](int gdev, uint8_t *dst, const char *src, size_t n) -> bool {
 		hipSetDevice(J.sdev[gdev]);
 		for (size_t o = 0; o < n; o += STG) {
 			const size_t m = std::min(STG, n - o);
-			if (stg_busy[stg_i] && hipEventSynchronize(stg_ev[stg_i]) != hipSuccess) return false;
+			if (stg_on[stg_i] >= 0 && hipEventSynchronize(stg_ev[stg_i][stg_on[stg_i]]) != hipSuccess) return false;
 			memcpy(stg[stg_i], src + o, m);
-			if (hipMemcpyAsync(dst + o, stg[stg_i], m, hipMemcpyHostToDevice, J.cp[gdev]) != hipSuccess || hipEventRecord(stg_ev[stg_i], J.cp[gdev]) != hipSuccess) return false;
-			stg_busy[stg_i] = true; stg_i ^= 1;
+			if (hipMemcpyAsync(dst + o, stg[stg_i], m, hipMemcpyHostToDevice, J.cp[gdev]) != hipSuccess || hipEventRecord(stg_ev[stg_i][gdev], J.cp[gdev]) != hipSuccess) return false;
+			stg_on[stg_i] = gdev; stg_i ^= 1;
 		}
 		return true;
 	};
@@ -1768,7 +1774,11 @@ static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t
 	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
 	wait_worker();
 	const double t_fed = yk_realtime() - t_job0;
-	for (int i = 0; i < 2; ++i) { if (stg_busy[i]) (void)hipEventSynchronize(stg_ev[i]); if (stg_ev[i]) (void)hipEventDestroy(stg_ev[i]); if (stg[i]) (void)hipHostFree(stg[i]); }
+	for (int i = 0; i < 2; ++i) {
+		if (stg_on[i] >= 0) (void)hipEventSynchronize(stg_ev[i][stg_on[i]]);
+		for (hipEvent_t e_ : stg_ev[i]) if (e_) (void)hipEventDestroy(e_);
+		if (stg[i]) (void)hipHostFree(stg[i]);
+	}
 	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
 	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
 		 * scratch of only one of them is alive at a time (one device posing as N = the pass in N sweeps over prefix ranges: what lets a
