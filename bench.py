@@ -232,8 +232,8 @@ def run_multi_c(a):
     tg = time.perf_counter()
     for b in range(n_rounds):
         for s in range(S):
-            first = (b * S + s) * chunk_reads
             n_reads = max(0, min(chunk_reads, per_dev - b * chunk_reads))
+            first = b * S * chunk_reads + s * n_reads           # the job's stream = reads 0, 1, 2, ... in order (every round before this one was a full one): the stream tests/golden/cfg3_full.json pins
             t = torch.empty(max(16, n_reads * rec_len), dtype=torch.uint8, device=f"cuda:{sdev[s]}")
             if n_reads:
                 syn.yaksynth_reads(h_buf.data_ptr(), n_reads, READ_LEN, genome, 42, err, 0.0005, first, threads)
@@ -267,16 +267,44 @@ def run_multi_c(a):
         L.yak_ch_destroy(h)
         return None, tot
 
-    for _ in range(a.warmup):
+    t_first = time.perf_counter()
+    first_ms = None
+    for i_ in range(a.warmup):
         step()
+        if i_ == 0:
+            sync_all(); first_ms = (time.perf_counter() - t_first) * 1e3     # the first job of the process: the driver hands out (and clears) the memory for the first time
+    for d in sdev:
+        L.yakamd_peak_bytes(d, 1)
     sync_all(); barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         _, tot = step()
     sync_all(); barrier()
     dt = time.perf_counter() - t0
+    # what a device needs at its peak: the library's buffers in use (tables, records, exchange) + the input chunks this harness keeps resident on it
+    in_bytes = {d: sum(bufs[i_].numel() for i_ in range(len(bufs)) if sdev[i_ % S] == d) for d in sdev}
+    peak = {d: int(L.yakamd_peak_bytes(d, 0)) + in_bytes[d] for d in sdev}
+    hbm_total = {d: torch.cuda.mem_get_info(d)[1] for d in sdev}
+    if any(peak[d] > 0.9 * hbm_total[d] for d in sdev):
+        raise SystemExit(f"FAILED: the job needs {max(peak.values()) / 1e9:.1f} GB on one device, more than 0.9 of its {hbm_total[sdev[0]] / 1e9:.0f} GB")
     inst = sum(sizes) // rec_len * (READ_LEN - K + 1) * (2 if bf else 1)
     verify = None
+    gfn = os.path.join(ROOT, "tests", "golden", "cfg3_full.json")
+    if bf == 0 and not a.no_verify and os.path.exists(gfn) and P % N == 0:
+        # BASELINE configs[2] itself (600 M reads, any N that divides the pinned ranges): the oracle counted the whole stream for sub-tables [0, 128) and
+        # [640, 768) (tests/gen_golden_cfg3.py); the job's bytes at those sub-tables must be the oracle's
+        g = json.load(open(gfn))
+        if (per_gpu * N, genome, PRE, K) == (g["reads"], g["genome"], g["pre"], g["k"]):
+            h, _ = step(keep=True)
+            tm = yak_amd.Table(K, PRE, N_HASH, bf, ptr=h)
+            verify = {"oracle": f"tests/golden/cfg3_full.json ({g['produced_by']})"}
+            for rng, ref in g["ranges"].items():
+                lo_, hi_ = (int(x) for x in rng.split(":"))
+                md5_, size_ = tm.range_md5(lo_, hi_)
+                verify[f"subtables_{lo_}_{hi_}_equal_oracle"] = (md5_, size_) == (ref["md5"], ref["size"])
+            tm.close()
+            if not all(v for k_, v in verify.items() if k_.startswith("subtables_")):
+                raise SystemExit(f"FAILED: the job's sub-tables differ from the oracle's: {verify}")
     if a.job_md5 or per_gpu * N <= 4_000_000:
         # the sharded table's .yak bytes against ONE unsharded table fed the same stream, chunk after chunk
         h, _ = step(keep=True)
@@ -297,7 +325,7 @@ def run_multi_c(a):
             t1.destroy_bf(); t1.clear(); t1.count_pass(0, feeds); t1.shrink(2, 1023)
         md5_1 = t1.dump_md5()[0]
         t1.close()
-        verify = {"job_yak_md5": md5_n, "one_table_yak_md5": md5_1, "equals_one_table": md5_n == md5_1}
+        verify = dict(verify or {}, job_yak_md5=md5_n, one_table_yak_md5=md5_1, equals_one_table=md5_n == md5_1)
         if md5_n != md5_1:
             raise SystemExit("FAILED: the sharded job's .yak differs from the single table's")
     barrier()
@@ -317,7 +345,8 @@ def run_multi_c(a):
                                    2: "hipMemcpyPeerAsync peer copies (RCCL unavailable or switched off)"}.get(exch.value, "?"),
                       "devices": devs, "rounds": n_rounds},
            "kmer_instances_per_s": inst / (dt / a.steps), "final_distinct": tot,
-           "input_generation_s_not_timed": round(gen_s, 2),
+           "input_generation_s_not_timed": round(gen_s, 2), "first_job_ms": first_ms,
+           "peak_hbm_bytes_per_device": {str(d): peak[d] for d in sdev}, "peak_hbm_note": "library buffers in use at their high-water mark (yakamd_peak_bytes: tables, records, exchange buffers; the pool's idle ranges are not in it) + the input chunks resident on the device; the job refuses to report above 0.9 of the device's memory",
            "roofline": {"bound": "hbm", "kernel": "whole job step (partition + exchange + per-rank count + exact layout), all GPUs", "achieved": by / (dt / a.steps) / 1e9,
                         "peak": HBM_PEAK_GBS * S, "unit": "GB/s", "frac": by / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * S), "traffic": None,
                         "algorithmic_bytes_per_instance": by / max(1, inst / (2 if bf else 1))},
@@ -339,6 +368,7 @@ def main():
                     help="BASELINE.json configuration: cfg2 = configs[1] (default, the metric's workload); nofilter = same reads, no bloom filter, one pass; "
                          "cfg4 = configs[3], yak count -k21 on a synthetic assembly (long contigs, singletons kept); cfg5 = configs[4], lookup-only path of yak qv")
     ap.add_argument("--of", type=int, default=8, help="cfg3shard: GPUs of the job whose rank 0 is measured on this one GPU (BASELINE configs[2]: 8)")
+    ap.add_argument("--rank", type=int, default=0, help="cfg3shard: which of the --of ranks (it owns sub-tables [rank * 1024 / of, (rank + 1) * 1024 / of); ranks 0 and 5 of the 600 M-read job are pinned on the oracle: tests/golden/cfg3_full.json)")
     ap.add_argument("--contigs", type=int, default=50, help="cfg4: number of contigs")
     ap.add_argument("--contig-len", type=int, default=100_000_000, help="cfg4: bases per contig")
     ap.add_argument("--sweeps", type=int, default=1, help="cfg4: > 1 = count through yak_count() in that many sweeps over prefix ranges (sizes beyond one pass: --contigs 50 --sweeps 8 = 5 Gb)")
@@ -811,7 +841,7 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc, pmc_src = {}, None
-    for cand_ in (("r04_pmc_traffic_nofilter.json",) if a.bf_shift == 0 else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    for cand_ in (("r05_pmc_traffic_nofilter.json", "r04_pmc_traffic_nofilter.json") if a.bf_shift == 0 else ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand_)))
             pmc_src = "profiles/" + cand_
@@ -846,13 +876,14 @@ def main():
     dom = max([k_ for k_ in kern if not k_["kernel"].startswith(("k_xpart", "k_r2_"))], key=lambda x: x["ms"])
     name, avg_ms, launches, ach = dom["kernel"], dom["avg_launch_ms"], dom["launches"], dom["achieved_GBs"]
     out = {
-        "metric": "distinct k-mers counted/sec (k=31), yak count -b37 two-pass protocol, .yak bit-exact",
+        "metric": (f"distinct k-mers counted/sec (k=31), yak count -b{a.bf_shift} two-pass protocol, .yak bit-exact" if bloom_on or a.bf_shift > 0 else
+                   "distinct k-mers counted/sec (k=31), yak count without a filter (one pass, singletons kept), .yak bit-exact"),
         "value": tot_all / (dt / a.steps), "unit": "distinct k-mers/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": f"yak count -k{K} -b{a.bf_shift} on {a.reads} x {READ_LEN} bp synthetic reads per GPU "
-                               f"(G={genome}, e=0.5%, N=0.05%), 30x, bloom prefilter on, both passes + shrink",
+        "config": {"workload": f"yak count -k{K}" + (f" -b{a.bf_shift}" if a.bf_shift > 0 else "") + f" on {a.reads} x {READ_LEN} bp synthetic reads per GPU "
+                               f"(G={genome}, e=0.5%, N=0.05%), 30x, " + ("bloom prefilter on, both passes + shrink" if a.bf_shift > 0 else "no filter: one pass, every k-mer kept"),
                    "reads_per_gpu": a.reads, "k": K, "pre": PRE, "bf_shift": a.bf_shift,
                    "sharding": "prefix-sharded sub-tables, RCCL all-to-all of hashed k-mers" if sharded else "1 GPU"},
         "kmer_instances_per_s": inst_all / (dt / a.steps),
@@ -885,6 +916,8 @@ def main():
                      "no_bloom_step": nb_probe,
                      "pass_bytes": {"pass1": b_pass1, "pass2": b_pass2, "per_instance_pass1": b_pass1 / max(1, n1), "per_instance_pass2": (b_pass2 / n2) if n2 else None},
                      "pass_ms": {"pass1": ms_p1, "pass2": w.get("pass2"), "step": ms_step},
+                     "pass2_frac_note": ("pass 2 ran on the level-2 records pass 1 retained: of the 16 B per instance the model counts for writing a prefix bucket and reading it back, "
+                                         "it only reads the 8 (the write was pass 1's); the counter bytes of k_cnt2 + k_cnt2_apply are in all_kernels") if (s2 and not p2_extracted) else None,
                      "pass2_input": "records retained by pass 1 (same input: main.c:57; sub-bucket records + key lists when pass 1 was one slice, else prefix-grouped records)" if (s2 and not p2_extracted) else "extracted again",
                      "dominant_kernel": {"kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
                                          "algorithmic_bytes_per_launch": dom["bytes"] / launches, "algorithmic_bytes_per_instance": dom["bytes"] / max(1, n1),

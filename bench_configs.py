@@ -42,16 +42,21 @@ def _gold(name):
 def pmc_step_traffic(name, scale=None, only=None):
     """HBM bytes of ONE step of a configuration from its committed rocprofv3 counter passes (profiles/r04_pmc_traffic_<name>.json: FETCH_SIZE x 2 as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, of a `--steps 1 --warmup 0 --no-verify` run of that very command): (bytes, source) or (None, None)"""
-    fn = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{name}.json")
-    try:
-        d = json.load(open(fn))
-    except Exception:
+    d = None
+    for rnd in ("r05", "r04"):                                 # the latest round that profiled this configuration
+        fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{name}.json")
+        try:
+            d = json.load(open(fn))
+            break
+        except Exception:
+            pass
+    if d is None:
         return None, None
     def w(k_):                                                # cfg3shard: the stand-ins for the peers' GPUs partition 7 of 8 chunks on this device
         return next((f for pre, f in (scale or {}).items() if k_.startswith(pre)), 1.0)
     by = sum(w(k_) * v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for k_, v in d.items()
              if isinstance(v, dict) and "launches" in v and (only is None or k_.startswith(only)))
-    return by, f"profiles/r04_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE)"
+    return by, f"profiles/{rnd}_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE)"
 
 
 def _roof_traffic(roof, name, seconds, scale=None, only=None):
@@ -286,7 +291,10 @@ def run_cfg3shard(a, torch, yak_amd):
     genome = 5 * per_src * of
     ERR = 0.001                                                # e = 0.1 % for configs[2] (at 0.5 % an unfiltered count of 600 M reads holds ~15 G distinct k-mers: ~200 GB of slots)
     threads = min(os.cpu_count() or 8, 64)
-    lo, hi = 0, P // of
+    rk = a.rank
+    if not 0 <= rk < of or P % of:
+        raise SystemExit("--rank must name one of the --of ranks, and --of divide the 1024 sub-tables")
+    lo, hi = rk * P // of, (rk + 1) * P // of
     rec_len = bench.READ_LEN + 1
     B = batch * rec_len
     h_buf = torch.empty(B, dtype=torch.uint8, pin_memory=True)
@@ -304,21 +312,22 @@ def run_cfg3shard(a, torch, yak_amd):
     def chunk(b, s, hashes):
         """source s's chunk of round b on the device, partitioned; returns (records, offsets of the owned slice, stream offset)"""
         n_reads = min(batch, per_src - b * batch)
+        first = b * of * batch + s * n_reads                     # the job's stream = reads 0, 1, 2, ... in order, dealt round by round, source by source (every round before this one was a full one)
         tg = time.perf_counter()
-        syn.yaksynth_reads(h_buf.data_ptr(), n_reads, bench.READ_LEN, genome, 42, ERR, 0.0005, (b * of + s) * batch, threads)
+        syn.yaksynth_reads(h_buf.data_ptr(), n_reads, bench.READ_LEN, genome, 42, ERR, 0.0005, first, threads)
         d_reads[:n_reads * rec_len].copy_(h_buf[:n_reads * rec_len])
         torch.cuda.synchronize()
         T["host_generation_not_counted"] += time.perf_counter() - tg
         tp = time.perf_counter()
         n = (L.yakamd_partition_hashes_dev if hashes else L.yakamd_partition_tagged_dev)(K, PRE, d_reads.data_ptr(), n_reads * rec_len, d_rec.data_ptr(), h_bst)
         torch.cuda.synchronize()
-        T["own_partition" if s == 0 else "peer_partitions_not_counted"] += time.perf_counter() - tp
+        T["own_partition" if s == rk else "peer_partitions_not_counted"] += time.perf_counter() - tp
         if n < 0:
             raise RuntimeError("partition: " + yak_amd._err())
         bst = list(h_bst)
         cnt = bst[hi] - bst[lo]
         ob = (C.c_uint64 * (P + 1))(*[bst[min(max(p_, lo), hi)] - bst[lo] for p_ in range(P + 1)])
-        return d_rec.data_ptr() + 8 * bst[lo], cnt, ob, (b * of + s) * B, n_reads * rec_len
+        return d_rec.data_ptr() + 8 * bst[lo], cnt, ob, first * rec_len, n_reads * rec_len
 
     def one_pass(t, create_new):
         if L.yakamd_pass_begin(t.h, create_new) != 0:
@@ -352,7 +361,7 @@ def run_cfg3shard(a, torch, yak_amd):
         t.h.contents.tot += n_ins
         return reuse == 0
 
-    def job():
+    def job(last_job=True):
         for k_ in T:
             T[k_] = 0.0
         fed[0] = 0
@@ -375,32 +384,64 @@ def run_cfg3shard(a, torch, yak_amd):
         L.yak_ch_hist(t.h, hist, 1)
         tot = t.tot
         caps = [t.subtable(p_) for p_ in range(lo, hi)]
+        share = t.range_md5(lo, hi) if last_job and not a.no_verify else None    # the bytes this rank contributes to the job's .yak file
         t.close()
-        return inst1, pass1, reused, hist, tot, caps
+        return inst1, pass1, reused, hist, tot, caps, share
 
     # --warmup W: W whole jobs before the measured one (the device memory pool is then warm: a fresh process pays the driver ~27 ms per GB it
     # allocates for the first time, which a job of this size -- 200 GB of buffers -- feels; the first job's time is reported beside the last's)
     first_job = None
-    for it_ in range(max(0, a.warmup if a.warmup_given else 0) + 1):
-        inst1, pass1, reused, hist, tot, caps = job()
+    n_jobs = max(0, a.warmup if a.warmup_given else 0) + 1
+    for it_ in range(n_jobs):
+        L.yakamd_peak_bytes(0, 1)
+        inst1, pass1, reused, hist, tot, caps, share = job(it_ == n_jobs - 1)
         if first_job is None:
             first_job = {k_: round(v, 3) for k_, v in T.items()}
     rank_s = T["own_partition"] + T["feed"] + T["finish"]
     # what the rank receives over xGMI per pass: (of - 1) / of of its records, 8 bytes each, over of - 1 point-to-point links (MI355X_MICROARCH.md: ~153 GB/s each way per link)
     exch_s = inst1 * 8.0 * (of - 1) / of / ((of - 1) * 153e9 * 0.8) * (2 if (bf > 0 and not reused) else 1)
+    # what the rank's device must hold in the REAL of-GPU job (bench.py --gpus of): the library's buffers at their high-water mark (measured here:
+    # tables, the slice's records, the counting stage; the pool's idle ranges are not in it) + its share of the input resident in HBM + the two sets of
+    # send / receive buffers of the exchange (one 2^29-byte chunk of reads per device and round: 8 bytes per k-mer instance each way)
+    lib_peak = int(L.yakamd_peak_bytes(0, 0))
+    chunk_reads_real = min(per_src, (1 << 29) // rec_len)
+    exch_buf = 2 * 2 * chunk_reads_real * (bench.READ_LEN - K + 1) * 8
+    real_peak = lib_peak + per_src * rec_len + exch_buf
+    if real_peak > 0.9 * tot_mem:
+        raise SystemExit(f"FAILED: a rank of the {of}-GPU job would need {real_peak / 1e9:.1f} GB of its device's {tot_mem / 1e9:.0f} GB")
     verify = {"count_mass_equals_instances": (sum(c * hist[c] for c in range(1024)) == inst1 and hist[1023] == 0) if bf == 0 else None,
               "sum_hist_equals_tot": sum(hist) == tot, "largest_subtable_slots": max(c_ for c_, _ in caps), "distinct": tot}
+    if share is not None:
+        verify["share_md5"], verify["share_bytes"] = share
+        # the oracle counted the whole 600 M-read stream for the sub-tables of ranks 0 and 5 (tests/gen_golden_cfg3.py -> tests/golden/cfg3_full.json;
+        # its own check at 1 M reads is on record too): a rank's share must be those bytes
+        gfn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cfg3_full.json")
+        if bf == 0 and os.path.exists(gfn):
+            g = json.load(open(gfn))
+            ref = None
+            if (per_src * of, genome, PRE) == (g["reads"], g["genome"], g["pre"]):
+                ref = g["ranges"].get(f"{lo}:{hi}")
+            elif (per_src * of, genome) == (1_000_000, 5_000_000):
+                ref = g["procedure_check_1M_reads"].get(f"{lo}:{hi}")
+            if ref is not None:
+                verify["share_equals_oracle"] = (ref["md5"], ref["size"], ref["distinct"]) == (share[0], share[1], tot)
+                verify["oracle"] = f"tests/golden/cfg3_full.json {lo}:{hi} ({g['produced_by']})"
+                if not verify["share_equals_oracle"]:
+                    raise SystemExit(f"FAILED: the rank's share differs from the oracle's: {verify} vs {ref}")
     if verify["count_mass_equals_instances"] is False or not verify["sum_hist_equals_tot"]:
         raise SystemExit(f"FAILED: {verify}")
     by = (32.0 if bf == 0 else (16.0 + 128.0 + 16.0 + 16.0 + 8.0 + 8.0)) * inst1
     return {"metric": f"distinct k-mers counted/sec (k=31): ONE rank's share of a {of}-GPU prefix-sharded job, measured on one GPU", "value": tot / rank_s, "unit": "distinct k-mers/s (this rank)",
             "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": rank_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"rank 0 of {of}: owns sub-tables [{lo}, {hi}); receives the records of its prefixes from {of} sources x {per_src} x {bench.READ_LEN} bp reads "
+            "config": {"workload": f"rank {rk} of {of}: owns sub-tables [{lo}, {hi}); receives the records of its prefixes from {of} sources x {per_src} x {bench.READ_LEN} bp reads "
                                    f"(G = {genome}, e = 0.1 %) in {n_rounds} rounds of {batch} reads per source; yak count -k{K}" + (f" -b{bf}, both passes + shrink" if bf else ", no filter"),
                        "k": K, "pre": PRE, "bf_shift": bf, "of": of, "reads_per_source": per_src, "batch_reads": batch},
             "rank_seconds": {k_: round(v, 3) for k_, v in T.items()}, "first_job_rank_seconds": first_job, "jobs_before_the_measured_one": max(0, a.warmup if a.warmup_given else 0), "pass1_seconds": {k_: round(v, 3) for k_, v in pass1.items()},
             "instances_received_per_pass": inst1, "final_distinct_this_rank": tot,
-            "peak_hbm_bytes": tot_mem - min_free[0], "pass2_counted_retained_records": reused,
+            "peak_hbm_bytes": lib_peak, "peak_hbm_bytes_incl_pool_cache_and_harness": tot_mem - min_free[0],
+            "peak_hbm_bytes_in_the_real_job": real_peak, "peak_hbm_note": f"library buffers in use at their high-water mark {lib_peak / 1e9:.1f} GB + this rank's {per_src * rec_len / 1e9:.1f} GB of the input resident in HBM "
+                                                                        f"+ {exch_buf / 1e9:.1f} GB of exchange buffers (two sets of send + receive, one 2^29-byte chunk of reads each); the line fails above 0.9 of the device's {tot_mem / 1e9:.0f} GB",
+            "pass2_counted_retained_records": reused,
             "prediction": {"label": "PREDICTED, not measured: all ranks take this rank's time; the exchange (8-byte records over of-1 xGMI links at 80 % of 153 GB/s) is added in full, not overlapped",
                            "exchange_seconds": exch_s, "job_seconds": rank_s + exch_s, "job_distinct_kmers_per_s": tot * of / (rank_s + exch_s),
                            "job_reads": per_src * of},

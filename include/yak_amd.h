@@ -175,6 +175,9 @@ void yakamd_host_free(void *p);
 int yakamd_device_sync(void);
 int yakamd_mem_info(size_t *free_bytes, size_t *total_bytes);
 
+/* high-water mark of the device memory the library had in use on device `dev` (buffers handed out by its pool; the idle ranges it keeps for the next
+ * pass do not count); reset != 0 starts a new measurement from what is in use now */
+int64_t yakamd_peak_bytes(int dev, int reset);
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
 
@@ -182,6 +185,9 @@ void yakamd_trim(void);
 int yakamd_sync_host(yak_ch_t *h);
 /* serialise the table in .yak format straight from the host view into memory (malloc'ed) */
 int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out);
+/* the bytes of sub-tables [lo, hi) alone ({u32 capacity, u32 size, keys in slot order} each, htab.c:385-389; no header): one rank's share of the
+ * .yak file of a prefix-sharded job; malloc'ed, returns the size or -1 */
+int64_t yakamd_dump_range_mem(yak_ch_t *h, int lo, int hi, uint8_t **out);
 
 /* sub-table shape, for tests: capacity and size of sub-table i (device-authoritative) */
 int yakamd_subtable(yak_ch_t *h, int i, uint32_t *capacity, uint32_t *size);

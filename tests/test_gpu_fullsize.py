@@ -96,3 +96,29 @@ def test_cfg4_5gb_assembly_in_sweeps():
         assert v["distinct"] == 4994315360 and v["yak_size_bytes"] == 16 + 8 * 1024 + 8 * 4994315360
         if sweeps == "2" and gold:
             assert v["equals_golden"] is True and v["yak_md5"] == gold["md5"] and gold["size"] == v["yak_size_bytes"]
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_cfg3_rank_share_equals_oracle(rank):
+    """BASELINE configs[2] (600 M x 150 bp reads, prefix-sharded over 8 GPUs), the only configuration that does not fit one GPU: ONE rank's share of it
+    does.  The rank receives, round after round, the records of its 128 sub-tables from all 8 sources' chunks of the 600 M-read stream -- exactly what
+    the exchange delivers -- and the bytes it contributes to the job's .yak file ({capacity, size, keys in slot order} of its sub-tables,
+    htab.c:385-389) must be those the ORACLE computed over the whole stream (oracle/yko_synth, tests/gen_golden_cfg3.py ->
+    tests/golden/cfg3_full.json: ranks 0 and 5).  Reference: count.c:129-143 (a sub-table is a function of its own put-calls in stream order)."""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_full.json")))
+    d = bench_line("--config", "cfg3shard", "--rank", str(rank))
+    v, ref = d["verify"], gold["ranges"][f"{128 * rank}:{128 * rank + 128}"]
+    assert v["share_equals_oracle"] is True and v["share_md5"] == ref["md5"] and v["share_bytes"] == ref["size"] and v["distinct"] == ref["distinct"]
+    assert v["count_mass_equals_instances"] and v["sum_hist_equals_tot"]
+    assert d["instances_received_per_pass"] == ref["instances"]          # no count saturates at 30x: the mass of the counts is the instances
+    assert d["peak_hbm_bytes_in_the_real_job"] <= 0.9 * 288e9
+
+
+def test_cfg3_rank_shares_at_1m_reads_equal_oracle():
+    """the same procedure at 1 M reads (8 x 125 000, G = 5 Mb), every rank that the golden holds: seconds instead of a minute"""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_full.json")))["procedure_check_1M_reads"]
+    for rng, ref in gold.items():
+        lo = int(rng.split(":")[0])
+        d = bench_line("--config", "cfg3shard", "--rank", str(lo // 128), "--reads", "125000", "--batch-reads", "50000")
+        v = d["verify"]
+        assert v["share_equals_oracle"] is True and v["share_md5"] == ref["md5"] and v["distinct"] == ref["distinct"], (rng, v)

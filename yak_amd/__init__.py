@@ -26,8 +26,8 @@ YAK_H_SYMBOLS = [
 YAK_AMD_H_SYMBOLS = [
     "yakamd_device_count", "yakamd_last_error", "yakamd_ctx_of", "yakamd_set_shard",
     "yakamd_pass_begin", "yakamd_feed_bases_dev", "yakamd_feed_bases_host", "yakamd_feed_packed_dev", "yakamd_pack_bases_dev", "yakamd_packed_bytes", "yakamd_pack_bases_host", "yakamd_feed_packed_host", "yakamd_feed_packed_pieces_host", "yakamd_feed_hashed_dev",
-    "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_subtable",
-    "yakamd_get_stats", "yakamd_trim", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
+    "yakamd_pass_end", "yakamd_extract_dev", "yakamd_sync_host", "yakamd_dump_mem", "yakamd_dump_range_mem", "yakamd_subtable",
+    "yakamd_get_stats", "yakamd_trim", "yakamd_peak_bytes", "yakamd_dev_alloc", "yakamd_dev_free", "yakamd_memcpy_h2d",
     "yakamd_memcpy_d2h", "yakamd_partition_dev", "yakamd_feed_partitioned_dev", "yakamd_debug_counters", "yakamd_count_hashes_dev",
     "yakamd_partition_hashes_dev", "yakamd_count_partitioned_dev", "yakamd_feed_partitioned_lent_dev",
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
@@ -125,6 +125,9 @@ def lib():
     L.yakamd_sync_host.restype = C.c_int; L.yakamd_sync_host.argtypes = [P(ChT)]
     L.yakamd_dump_mem.restype = C.c_int64
     L.yakamd_dump_mem.argtypes = [P(ChT), P(P(C.c_uint8))]
+    L.yakamd_dump_range_mem.restype = C.c_int64
+    L.yakamd_dump_range_mem.argtypes = [P(ChT), C.c_int, C.c_int, P(P(C.c_uint8))]
+    L.yakamd_peak_bytes.restype = C.c_int64; L.yakamd_peak_bytes.argtypes = [C.c_int, C.c_int]
     L.yakamd_subtable.restype = C.c_int
     L.yakamd_subtable.argtypes = [P(ChT), C.c_int, P(C.c_uint32), P(C.c_uint32)]
     L.yakamd_get_stats.restype = C.c_int; L.yakamd_get_stats.argtypes = [P(ChT), P(StatsT)]
@@ -306,6 +309,21 @@ class Table:
         import hashlib
         out = C.POINTER(C.c_uint8)()
         n = self.L.yakamd_dump_mem(self.h, C.byref(out))
+        if n < 0:
+            raise RuntimeError(_err())
+        addr = C.cast(out, C.c_void_p).value
+        h = hashlib.md5()
+        step = 1 << 28
+        for o in range(0, n, step):
+            h.update((C.c_char * min(step, n - o)).from_address(addr + o))
+        C.CDLL(None).free(out)
+        return h.hexdigest(), n
+
+    def range_md5(self, lo, hi):
+        """md5 and size of the bytes of sub-tables [lo, hi) ({capacity, size, keys in slot order} each, no header): one rank's share of the .yak file"""
+        import hashlib
+        out = C.POINTER(C.c_uint8)()
+        n = self.L.yakamd_dump_range_mem(self.h, lo, hi, C.byref(out))
         if n < 0:
             raise RuntimeError(_err())
         addr = C.cast(out, C.c_void_p).value

@@ -118,6 +118,7 @@ struct DevPool {
 	std::multimap<size_t, char*> free_sz;              /* the same ranges by length */
 	std::unordered_map<void*, size_t> live;            /* ranges handed out */
 	size_t cached = 0;                                 /* bytes in free ranges */
+	size_t in_use = 0, peak_in_use = 0;                /* bytes handed out, and their high-water mark (yakamd_peak_bytes) */
 	u64 clock = 0;
 	/* what the driver was asked for (YAKAMD_VERBOSE prints it: a job whose buffers do not come out of the pool pays ~27 ms per GB) */
 	u64 n_malloc = 0, n_release = 0, n_trim = 0; double gb_malloc = 0, ms_malloc = 0, ms_release = 0;
@@ -185,6 +186,7 @@ static void *pool_alloc(size_t bytes)
 			if (have - take < (2u << 20) || bytes < POOL_SPLIT_MIN) take = have;      /* no crumbs; small requests never split */
 			if (have > take) { P.free_at[p + take] = have - take; P.free_sz.insert({ have - take, p + take }); P.cached += have - take; }
 			P.live[p] = take;
+			P.in_use += take; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
 			pool_super_of(P, p)->second.stamp = ++P.clock;
 			return p;
 		}
@@ -199,6 +201,7 @@ static void *pool_alloc(size_t bytes)
 	P.ms_malloc += now_ms() - t0; ++P.n_malloc; P.gb_malloc += (double)bytes / 1e9;
 	P.supers[(char*)p] = DevPool::Super{ bytes, ++P.clock };
 	P.live[p] = bytes;
+	P.in_use += bytes; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
 	return p;
 }
 
@@ -226,12 +229,23 @@ static void pool_free(void *p)
 	if (it == P.live.end()) { (void)hipFree(p); return; }          /* not the pool's */
 	const size_t n = it->second;
 	P.live.erase(it);
+	P.in_use -= n;
 	pool_range_add(P, (char*)p, n);
 	pool_release(P, on ? cap : 0);
 }
 
 size_t yk_pool_cached_bytes(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); return P.cached; }
 
+/* high-water mark of the device memory the library had IN USE on device `dev` (what a job needs; the idle ranges the pool keeps are not in it);
+ * reset != 0 starts a new measurement from what is in use now */
+extern "C" int64_t yakamd_peak_bytes(int dev, int reset)
+{
+	DevPool &P = g_pool[dev & 15];
+	std::lock_guard<std::mutex> lk(P.mu);
+	const int64_t v = (int64_t)P.peak_in_use;
+	if (reset) P.peak_in_use = P.in_use;
+	return v;
+}
 extern "C" void yakamd_trim(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); pool_trim(P); }
 void yk_pool_report(const char *what)
 {
@@ -1770,9 +1784,27 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	 * k-mers far below the table's 624 (30 x coverage: ~100 distinct per 560 instances), and 2048 sub-buckets per sub-table are what the
 	 * level-2 scatter takes in one sweep -- 30 M reads: 13 -> 11 bits, its partition 124 -> ~40 ms.  A sub-bucket that does overflow goes to
 	 * the tiers behind k_lc2, as always */
-	const u64 per_sb = (u64)(c->bloom_mode ? 1800 : 600);
+	const u64 per_sb = (u64)yk_lc2_per_sb(c->bloom_mode);         /* 1800 with a filter; without one 1200 (k_lc2's 2048-slot table) or 600 (the older tiers) */
+	/* the largest stream of one sub-table in this slice: decides whether the level-2 records take 8 bytes (below), which the plan needs */
+	u64 np_max = 0;
+	for (int p = 0; p < P; ++p) { u64 np = 0; for (auto &k : c->kept) np += k.bstart[p + 1] - k.bstart[p]; np_max = std::max(np_max, np); }
+	/* Known before the partition: will every record of this pass stay on the device for the count pass over the same input (keep2 below) while
+	 * the filter is still untouched?  Then nobody reads the filter's bits before the records can rebuild them (bf_nowb), k_lc2 needs no stage of
+	 * the filter in LDS, and a sub-bucket may own 256 blocks instead of 128: half as many, twice as large */
+	bool nowb_plan = false;
+	{
+		size_t fr = 0, tot = 0;
+		const int64_t cap_gb = env_i64("YAKAMD_RETAIN_GB", -1);
+		u64 budget = cap_gb >= 0 ? (u64)cap_gb << 30 : 0;
+		if (cap_gb < 0 && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = tot / 8;
+		nowb_plan = c->bloom_mode && c->bf_virgin && last && c->n_slices == 0 && c->img_keys_total == 0 && c->retain_on && !c->retain_broken && fmt_in == 1 &&
+		            !c->or_mode && c->retained.empty() && c->retained_bytes + n_total * 8 <= budget && c->n_hash <= 32 &&
+		            env_i64("YAKAMD_RETAIN2", 1) != 0 && env_i64("YAKAMD_BF_DEFER", 1) != 0 && env_i64("YAKAMD_LC2", 1) != 0 && env_i64("YAKAMD_LC2_NOSTAGE", 1) != 0;
+		for (auto &k : c->kept) nowb_plan = nowb_plan && k.owned;
+	}
+	const int lb_max = nowb_plan ? 8 : 7;                          /* log2 blocks a sub-bucket may own: k_lc2 stages at most 128; without a stage its table gives every block >= 4 home slots */
 	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
-	if (c->bloom_mode && s2 < c->nb - 9 - 7 && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - 7;   /* k_lc2 stages at most 128 bloom blocks per sub-bucket */
+	if (c->bloom_mode && s2 < c->nb - 9 - lb_max && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - lb_max;
 	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
 	/* one sweep of the level-2 scatter takes up to 2^11 sub-buckets (2^13 in sweeps over the chunk); beyond that -- the share of an N-GPU job's rank:
 	 * 128 sub-tables of 69 M instances each -- the partition takes two sweeps (p3): the high bits first into {hash, rank} records, then 2^p3_low
@@ -1794,7 +1826,8 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.rec8_in = fmt_in; fp.tb = YK_R8_TAG_BITS + s2;
 	fp.rec8_out = 0;                                         /* set below, once the largest sub-table stream is known */
 	if (c->bloom_mode) {
-		if (c->bf_virgin && c->nb - 9 - s2 <= 7) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
+		if (nowb_plan && (YK_R8_TAG_BITS + s2 >= 64 || np_max >= (1ull << (YK_R8_TAG_BITS + s2)) || env_i64("YAKAMD_REC8_OUT", 1) == 0 || c->nb - 9 - s2 > 8 || c->nb - 9 - s2 < 0)) nowb_plan = false;   /* (16-byte level-2 records are not kept; ranges beyond 256 blocks go to the older tiers) */
+		if (c->bf_virgin && c->nb - 9 - s2 <= (nowb_plan ? 8 : 7)) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
 		else if (bloom_materialise(c)) return -1;
 		c->bf_virgin = false;
 	}
@@ -1804,7 +1837,6 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	std::vector<Chunk2> chunks;
 	std::vector<u32> chunk_first(P + 1, 0);
 	std::vector<u64> bbase(P + 1, 0);
-	u64 np_max = 0;
 	for (int p = 0; p < P; ++p) {
 		chunk_first[p] = (u32)chunks.size();
 		u64 np = 0;
@@ -1820,7 +1852,6 @@ static int fast_finish(yakamd_ctx *c, bool last)
 			}
 			np += b - a;
 		}
-		np_max = std::max(np_max, np);
 		bbase[p + 1] = bbase[p] + np;
 		if (chunks.size() > chunk_first[p]) chunks.back().spare = 1;   /* last chunk of its sub-table */
 	}
@@ -1919,21 +1950,30 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	}
 	lap("release / second sweep");
 	/* the keys a sub-bucket selects are written over the front of its own record range in lo.kc / lo.T */
-	if (dmalloc(&lo.kc, n_total) || dmalloc(&lo.T, n_total) || dmalloc(&lo.nsel, n_sb) || dmalloc(&lo.lp, n_sb) || dmalloc(&lo.nd, n_sb) || dmalloc(&d_ndist, P)) return -1;
+	/* 8-byte level-2 records that nobody keeps: the keys go over the records themselves (a workgroup has read all of its sub-bucket's records
+	 * before it writes its first key, and nobody else reads them) -- 8 bytes per record less at the peak of a slice (a cfg3 rank: 71 GB) */
+	const bool kc_inplace = fp.rec8_out && !keep2 && env_i64("YAKAMD_KC_INPLACE", 1) != 0;
+	if (kc_inplace) { lo.kc = (u64*)d_r2; d_r2 = 0; }
+	else if (dmalloc(&lo.kc, n_total)) return -1;
+	if (dmalloc(&lo.T, n_total) || dmalloc(&lo.nsel, n_sb) || dmalloc(&lo.lp, n_sb) || dmalloc(&lo.nd, n_sb) || dmalloc(&d_ndist, P)) return -1;
+	const Rec *lc_rec_in = kc_inplace ? (const Rec*)lo.kc : d_r2;
 	if (c->plo > 0 || c->phi < P) {                              /* sub-buckets outside the shard are never visited */
 		HIPCK(hipMemsetAsync(lo.nsel, 0, n_sb * 4, c->st)); HIPCK(hipMemsetAsync(lo.lp, 0, n_sb * 4, c->st)); HIPCK(hipMemsetAsync(lo.nd, 0, n_sb * 4, c->st));
 	}
 	HIPCK(hipMemsetAsync(d_ndist, 0, P * 4, c->st));
 	HIPCK(hipMemsetAsync(d_segcur, 0, P * 4, c->st));
 	u64 h_cnt[YKC_N];
+	/* every record of the pass stays on the device (keep2) and the filter has never been written: the 2^bf_shift bits are not written at all --
+	 * yak_ch_destroy_bf usually comes next (main.c:55); whatever reads the filter first rebuilds it (bloom_undefer).  nowb_plan said so before the
+	 * partition (sub-buckets of up to 256 blocks, no stage in LDS); with the stage (a plan that was off) the bits are kept in LDS and dropped */
+	fp.bf_nowb = keep2 && fp.bf_virgin && env_i64("YAKAMD_BF_DEFER", 1) != 0 && env_i64("YAKAMD_LC2", 1) != 0 && c->n_hash <= 32;
+	if (nowb_plan && !fp.bf_nowb) return fail("internal: the records of a pass planned without a filter stage are not kept");
 	const bool lc2 = yk_lc2_ok(fp) != 0;
-	/* every record of the pass stays on the device (keep2) and the filter has never been written: k_lc2 keeps the bits in LDS and the 2^bf_shift
-	 * bits are not written at all -- yak_ch_destroy_bf usually comes next (main.c:55); whatever reads the filter first rebuilds it (bloom_undefer) */
-	fp.bf_nowb = lc2 && keep2 && fp.bf_virgin && env_i64("YAKAMD_BF_DEFER", 1) != 0;
+	if (!lc2) fp.bf_nowb = 0;
 	{
 		EvTimer tm(c->st);
-		if (lc2) yk_launch_lc2(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, d_ovf2, c->st);
-		else yk_launch_lds_count(0, fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, 0, 0, d_ovf, c->st);
+		if (lc2) yk_launch_lc2(fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, d_ovf2, c->st);
+		else yk_launch_lds_count(0, fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, 0, 0, d_ovf, c->st);
 		c->ms_lds = tm.stop();
 		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
 	}
@@ -1942,7 +1982,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] %s: %.2f ms, %llu of %zu sub-buckets passed on\n", lc2 ? "k_lc2" : "lds tier G", c->ms_lds, (unsigned long long)(h_cnt[YKC_NOVF] + h_cnt[YKC_NOVF2]), n_sb);
 	if (h_cnt[YKC_NOVF]) {      /* crowded bloom blocks / un-staged range: the tier with sort arrays */
 		EvTimer tm(c->st);
-		yk_launch_lds_count(1, fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
+		yk_launch_lds_count(1, fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
 		c->st_cur.ms_insert += tm.stop();
 		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 		HIPCK(hipStreamSynchronize(c->st));
@@ -1970,7 +2010,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 			if (dmalloc(&d_scr, words)) return -1;
 			HIPCK(hipMemcpyAsync(d_scroff + i0, off.data() + i0, (size_t)(i1 - i0) * 8, hipMemcpyHostToDevice, c->st));
 			EvTimer tm(c->st);
-			yk_launch_lds_count_ovf(fp, d_sbstart, d_r2, c->d_bf, img_view(c), lo, d_ovf2 + i0, i1 - i0, d_scroff + i0, d_scr, c->st);
+			yk_launch_lds_count_ovf(fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, d_ovf2 + i0, i1 - i0, d_scroff + i0, d_scr, c->st);
 			c->st_cur.ms_insert += tm.stop();
 			HIPCK(hipStreamSynchronize(c->st));
 			dfree(d_scr); d_scr = 0;
@@ -2416,7 +2456,7 @@ int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_wor
 	const int P = c->P, n = hi - lo;
 	*d_img = 0; *n_words = 0;
 	if (lo < 0 || hi > P || n <= 0) return fail("yk_ctx_dump_image_dev: sub-tables [%d, %d) of %d", lo, hi, P);
-	std::vector<u64> seg_off(P + 1, 0), head(2 * (size_t)n);
+	std::vector<u64> seg_off(P + 1, ~0ull), head(2 * (size_t)n);     /* ~0: a sub-table outside [lo, hi) is skipped */
 	u64 at = 0;
 	for (int p = lo; p < hi; ++p) {
 		head[p - lo] = at;
@@ -2429,7 +2469,7 @@ int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_wor
 	if (dmalloc(&d_segoff, P + 1) || dmalloc(&d_head, 2 * (size_t)n) || dmalloc(&img, at)) { dfree(img); return -1; }
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_head, head.data(), head.size() * 8, hipMemcpyHostToDevice, c->st));
-	yk_launch_shrink_scatter(img_view(c), P, 0, 1023, 0, img_view(c), d_segoff, img, c->st);   /* (a shard holds nothing outside its own range) */
+	yk_launch_shrink_scatter(img_view(c), P, 0, 1023, 0, img_view(c), d_segoff, img, c->st);
 	yk_launch_put_u64(d_head, d_head + n, (u32)n, img, c->st);
 	HIPCK(hipStreamSynchronize(c->st));                            /* (the two small host arrays and the offsets go away with this call) */
 	*d_img = img; *n_words = at;

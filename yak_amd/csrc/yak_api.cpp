@@ -261,6 +261,7 @@ void yak_ch_tighten(yak_ch_t *h)
  * unfiltered count of a large plain file taken in sweeps); every sub-table belongs to exactly one shard of each operand, and the
  * reference's operations are per sub-table (kt_for over 1 << pre, htab.c:246-347), so they are carried out shard by shard. ---- */
 int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out);
+int64_t yakamd_dump_range_mem(yak_ch_t *h, int lo, int hi, uint8_t **out);
 static std::vector<yak_ch_t*> shards_of(const yak_ch_t *h)
 {
 	const yak_ch_ext *e = (const yak_ch_ext*)h;
@@ -543,6 +544,47 @@ int64_t yakamd_dump_mem(yak_ch_t *h, uint8_t **out)
 	return sz;
 }
 
+/* the bytes of sub-tables [lo, hi) alone -- {capacity, size, keys in slot order} each, no header: what one rank of a prefix-sharded job owns of
+ * the .yak file (tests and bench.py compare a rank's share with the oracle's without serialising the whole table) */
+int64_t yakamd_dump_range_mem(yak_ch_t *h, int lo, int hi, uint8_t **out)
+{
+	*out = 0;
+	yak_ch_ext *e = (yak_ch_ext*)h;
+	const int P = 1 << h->pre, n_sub = YK_MULTI(e) ? e->n_sub : 1;
+	if (lo < 0 || hi > P || lo >= hi) return -1;
+	size_t sz = (size_t)8 * (hi - lo);
+	uint32_t cap, cnt;
+	auto owner_range = [&](int r, int *a, int *b) {
+		*a = YK_MULTI(e) ? (int)(((int64_t)r << h->pre) / n_sub) : 0; *b = YK_MULTI(e) ? (int)(((int64_t)(r + 1) << h->pre) / n_sub) : P;
+		*a = std::max(*a, lo); *b = std::min(*b, hi);
+	};
+	for (int r = 0; r < n_sub; ++r) {
+		int a, b;
+		owner_range(r, &a, &b);
+		yak_ch_t *hs = YK_MULTI(e) ? e->sub[r] : h;
+		for (int p = a; p < b; ++p) { if (yakamd_subtable(hs, p, &cap, &cnt) != 0) return -1; sz += (size_t)8 * cnt; }
+	}
+	DumpSink sink; sink.mem = (uint8_t*)malloc(sz); sink.fd = -1;
+	if (!sink.mem) return -1;
+	size_t off = 0;
+	for (int r = 0; r < n_sub; ++r) {
+		int a, b;
+		owner_range(r, &a, &b);
+		if (a >= b) continue;
+		yakamd_ctx *c = ((yak_ch_ext*)(YK_MULTI(e) ? e->sub[r] : h))->ctx;
+		u64 *d_img = 0, n_words = 0;
+		bool ok = yk_ctx_dump_image_dev(c, a, b, &d_img, &n_words) == 0 && off + (size_t)n_words * 8 <= sz;
+		ok = ok && sink.put(yk_ctx_device(c), yk_ctx_stream(c), (const uint8_t*)d_img, (size_t)n_words * 8, off);
+		(void)hipSetDevice(yk_ctx_device(c));
+		if (d_img) yk_pool_release(d_img);
+		if (!ok) { free(sink.mem); return -1; }
+		off += (size_t)n_words * 8;
+	}
+	if (off != sz) { free(sink.mem); return -1; }
+	*out = sink.mem;
+	return (int64_t)sz;
+}
+
 int yak_ch_dump(const yak_ch_t *h, const char *fn)
 {
 	struct stat sb;
@@ -565,6 +607,7 @@ int yak_ch_dump(const yak_ch_t *h, const char *fn)
 		if (sink.fd < 0) return -1;
 		const int64_t sz = dump_through((yak_ch_t*)h, &sink, false);
 		const bool cut = sz >= 0 && ::ftruncate(sink.fd, (off_t)sz) == 0;
+		if (sz < 0) (void)::ftruncate(sink.fd, 0);                  /* a dump that failed midway leaves an empty file, not a header in front of old bytes (fopen "wb", htab.c:377, never keeps any) */
 		if (::close(sink.fd) != 0 || !cut) return -1;
 		if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] dump: %.1f MB in %.3f s\n", sz / 1e6, yk_realtime() - t0);
 	}

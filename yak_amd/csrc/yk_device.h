@@ -217,6 +217,7 @@ size_t yk_count_own_lds(u32 range_len, u32 kmax);
 int yk_launch_img_count_own(const void *rec, int hash_only, int cross, int ytag, const u64 *bstart, ImgView img, int plo, int phi, int rb, int rng_log, u32 kmax,
                             size_t lds, u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
 int yk_lc2_ok(FastParams fp);
+int yk_lc2_per_sb(int bloom_mode);
 void yk_launch_lc2(FastParams fp, const u64 *sbstart, const Rec *rec, u32 *bloom32, ImgView img, LcOut O, u64 *counters, u32 *ovf_list, hipStream_t st);
 void yk_launch_lc_sum(const u32 *nsel, int s2_bits, int plo, int phi, u32 *seg_cnt, hipStream_t st);
 void yk_launch_lc_compact(LcOut O, const u64 *sbstart, int s2_bits, int plo, int phi, u64 t_pass0, const u64 *seg_base,
