@@ -2323,14 +2323,20 @@ static int rebuild(yakamd_ctx *c, int cmin, int cmax, int which, yakamd_ctx *oth
 	std::vector<u64> seg_off(P + 1, 0);
 	u32 *d_segcnt = 0; u64 *d_segoff = 0, *d_kc = 0;
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() { dfree(d_segcnt); dfree(d_segoff); dfree(d_kc); } };
-	if (dmalloc(&d_segcnt, P) || dmalloc(&d_segoff, P + 1)) return -1;
-	yk_launch_shrink_count(img_view(c), P, cmin, cmax, which, ov, d_segcnt, c->st);
-	HIPCK(hipMemcpyAsync(m.data(), d_segcnt, P * 4, hipMemcpyDeviceToHost, c->st));
+	const int RG = yk_shrink_shares();                            /* workgroups per sub-table */
+	std::vector<u32> mr((size_t)P * RG);
+	if (dmalloc(&d_segcnt, (size_t)P * RG) || dmalloc(&d_segoff, P + 1)) return -1;
+	yk_launch_shrink_count(img_view(c), P, cmin, cmax, which, ov, d_segcnt, c->st, 1);
+	HIPCK(hipMemcpyAsync(mr.data(), d_segcnt, mr.size() * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	for (int p = 0; p < P; ++p) { seg_off[p + 1] = seg_off[p] + m[p]; init[p] = kh_bits_for(c->h_count[p]); }
+	for (int p = 0; p < P; ++p) {
+		m[p] = 0;
+		for (int g = 0; g < RG; ++g) m[p] += mr[(size_t)p * RG + g];
+		seg_off[p + 1] = seg_off[p] + m[p]; init[p] = kh_bits_for(c->h_count[p]);
+	}
 	if (dmalloc(&d_kc, seg_off[P])) return -1;
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, which, ov, d_segoff, d_kc, c->st);
+	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, which, ov, d_segoff, d_kc, c->st, d_segcnt);
 	EvTimer tm(c->st);
 	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
 	c->st_last.ms_shrink = tm.stop();

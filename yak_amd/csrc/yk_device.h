@@ -121,8 +121,9 @@ void yk_launch_replay(const ReplayTask *tasks, int n_tasks, int n_threads, const
                       u64 *new_keys, u32 *new_used, u32 *scr_used, u32 *scr_owner, u64 *scr_par,
                       const u64 *rec_kc, const u64 *rec_t, const u64 *lastput,
                       u32 *out_bits, u32 *out_count, u32 lds_words, hipStream_t st);
-void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, int which, ImgView other, u32 *seg_cnt, hipStream_t st);
-void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, int which, ImgView other, const u64 *seg_off, u64 *rec_kc, hipStream_t st);
+int yk_shrink_shares(void);
+void yk_launch_shrink_count(ImgView img, int P, int cmin, int cmax, int which, ImgView other, u32 *seg_cnt, hipStream_t st, int rng = 0);
+void yk_launch_shrink_scatter(ImgView img, int P, int cmin, int cmax, int which, ImgView other, const u64 *seg_off, u64 *rec_kc, hipStream_t st, const u32 *rng_cnt = 0);
 struct ResizeTask { u32 old_bits, new_bits, rehash, pad; u64 old_off, new_off; };
 void yk_launch_resize(const ResizeTask *tasks, int P, const u64 *old_keys, const u32 *old_used, u64 *new_keys, u32 *new_used, u32 *scr_used, hipStream_t st);
 void yk_launch_keys_to_hashes(const u64 *kc, const u64 *seg_off, int P, int pre, u64 *hash, u32 *t, hipStream_t st);
