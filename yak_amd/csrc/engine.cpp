@@ -971,20 +971,6 @@ static int fast_keep(yakamd_ctx *c, u64 n_rec)
 	return 0;
 }
 
-/* The level-1 partition of tagged records extracts and hashes every k-mer in its histogram sweep and again in its scatter sweep -- unless the first
- * sweep may leave the hashes behind: 8 bytes per stream position (whole 4096-position tiles) until the second sweep has read them.  Taken when that
- * much is idle anyway (a quarter of what the device and the pool have free at most): NULL otherwise, and the sweeps recompute */
-static u64 *hash_stream_alloc(int64_t n_pos)
-{
-	if (env_i64("YAKAMD_HASH_ONCE", 1) == 0 || n_pos <= 0) return 0;
-	const size_t words = ((size_t)n_pos + 4095) / 4096 * 4096;
-	size_t fr = 0, tot = 0;
-	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 0; }
-	if (words * 8 > (fr + yk_pool_cached_bytes()) / 4) return 0;
-	u64 *p = 0;
-	if (dmalloc(&p, words)) { g_err[0] = 0; return 0; }
-	return p;
-}
 static int feed_image(yak_ch_t *h, const void *d_bases, const u32 *d_valid, int64_t n_bytes, uint64_t t0);
 extern "C" int yakamd_feed_bases_dev(yak_ch_t *h, const void *d_bases, int64_t n_bytes, uint64_t t0) { return feed_image(h, d_bases, 0, n_bytes, t0); }
 /* the same stream at 0.375 bytes per base: 2-bit codes, 16 bases per 32-bit word (base j at bits 2 (j % 16)), and a validity bit
@@ -1028,14 +1014,11 @@ static int feed_image(yak_ch_t *h, const void *d_bases, const u32 *d_valid, int6
 			if (!c->fast) { if (rec_reserve(c, bmax)) return -1; out = c->d_rec; }   /* the pass has just left the fast path */
 		}
 		{
-			const bool tagged = c->fast && c->kept.back().fmt;
-			u64 *d_hs = tagged ? hash_stream_alloc(end - pos) : 0;          /* 8 bytes per position for the length of the two sweeps, if they are to be had */
 			EvTimer tm(c->st);
 			yk_launch_xpart((const uint8_t*)d_bases, pos, end, pos, c->k, c->pre, c->plo, c->phi, c->nb_bits,
-			                c->d_rows, c->d_partial, c->d_bstart, out, tagged ? 2 : hash_only, c->st, d_valid, d_hs);
+			                c->d_rows, c->d_partial, c->d_bstart, out, (c->fast && c->kept.back().fmt) ? 2 : hash_only, c->st, d_valid);
 			HIPCK(hipMemcpyAsync(&n_rec, c->d_bstart + ((size_t)1 << c->nb_bits), 8, hipMemcpyDeviceToHost, c->st));
-			c->st_cur.ms_extract += tm.stop();                            /* (waits for the stream: the sweeps are through) */
-			dfree(d_hs);
+			c->st_cur.ms_extract += tm.stop();
 		}
 		if (c->fast) { if (fast_keep(c, n_rec)) return -1; if (t0 + (u64)end > c->t_end) c->t_end = t0 + (u64)end; continue; }
 		if (consume_records(c, (int64_t)n_rec, t0 + (u64)pos, t0 + (u64)pos, t0 + (u64)end, c->d_bstart, hash_only ? 1 : 0, ytag)) return -1;
@@ -1129,10 +1112,9 @@ static int64_t partition_dev(int k, int pre, const void *d_bases, int64_t n_byte
 	const int n_blk = yk_xpart_blocks(n_bytes);
 	u32 *d_rows = 0; u64 *d_partial = 0, *d_bstart = 0;
 	if (dmalloc(&d_rows, NB * (size_t)n_blk) || dmalloc(&d_partial, NB * yk_part_groups()) || dmalloc(&d_bstart, NB + 1)) return -1;
-	u64 *d_hs = hash_only == 2 ? hash_stream_alloc(n_bytes) : 0;
-	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_out, hash_only, 0, 0, d_hs);
+	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_out, hash_only, 0);
 	const hipError_t e = hipMemcpy(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost);
-	dfree(d_rows); dfree(d_partial); dfree(d_bstart); dfree(d_hs);
+	dfree(d_rows); dfree(d_partial); dfree(d_bstart);
 	if (e != hipSuccess) { fail("partition: %s", hipGetErrorString(e)); return -1; }
 	return (int64_t)h_bstart[NB];
 }

@@ -73,7 +73,7 @@ void yk_launch_extract(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_
                        u64 *out_hash, u32 *out_t, u64 *cursor, hipStream_t st);
 void yk_launch_pack(const uint8_t *a, int64_t n, u32 *codes, u32 *valid, hipStream_t st);
 void yk_launch_xpart(const uint8_t *bases, int64_t pos0, int64_t n, int64_t t_sub, int k, int pre, int plo, int phi,
-                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st, const u32 *valid = 0, u64 *hs = 0);   /* hs != 0 (tagged records only): room for one u64 per stream position from pos0 on, rounded up to 4096 -- the k-mers are extracted and hashed once */   /* valid != 0: `bases` is the packed 2-bit image (yakamd_feed_packed_dev) */   /* hash_only: 0 = Rec, 1 = bare hashes, 2 = tagged 8-byte records */
+                     int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, int hash_only, hipStream_t st, const u32 *valid = 0);   /* valid != 0: `bases` is the packed 2-bit image (yakamd_feed_packed_dev) */   /* hash_only: 0 = Rec, 1 = bare hashes, 2 = tagged 8-byte records */
 void yk_launch_rpart(const u64 *in_hash, const u32 *in_t, int64_t n, int pre, int plo, int phi,
                      int nb_bits, u32 *rows, u64 *partial, u64 *bstart, Rec *out, hipStream_t st);
 int yk_xpart_blocks(int64_t n_pos);
