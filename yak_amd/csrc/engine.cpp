@@ -191,24 +191,16 @@ static void *pool_alloc(size_t bytes)
 			return p;
 		}
 	}
-	/* Large requests are cut from superblocks of at least POOL_QUANTUM: the free ranges of ONE superblock join each other, those of two never do, and a
-	 * job of the larger configurations that took every buffer from the driver at its own size ended with twice its peak in superblocks (5 Gb assembly:
-	 * 329 GB obtained, one trim on the way, for 188 GB in use at the peak) -- at ~30 ms per GB beyond the first ~112 GB a fresh process gets from this
-	 * driver at no cost (tests/tools/mb/mb_malloc.hip).  Small requests keep superblocks of their own size */
 	void *p = 0;
 	const double t0 = now_ms();
-	static const size_t quantum = (size_t)std::max<int64_t>(0, yk_knob("YAKAMD_POOL_QUANTUM_MB", 16384)) << 20;
-	size_t sb = bytes >= POOL_SPLIT_MIN && bytes < quantum ? quantum : bytes;
-	if (sb > bytes && hipMalloc(&p, sb) != hipSuccess) { (void)hipGetLastError(); p = 0; sb = bytes; }
-	if (!p && hipMalloc(&p, bytes) != hipSuccess) {
+	if (hipMalloc(&p, bytes) != hipSuccess) {
 		(void)hipGetLastError();
 		pool_trim(P);
 		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	}
-	P.ms_malloc += now_ms() - t0; ++P.n_malloc; P.gb_malloc += (double)sb / 1e9;
-	P.supers[(char*)p] = DevPool::Super{ sb, ++P.clock };
+	P.ms_malloc += now_ms() - t0; ++P.n_malloc; P.gb_malloc += (double)bytes / 1e9;
+	P.supers[(char*)p] = DevPool::Super{ bytes, ++P.clock };
 	P.live[p] = bytes;
-	if (sb > bytes) { P.free_at[(char*)p + bytes] = sb - bytes; P.free_sz.insert({ sb - bytes, (char*)p + bytes }); P.cached += sb - bytes; }
 	P.in_use += bytes; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
 	return p;
 }
