@@ -16,9 +16,14 @@ yak_amd/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/kern_*.inc) $(CSRC)/yk
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 yak_amd/engine.o: $(CSRC)/engine.cpp $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-yak_amd/yak_api.o: $(CSRC)/yak_api.cpp $(CSRC)/pgz.h $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
+HOSTDEPS = $(CSRC)/yak_host.h $(CSRC)/pgz.h $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
+yak_amd/yak_api.o: $(CSRC)/yak_api.cpp $(HOSTDEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/engine.o yak_amd/yak_api.o
+yak_amd/yak_reader.o: $(CSRC)/yak_reader.cpp $(HOSTDEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+yak_amd/yak_multi.o: $(CSRC)/yak_multi.cpp $(HOSTDEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/engine.o yak_amd/yak_api.o yak_amd/yak_reader.o yak_amd/yak_multi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-Bsymbolic -o $@ $^ -lz
 
 yak_amd/yak-amd: $(CSRC)/main.c include/yak.h yak_amd/libyak_amd.so

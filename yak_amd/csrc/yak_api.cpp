@@ -6,37 +6,7 @@
  * input file, staging bases, writing the .yak file from the host mirror.  All counting, bloom
  * gating, table layout, clearing and shrinking run in the HIP kernels of kernels.hip.
  */
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <ctype.h>
-#include <assert.h>
-#include <zlib.h>
-#include <sys/time.h>
-#include <sys/resource.h>
-#include <fcntl.h>
-#include <unistd.h>
-#include <cstdarg>
-#include <thread>
-#include <functional>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <vector>
-#include <map>
-#include <algorithm>
-#include <string>
-#include <mutex>
-#include <condition_variable>
-#include <cmath>
-#include "engine.h"
-#include <dlfcn.h>
-#include <immintrin.h>
-#include "pgz.h"                                            /* parallel inflate of ordinary gzip files */
-#include <rccl/rccl.h>                                   /* types and prototypes only: the library is opened when a job asks for several GPUs */
-
-struct yak_ht_t { uint32_t bits, count; uint32_t *used; uint64_t *keys; };
-struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; uint32_t magic; int n_sub; yak_ch_t **sub; };   /* n_sub > 1: sharded over several GPUs, sub[r] owns prefixes [r P / n_sub, (r + 1) P / n_sub) */
-#define EXT_MAGIC 0x59414b41u
+#include "yak_host.h"
 
 extern "C" {
 
@@ -56,8 +26,9 @@ unsigned char seq_nt4_table[256] = {                         /* reference misc.c
 #undef R4
 };
 
+} /* extern "C" */
 static double yk_realtime0 = -1;
-static double yk_realtime(void)
+double yk_realtime(void)                                     /* (C++ linkage, as yak_host.h declares them) */
 {
 	struct timeval tp;
 	gettimeofday(&tp, 0);
@@ -65,12 +36,13 @@ static double yk_realtime(void)
 	if (yk_realtime0 < 0) yk_realtime0 = t;
 	return t - yk_realtime0;
 }
-static double yk_cputime(void)
+double yk_cputime(void)
 {
 	struct rusage r;
 	getrusage(RUSAGE_SELF, &r);
 	return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
 }
+extern "C" {
 
 void yak_copt_init(yak_copt_t *o)                            /* reference misc.c:23-32 */
 {
@@ -131,8 +103,6 @@ yak_ch_t *yak_ch_init(int k, int pre, int n_hash, int n_shift)
 	return h;
 }
 
-#define YK_MULTI(e) ((e)->n_sub > 1)
-static void multi_tot(yak_ch_t *h) { yak_ch_ext *e = (yak_ch_ext*)h; uint64_t t = 0; for (int r = 0; r < e->n_sub; ++r) t += e->sub[r]->tot; h->tot = t; }
 static int multi_refuse(const yak_ch_t *h, const char *what)
 {
 	if (!YK_MULTI((const yak_ch_ext*)h)) return 0;
@@ -736,1208 +706,6 @@ yak_ch_t *yak_ch_restore_core(yak_ch_t *ch0, const char *fn, int mode, ...)
 
 yak_ch_t *yak_ch_restore(const char *fn) { return yak_ch_restore_core(0, fn, YAK_LOAD_ALL); }   /* reference htab.c:478 */
 
-/* ------------------------------------------------------------------------------------------
- * FASTA/FASTQ record reader with the observable behaviour of the reference's parser as driven by
- * count.c:88-110 (record grammar of kseq.h:192-232): header lines start with '>' or '@', the
- * sequence is every following line up to one starting with '>', '@' or '+', a '+' line introduces
- * quality lines covering at least the sequence length; a truncated quality ends the input.
- * ------------------------------------------------------------------------------------------ */
-extern "C++" {
-/* What the parallel parser reads: a plain file, or the uncompressed stream of a BGZF file (block gzip: every member carries its
- * compressed size in a 'BC' extra field and holds <= 64 KiB of data, so members can be found without inflating and inflated
- * independently).  A read at any offset inflates just the blocks it touches, on the calling thread -- the parser's threads each
- * read their own segment, so inflation is spread over them by itself.  libdeflate is used when the image has it, else zlib. */
-struct ByteSource {
-	struct Blk { int64_t foff, uoff; uint32_t csize, usize; };   /* offset of the deflate payload, offset in the uncompressed stream, bytes of both */
-	int fd; int64_t size; bool bgzf; std::vector<Blk> blk;
-	uint64_t gen;                                                 /* identity of this source for the per-thread block cache (an address can be reused by the next job's source) */
-	const unsigned char *map; size_t map_len;                     /* a plain file, mapped: the body of a long FASTA record is stripped of its line ends by several threads straight from here */
-	bool pack;                                                    /* the parser threads also pack what they parsed (yakamd_pack_bases_host) */
-	bool in_memory, partial;                                      /* bytes in memory (a batch of an inflated gzip stream; map is not ours); more of the stream follows them: a record that touches their end is not finished */
-	static uint64_t next_gen() { static uint64_t g = 0; return __atomic_add_fetch(&g, 1, __ATOMIC_RELAXED); }
-	ByteSource() : fd(-1), size(0), bgzf(false), gen(next_gen()), map(0), map_len(0), pack(false), in_memory(false), partial(false) {}
-	~ByteSource() { if (map && !in_memory) munmap((void*)map, map_len); }
-	void set_memory(const unsigned char *p, size_t n, bool more_follows) { fd = -1; bgzf = false; map = p; map_len = n; size = (int64_t)n; in_memory = true; partial = more_follows; }
-	ByteSource(const ByteSource&) = delete; ByteSource &operator=(const ByteSource&) = delete;
-	void map_plain() {
-		if (bgzf || fd < 0 || size <= 0 || map) return;
-		void *m = mmap(0, (size_t)size, PROT_READ, MAP_PRIVATE, fd, 0);
-		if (m != MAP_FAILED) { map = (const unsigned char*)m; map_len = (size_t)size; (void)madvise(m, map_len, MADV_SEQUENTIAL); }
-	}
-	typedef void *(*ld_alloc_t)(void); typedef int (*ld_dec_t)(void*, const void*, size_t, void*, size_t, size_t*); typedef void (*ld_free_t)(void*);
-	static void ld_api(ld_alloc_t *al, ld_dec_t *de, ld_free_t *fr = 0) {
-		static ld_alloc_t a = 0; static ld_dec_t d = 0; static ld_free_t f = 0; static bool tried = false;
-		if (!tried) {                                              /* benign race: every thread resolves the same pointers */
-			void *l = yk_knob("YAKAMD_NO_LIBDEFLATE", 0) ? 0 : dlopen("libdeflate.so.0", RTLD_NOW);
-			if (l) { a = (ld_alloc_t)dlsym(l, "libdeflate_alloc_decompressor"); d = (ld_dec_t)dlsym(l, "libdeflate_deflate_decompress"); f = (ld_free_t)dlsym(l, "libdeflate_free_decompressor"); }
-			if (!a || !d) { a = 0; d = 0; f = 0; }
-			tried = true;
-		}
-		*al = a; *de = d; if (fr) *fr = f;
-	}
-	/* per-thread inflate state, released when the thread ends (the parser starts fresh threads for every window) */
-	struct LdState { void *dec; ld_free_t fr; LdState() : dec(0), fr(0) {} ~LdState() { if (dec && fr) fr(dec); } };
-	struct ZState { z_stream zs; bool init; ZState() : init(false) { memset(&zs, 0, sizeof(zs)); } ~ZState() { if (init) inflateEnd(&zs); } };
-	/* index the members of an open file; false if it is not BGZF from the first byte to the last */
-	bool index_bgzf(int f) {
-		struct stat sb;
-		if (fstat(f, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
-		int64_t off = 0, uoff = 0;
-		unsigned char h[18], t[4];
-		blk.clear();
-		while (off < sb.st_size) {
-			if (::pread(f, h, 18, off) != 18) return false;
-			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
-			const uint32_t xlen = h[10] | h[11] << 8;
-			/* the 'BC' subfield is the first one in every BGZF writer; anything else is not indexed */
-			if (xlen < 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0 || (h[3] & ~4)) return false;
-			const uint32_t bsize = (h[16] | h[17] << 8) + 1u;
-			if (bsize < 12 + xlen + 8 || off + bsize > sb.st_size) return false;
-			if (::pread(f, t, 4, off + bsize - 4) != 4) return false;
-			const uint32_t isize = t[0] | t[1] << 8 | t[2] << 16 | (uint32_t)t[3] << 24;
-			if (isize > 65536) return false;
-			Blk b; b.foff = off + 12 + xlen; b.csize = bsize - 12 - xlen - 8; b.uoff = uoff; b.usize = isize;
-			if (isize) blk.push_back(b);
-			off += bsize; uoff += isize;
-		}
-		fd = f; size = uoff; bgzf = true;
-		return true;
-	}
-	bool inflate_block(const Blk &b, unsigned char *out, std::vector<unsigned char> &cbuf) const {
-		cbuf.resize(b.csize + 8);
-		size_t got = 0;
-		while (got < b.csize + 8) { const ssize_t r = ::pread(fd, cbuf.data() + got, b.csize + 8 - got, b.foff + got); if (r <= 0) return false; got += r; }
-		ld_alloc_t al; ld_dec_t de; ld_api(&al, &de);
-		bool ok = false;
-		if (al) {
-			static thread_local LdState st;
-			if (!st.dec) { st.dec = al(); ld_free_t fr = 0; ld_api(&al, &de, &fr); st.fr = fr; }
-			size_t n = 0;
-			ok = st.dec && de(st.dec, cbuf.data(), b.csize, out, b.usize, &n) == 0 && n == b.usize;
-		} else {
-			static thread_local ZState st;
-			z_stream &zs = st.zs;
-			if (!st.init) { if (inflateInit2(&zs, -15) != Z_OK) return false; st.init = true; } else inflateReset(&zs);
-			zs.next_in = cbuf.data(); zs.avail_in = b.csize; zs.next_out = out; zs.avail_out = b.usize;
-			ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
-		}
-		if (!ok) return false;
-		const unsigned char *t = cbuf.data() + b.csize;            /* CRC32 of the uncompressed data, as gzread would check it */
-		const uint32_t crc = t[0] | t[1] << 8 | t[2] << 16 | (uint32_t)t[3] << 24;
-		return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, b.usize) == crc;
-	}
-	/* pread(2) semantics on the uncompressed stream; -1 on a corrupt block */
-	ssize_t pread_at(void *dst, size_t n, int64_t off) const {
-		if (in_memory) { if (off >= size || n == 0) return 0; const size_t take = std::min<size_t>(n, (size_t)(size - off)); memcpy(dst, map + off, take); return (ssize_t)take; }
-		if (!bgzf) return ::pread(fd, dst, n, off);
-		if (off >= size || n == 0) return 0;
-		static thread_local std::vector<unsigned char> ub, cb;
-		static thread_local uint64_t who = 0; static thread_local size_t which = (size_t)-1;
-		size_t lo = 0, hi = blk.size();                            /* the block that holds `off` */
-		while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (blk[mid].uoff <= off) lo = mid; else hi = mid; }
-		size_t done = 0;
-		for (size_t bi = lo; bi < blk.size() && done < n; ++bi) {
-			const Blk &b = blk[bi];
-			if (who != gen || which != bi) {
-				ub.resize(65536);
-				if (!inflate_block(b, ub.data(), cb)) { who = 0; return -1; }
-				who = gen; which = bi;
-			}
-			const size_t skip = (size_t)(off + (int64_t)done - b.uoff), take = std::min<size_t>(b.usize - skip, n - done);
-			memcpy((char*)dst + done, ub.data() + skip, take);
-			done += take;
-		}
-		return (ssize_t)done;
-	}
-};
-
-struct FxReader {
-	gzFile fp; int fd; unsigned char *buf; int beg, end, eof, last;
-	std::vector<char> seq, name; size_t qlen; int qlast;
-	enum { BUF = 1 << 20, NOT_FAST = -3 };
-	FxReader() : fp(0), fd(-1), buf(0), beg(0), end(0), eof(0), last(0), qlen(0), qlast(0), mem(false), psrc(0), poff(0), pos0(0) {}
-	/* open `fn` (NULL or "-": stdin); a plain (not gzip) regular file is then read with read(2), skipping zlib's copy */
-	bool open_file(const char *fn) {
-		const bool is_stdin = fn == 0 || strcmp(fn, "-") == 0;
-		fp = is_stdin ? gzdopen(0, "r") : gzopen(fn, "r");
-		if (fp == 0) return false;
-		gzbuffer(fp, 1 << 20);                               /* zlib's default 8 KB means a read() per 8 KB */
-		if (!is_stdin && gzdirect(fp)) fd = ::open(fn, O_RDONLY);
-		buf = (unsigned char*)malloc(BUF);
-		return true;
-	}
-	void close_file() { if (fd >= 0) ::close(fd); if (fp) gzclose(fp); if (!mem) free(buf); fp = 0; fd = -1; buf = 0; }
-	/* positional mode for the parallel parser: read a shared source (plain file or BGZF stream) from offset `from` */
-	bool mem; const ByteSource *psrc; int64_t poff, pos0;
-	void open_at(const ByteSource *src, int64_t from) { psrc = src; poff = pos0 = from; buf = (unsigned char*)malloc(BUF); beg = end = 0; eof = 0; last = 0; }
-	void close_at() { free(buf); buf = 0; }
-	/* consume up to the next record marker ('>' or '@', kseq.h:196-199) so that `last` holds it; false at EOF */
-	bool seek_marker() {
-		if (last != 0) return true;
-		int c;
-		while ((c = getc()) != -1 && c != '>' && c != '@') {}
-		if (c == -1) return false;
-		last = c;
-		return true;
-	}
-	int64_t marker_pos() const { return pos0 + (last != 0 ? beg - 1 : end); }   /* file offset of the marker `last` was read from (positional mode) */
-	bool fill() {
-		if (beg < end) return true;
-		if (eof) return false;
-		beg = 0;
-		if (psrc) {
-			pos0 = poff; end = 0;
-			while (end < BUF) { const ssize_t r = psrc->pread_at(buf + end, BUF - end, poff); if (r <= 0) break; end += (int)r; poff += r; }
-		} else if (fd >= 0) {                                /* read(2) may return short counts before EOF */
-			end = 0;
-			while (end < BUF) { const ssize_t r = ::read(fd, buf + end, BUF - end); if (r <= 0) break; end += (int)r; }
-		} else end = gzread(fp, buf, BUF);
-		if (end < BUF) eof = 1;
-		if (end <= 0) { end = 0; return false; }
-		return true;
-	}
-	int getc() { return fill() ? buf[beg++] : -1; }
-	/* consume through the next delimiter; what: 0 discard, 1 append to seq, 2 count quality bytes, 3 append to name */
-	int until(bool line, int what, int *dret) {
-		if (dret) *dret = 0;
-		if (beg >= end && eof) return -1;
-		while (fill()) {
-			int i = beg;
-			if (line) { const unsigned char *q = (const unsigned char*)memchr(buf + beg, '\n', end - beg); i = q ? (int)(q - buf) : end; }
-			else while (i < end && !isspace(buf[i])) ++i;
-			if (what == 1) seq.insert(seq.end(), buf + beg, buf + i);
-			else if (what == 3) name.insert(name.end(), buf + beg, buf + i);
-			else if (what == 2 && i > beg) { qlen += i - beg; qlast = buf[i - 1]; }
-			const bool hit = i < end;
-			if (hit && dret) *dret = buf[i];
-			beg = i + 1;
-			if (hit) break;
-		}
-		if (line && what == 1 && seq.size() > 1 && seq.back() == '\r') seq.pop_back();
-		if (line && what == 2 && qlen > 1 && qlast == '\r') { --qlen; qlast = 0; }
-		return 0;
-	}
-	/* Fast path for the record shapes real files are made of -- header line, ONE sequence line, and
-	 * either the next record's marker (FASTA) or a '+' line and ONE quality line of the same length
-	 * (FASTQ) -- when all of it, plus the byte after it, already sits in the buffer: located with
-	 * memchr and appended to `out` (sequence + '\n') straight from the buffer if it has >= min_len
-	 * bases.  The reader state it leaves is exactly what next() would leave; anything else (blank or
-	 * wrapped lines, CR, a record cut by the buffer end, EOF) returns NOT_FAST without touching the
-	 * state, and the caller takes next(). */
-	template <class V> int64_t fast(V &out, int64_t min_len) {
-		const unsigned char *b = buf;
-		int p = beg;
-		if (p >= end) return NOT_FAST;
-		if (last == 0) { if (b[p] != '@' && b[p] != '>') return NOT_FAST; ++p; }
-		const unsigned char *q = (const unsigned char*)memchr(b + p, '\n', end - p);
-		if (!q) return NOT_FAST;
-		const int s0 = (int)(q - b) + 1;
-		if (s0 >= end) return NOT_FAST;
-		const int c0 = b[s0];
-		if (c0 == '\n' || c0 == '>' || c0 == '+' || c0 == '@') return NOT_FAST;
-		q = (const unsigned char*)memchr(b + s0, '\n', end - s0);
-		if (!q) return NOT_FAST;
-		const int s1 = (int)(q - b), slen = s1 - s0, n0 = s1 + 1;
-		if (b[s1 - 1] == '\r' || n0 >= end) return NOT_FAST;
-		int nbeg, nlast;
-		if (b[n0] == '>' || b[n0] == '@') { nlast = b[n0]; nbeg = n0 + 1; }
-		else if (b[n0] == '+') {
-			q = (const unsigned char*)memchr(b + n0, '\n', end - n0);
-			if (!q) return NOT_FAST;
-			const int q0 = (int)(q - b) + 1;
-			if ((int64_t)q0 + slen + 1 >= end) return NOT_FAST;
-			if (b[q0 + slen] != '\n' || memchr(b + q0, '\n', slen)) return NOT_FAST;
-			if (slen > 1 && b[q0 + slen - 1] == '\r') return NOT_FAST;
-			nlast = 0; nbeg = q0 + slen + 1;
-		} else return NOT_FAST;
-		if (slen >= min_len) { out.insert(out.end(), b + s0, b + s1); out.push_back('\n'); }
-		beg = nbeg; last = nlast;
-		return slen;
-	}
-	/* The body of a long FASTA record (a chromosome: 1.7 M lines), from a mapped plain file: `n_thr` threads each take a range of the bytes from
-	 * `from` on, walk the lines that START in their range -- a line that begins with '>', '@' or '+' ends the body (kseq.h:209) -- and count the
-	 * bytes the lines contribute (kseq.h:145: a '\r' before the line end is dropped; the sequence is longer than one byte here); then every thread
-	 * copies its lines to their place in `out`.  Returns the offset where the body scan stopped (a line start: the marker line, or the end of
-	 * the span / file); out grows by the body's bytes.  `from` must be a line start */
-	template <class V> int64_t bulk_body(V &out, int64_t from, int n_thr) {
-		const unsigned char *m = psrc->map;
-		if (n_thr > 64) n_thr = 64;
-		/* a span of 4 MB per thread: a body of 100 MB then keeps every thread busy for several spans (with one span of 1 GB cut into n_thr parts the
-		 * first three parts held the whole body and the other threads walked the records behind it for nothing) */
-		const int64_t fend = (int64_t)psrc->map_len, span_end = std::min<int64_t>(fend, from + std::max<int64_t>((int64_t)8 << 20, (int64_t)n_thr << 22));
-		const int64_t step = (span_end - from + n_thr - 1) / n_thr;
-		struct Part { int64_t a, stop, bytes; bool hit; };
-		std::vector<Part> part(n_thr);
-		int64_t first_hit = INT64_MAX;                                  /* where the body was seen to end: the threads behind it stop counting (their part is not the body's) */
-		auto walk = [&](int t, char *dst) {                             /* dst == 0: count; else copy */
-			Part &P = part[t];
-			int64_t p = P.a;
-			const int64_t lim = dst ? P.stop : std::min<int64_t>(span_end, from + (int64_t)(t + 1) * step);
-			int64_t nb = 0;
-			bool hit = false;
-			unsigned n_line = 0;
-			while (p < lim) {                                          /* p is a line start */
-				const unsigned char c = m[p];
-				if (c == '>' || c == '@' || c == '+') {
-					hit = true;
-					if (!dst) { int64_t cur = __atomic_load_n(&first_hit, __ATOMIC_RELAXED); while (p < cur && !__atomic_compare_exchange_n(&first_hit, &cur, p, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
-					break;
-				}
-				if (!dst && (++n_line & 255) == 0 && P.a > __atomic_load_n(&first_hit, __ATOMIC_RELAXED)) break;
-				const unsigned char *q = (const unsigned char*)memchr(m + p, '\n', (size_t)(fend - p));
-				const int64_t e = q ? (int64_t)(q - m) : fend;
-				int64_t len = e - p;
-				if (len > 0 && m[e - 1] == '\r') --len;
-				if (dst) memcpy(dst + nb, m + p, (size_t)len);
-				nb += len;
-				p = q ? e + 1 : fend;
-			}
-			if (!dst) { P.stop = p; P.bytes = nb; P.hit = hit; }
-		};
-		std::vector<std::thread> th;
-		for (int t = 0; t < n_thr; ++t) {
-			int64_t a = from + (int64_t)t * step;
-			if (t > 0 && a < span_end) {                                /* first line start at or behind the cut */
-				const unsigned char *q = (const unsigned char*)memchr(m + a - 1, '\n', (size_t)(fend - (a - 1)));
-				a = q ? (int64_t)(q - m) + 1 : fend;
-			}
-			part[t].a = std::min(a, span_end); part[t].stop = part[t].a; part[t].bytes = 0; part[t].hit = false;
-		}
-		for (int t = 1; t < n_thr; ++t) th.emplace_back(walk, t, (char*)0);
-		walk(0, 0);
-		for (auto &x : th) x.join();
-		th.clear();
-		/* a part whose first line lies beyond its range walked nothing; the body ends at the first marker.  Parts tile the span: part t stops
-		 * where part t + 1 starts, unless a marker stopped it */
-		int n_use = 0;
-		int64_t total = 0, stop = part[0].a;
-		std::vector<int64_t> off(n_thr, 0);
-		for (int t = 0; t < n_thr; ++t) {
-			if (part[t].a != stop) break;                               /* (a long line swallowed this part's range) */
-			off[t] = total; total += part[t].bytes; stop = part[t].stop; ++n_use;
-			if (part[t].hit) break;
-		}
-		const size_t at = out.size();
-		out.resize(at + (size_t)total);
-		char *base = &out[0] + at;
-		for (int t = 1; t < n_use; ++t) th.emplace_back(walk, t, base + off[t]);
-		if (n_use > 0) walk(0, base + off[0]);
-		for (auto &x : th) x.join();
-		return stop;
-	}
-	/* next(), with the sequence appended to `out` (+ '\n') when it has >= min_len bytes, and long FASTA bodies of a mapped file stripped by
-	 * bulk_threads threads.  Same return values and reader state as next() */
-	template <class V> int64_t next_to(V &out, int64_t min_len, int bulk_threads) {
-		if (!(psrc && psrc->map && bulk_threads > 1)) {
-			const int64_t l = next();
-			if (l >= min_len) { out.insert(out.end(), seq.begin(), seq.end()); out.push_back('\n'); }
-			return l;
-		}
-		int c, d;
-		if (last == 0) {
-			while ((c = getc()) != -1 && c != '>' && c != '@') {}
-			if (c == -1) return -1;
-			last = c;
-		}
-		seq.clear(); name.clear(); qlen = 0; qlast = 0;
-		if (until(false, 3, &d) < 0) return -1;
-		if (d != '\n') until(true, 0, 0);
-		const size_t at0 = out.size();
-		int64_t bulked = 0;
-		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
-			if (c == '\n') continue;
-			seq.push_back((char)c);
-			until(true, 1, 0);
-			if (seq.size() >= ((size_t)1 << 20)) {                       /* a long body: what is read so far goes out, the rest in parallel from the map */
-				out.insert(out.end(), seq.begin(), seq.end());
-				bulked += (int64_t)seq.size();
-				seq.clear();
-				int64_t p = pos0 + beg;                                 /* the reader stands at a line start (or at the end of the file) */
-				for (;;) {
-					const size_t before = out.size();
-					/* room for the spans to come in one step (a vector that grows span by span copies the whole body again and again, on one thread:
-					 * a quarter of the time of a 100 Mb record); address space only until it is written */
-					const size_t ahead = (size_t)std::min<int64_t>((int64_t)psrc->map_len - p, (int64_t)1 << 30) + ((size_t)1 << 20);
-					if (out.capacity() - before < std::min<size_t>(ahead, (size_t)bulk_threads << 22)) { try { out.reserve(before + ahead); } catch (const std::bad_alloc&) {} }
-					const int64_t q = bulk_body(out, p, bulk_threads);
-					bulked += (int64_t)(out.size() - before);
-					const bool more = q > p && q < (int64_t)psrc->map_len && psrc->map[q] != '>' && psrc->map[q] != '@' && psrc->map[q] != '+';   /* the span ended before the body did */
-					p = q;
-					if (!more) break;
-				}
-				beg = end = 0; eof = 0; poff = p;                       /* the buffered reader goes on from there */
-				seq.push_back('x'); seq.push_back('x');                 /* (kseq.h:145 looks at the sequence's length: "more than one byte" stays true) */
-			}
-		}
-		const int64_t slen = bulked ? bulked + (int64_t)seq.size() - 2 : (int64_t)seq.size();
-		if (bulked) { out.insert(out.end(), seq.begin() + 2, seq.end()); }
-		else if ((int64_t)seq.size() >= min_len) out.insert(out.end(), seq.begin(), seq.end());
-		if (c == '>' || c == '@') last = c;
-		int64_t ret = slen;
-		if (c == '+') {
-			while ((c = getc()) != -1 && c != '\n') {}
-			if (c == -1) ret = -2;
-			else {
-				while (until(true, 2, 0) >= 0 && (int64_t)qlen < slen) {}
-				last = 0;
-				if ((int64_t)qlen != slen) ret = -2;
-			}
-		}
-		if (ret >= min_len) out.push_back('\n'); else out.resize(at0);
-		return ret;
-	}
-	int64_t next() {
-		int c, d;
-		if (last == 0) {
-			while ((c = getc()) != -1 && c != '>' && c != '@') {}
-			if (c == -1) return -1;
-			last = c;
-		}
-		seq.clear(); name.clear(); qlen = 0; qlast = 0;
-		if (until(false, 3, &d) < 0) return -1;
-		if (d != '\n') until(true, 0, 0);
-		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
-			if (c == '\n') continue;
-			seq.push_back((char)c);
-			until(true, 1, 0);
-		}
-		if (c == '>' || c == '@') last = c;
-		if (c != '+') return (int64_t)seq.size();
-		while ((c = getc()) != -1 && c != '\n') {}
-		if (c == -1) return -2;
-		while (until(true, 2, 0) >= 0 && qlen < seq.size()) {}
-		last = 0;
-		return qlen == seq.size() ? (int64_t)seq.size() : -2;
-	}
-};
-} /* extern "C++" */
-
-/* ------------------------------------------------------------------------------------------
- * Parallel parsing of a plain (uncompressed, mapped) file.  A window of the file is cut into one
- * segment per thread.  Segment 0 starts at a verified record boundary; the others start at a GUESS
- * (first line after the cut that begins with '>' or, for '@', whose third line begins with '+').
- * Every thread parses records with the ordinary reader until the next record would start at or
- * beyond its segment's end and reports where that is.  A segment's output is accepted only if the
- * previous accepted segment stopped exactly at its start -- so the accepted stream is, by induction,
- * what the single reader would have produced; the next window starts where the last accepted
- * segment stopped.  A wrong guess costs time, never correctness.
- * ------------------------------------------------------------------------------------------ */
-static int64_t env_threads_window() { const int64_t w = yk_knob("YAKAMD_PARSE_WINDOW", 0); return w > 0 ? w : 0; }
-static int parse_threads(int n_thread)
-{
-	const char *e = getenv("YAKAMD_PARSE_THREADS");
-	int n = e ? atoi(e) : n_thread;
-	const int hw = (int)std::thread::hardware_concurrency();
-	if (hw > 0 && n > hw) n = hw;
-	return n < 1 ? 1 : n > 32 ? 32 : n;
-}
-
-/* The parsed base images' buffers (reused from window to window; pageable: page-locking them cost more than the runtime's staged copies of
- * pageable memory -- CLI run 1.44 s against 2.2 s -- and the multi-GPU reader stages through its own two pinned buffers) */
-extern "C++" {
-template <class T> struct PinAlloc {
-	typedef T value_type;
-	PinAlloc() {}
-	template <class U> PinAlloc(const PinAlloc<U>&) {}
-	T *allocate(size_t n) {
-		void *p = malloc(n * sizeof(T) + 16);
-		if (!p) throw std::bad_alloc();
-		return (T*)p;
-	}
-	void deallocate(T *p, size_t) { free((void*)p); }
-	template <class U> void construct(U*) {}                        /* resize() leaves new bytes alone: they are written right away (no zero fill of a 100 MB sequence) */
-	template <class U, class A0> void construct(U *p, const A0 &a) { ::new ((void*)p) U(a); }
-	template <class U> bool operator==(const PinAlloc<U>&) const { return true; }
-	template <class U> bool operator!=(const PinAlloc<U>&) const { return false; }
-};
-typedef std::vector<char, PinAlloc<char> > PinVec;
-} /* extern "C++" */
-
-/* ---- the base image packed on the host (include/yak_amd.h: yakamd_feed_packed_dev's format): 2-bit codes, 16 bases per 32-bit word, and one
- * validity bit per base, by the table the kernels use (seq_nt4_table, reference yak.h / count.c:28-31: ACGT, acgt, U, u and the bytes 0..3 are
- * bases, everything else -- N, the '\n' between two records -- is not) ---- */
-static const uint8_t yk_nt4[256] = {
-#define R4(v) v, v, v, v
-#define R16(v) R4(v), R4(v), R4(v), R4(v)
-	0, 1, 2, 3, R4(4), R4(4), R4(4),
-	R16(4), R16(4), R16(4),
-	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
-	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
-	4, 0, 4, 1, 4, 4, 4, 2, R4(4), R4(4),
-	4, 4, 4, 4, 3, 3, 4, 4, R4(4), R4(4),
-	R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4), R16(4)
-#undef R16
-#undef R4
-};
-static inline void pack32_scalar(const uint8_t *a, int64_t left, uint32_t *c0, uint32_t *c1, uint32_t *v)
-{
-	uint32_t x0 = 0, x1 = 0, m = 0;
-	const int n = left < 32 ? (int)left : 32;
-	for (int j = 0; j < n; ++j) {
-		const uint32_t c = yk_nt4[a[j]];
-		if (c < 4) { m |= 1u << j; if (j < 16) x0 |= c << (2 * j); else x1 |= c << (2 * (j - 16)); }
-	}
-	*c0 = x0; *c1 = x1; *v = m;
-}
-/* 32 bases per step with AVX2 + BMI2: A / C / G / T of either case by four compares (the validity word is their movemask), the code of such a
- * byte is bits 1..2 of it with bit 1 flipped when bit 2 is set (A 0x41 -> 0, C 0x43 -> 1, G 0x47 -> 2, T 0x54 -> 3), gathered by pext; a group
- * that holds one of the rare other bases (U, u, a raw 0..3) goes through the table */
-__attribute__((target("avx2,bmi2")))
-static void pack_words_avx2(const uint8_t *a, int64_t n_words, uint32_t *codes, uint32_t *valid)
-{
-	const __m256i up = _mm256_set1_epi8((char)0xDF), A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'), G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T'),
-	              U = _mm256_set1_epi8('U'), four = _mm256_set1_epi8(4), b4 = _mm256_set1_epi8(0x04);
-	for (int64_t w = 0; w < n_words; ++w, a += 32) {
-		const __m256i x = _mm256_loadu_si256((const __m256i*)a), u = _mm256_and_si256(x, up);
-		const __m256i acgt = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, A), _mm256_cmpeq_epi8(u, C)), _mm256_or_si256(_mm256_cmpeq_epi8(u, G), _mm256_cmpeq_epi8(u, T)));
-		const __m256i rare = _mm256_or_si256(_mm256_cmpeq_epi8(u, U), _mm256_cmpeq_epi8(_mm256_min_epu8(x, four), x) /* x <= 4 */);
-		const __m256i rare4 = _mm256_andnot_si256(_mm256_cmpeq_epi8(x, four), rare);   /* x < 4, or U / u */
-		if (_mm256_movemask_epi8(rare4)) { pack32_scalar(a, 32, &codes[2 * w], &codes[2 * w + 1], &valid[w]); continue; }
-		const uint32_t m = (uint32_t)_mm256_movemask_epi8(acgt);
-		const __m256i y = _mm256_xor_si256(x, _mm256_srli_epi16(_mm256_and_si256(x, b4), 1));
-		uint64_t q[4];
-		_mm256_storeu_si256((__m256i*)q, y);
-		const uint64_t sel = 0x0606060606060606ull;
-		const uint64_t code = _pext_u64(q[0], sel) | _pext_u64(q[1], sel) << 16 | _pext_u64(q[2], sel) << 32 | _pext_u64(q[3], sel) << 48;
-		const uint64_t keep = _pdep_u64((uint64_t)m, 0x5555555555555555ull) * 3;
-		const uint64_t cv = code & keep;
-		codes[2 * w] = (uint32_t)cv; codes[2 * w + 1] = (uint32_t)(cv >> 32); valid[w] = m;
-	}
-}
-/* n bases -> (n + 31) / 32 words of validity bits and twice as many of codes; the bits behind base n - 1 in the last words are zero */
-static void pack_into(const uint8_t *a, int64_t n, uint32_t *codes, uint32_t *valid)
-{
-	const int64_t nw = (n + 31) / 32, whole = n / 32;
-	static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !yk_knob("YAKAMD_NO_AVX2", 0);
-	int64_t w = 0;
-	if (wide) { pack_words_avx2(a, whole, codes, valid); w = whole; }
-	for (; w < nw; ++w) pack32_scalar(a + 32 * w, n - 32 * w, &codes[2 * w], &codes[2 * w + 1], &valid[w]);
-}
-void yakamd_pack_bases_host(const void *ascii, int64_t n, void *h_packed)
-{
-	if (n <= 0) return;
-	const int64_t nw = (n + 31) / 32;
-	uint32_t *codes = (uint32_t*)h_packed, *valid = (uint32_t*)((char*)h_packed + ((nw * 8 + 15) & ~(int64_t)15));
-	pack_into((const uint8_t*)ascii, n, codes, valid);
-	const int64_t pad = (((nw * 8 + 15) & ~(int64_t)15) - nw * 8) / 4;
-	for (int64_t i = 0; i < pad; ++i) codes[2 * nw + i] = 0;
-}
-
-typedef std::vector<uint32_t, PinAlloc<uint32_t> > PinWords;
-/* a parsed segment: its base image -- or, when the source asks for packed pieces, that image packed as it grows (the ASCII bytes then only pass
- * through a buffer of ~1 MB that stays in the thread's cache): code words, validity words, 32 stream positions per validity word.  The image
- * of a segment is taken to end at a multiple of 32 positions: the up to 31 positions behind it are no bases (stream positions only order the
- * k-mers; a few of them unused change nothing), so a window's segments can be laid one behind the other word by word */
-struct ParSeg { int64_t start, end, stop; PinVec img; PinWords codes, valid; int64_t n_seq, sum_len; bool hard_end; };
-/* the accepted segments of a window as packed pieces, in stream order (yakamd_feed_packed_pieces_host lays them out on the device: one feed) */
-struct WinPack { std::vector<const void*> codes, valid; std::vector<int64_t> n_words; int64_t n_pos, n_seq; WinPack() : n_pos(0), n_seq(0) {} };
-/* what takes the parsed pieces, in stream order: the base image (sequences, each followed by '\n'), its bytes, its sequences, and -- when the
- * source asked for it (ByteSource::pack) -- no ASCII image but the packed pieces of a whole window (n = its stream positions), else 0 */
-typedef std::function<bool(const char*, size_t, int64_t, const WinPack*)> ImgSink;
-
-static int64_t guess_record_start(const ByteSource *src, int64_t from, int64_t limit)
-{
-	std::vector<unsigned char> tmp((size_t)(limit - from));
-	int64_t got = 0;
-	while (got < (int64_t)tmp.size()) { const ssize_t r = src->pread_at(tmp.data() + got, tmp.size() - got, from + got); if (r <= 0) break; got += r; }
-	const unsigned char *base = tmp.data(), *p = base, *e = base + got;
-	p = (const unsigned char*)memchr(p, '\n', e - p);
-	if (!p) return -1;
-	for (++p; p < e; ) {
-		const unsigned char *l1 = (const unsigned char*)memchr(p, '\n', e - p);
-		if (*p == '>') return from + (p - base);
-		if (*p == '@' && l1) {
-			const unsigned char *l2 = l1 + 1 < e ? (const unsigned char*)memchr(l1 + 1, '\n', e - (l1 + 1)) : 0;
-			if (l2 && l2 + 1 < e && l2[1] == '+') return from + (p - base);
-		}
-		if (!l1) return -1;
-		p = l1 + 1;
-	}
-	return -1;
-}
-
-static void parse_segment(const ByteSource *src, int64_t file_end, ParSeg *sg, int min_len, int bulk_threads)
-{
-	FxReader r;
-	r.open_at(src, sg->start);
-	sg->n_seq = sg->sum_len = 0; sg->hard_end = false;
-	sg->img.clear(); sg->codes.clear(); sg->valid.clear();
-	const bool pack = src->pack;
-	if (!pack && sg->img.capacity() < (size_t)(sg->end - sg->start)) sg->img.reserve((size_t)(sg->end - sg->start) + (1 << 16));   /* the sequences are a part of the segment's bytes */
-	if (pack) { const size_t w = (size_t)(sg->end - sg->start) / 32 + 64; if (sg->valid.capacity() < w) { sg->valid.reserve(w); sg->codes.reserve(2 * w); } }
-	auto flush = [&](bool all) {                                  /* whole words of the staged bases go to the packed image; at the end the rest too, padded */
-		const size_t n = all ? sg->img.size() : sg->img.size() & ~(size_t)31;
-		if (n == 0) return;
-		const size_t w0 = sg->valid.size(), nw = (n + 31) / 32;
-		sg->valid.resize(w0 + nw); sg->codes.resize(2 * (w0 + nw));
-		pack_into((const uint8_t*)sg->img.data(), (int64_t)n, &sg->codes[2 * w0], &sg->valid[w0]);
-		const size_t rest = sg->img.size() - n;
-		if (rest) memmove(&sg->img[0], &sg->img[n], rest);
-		sg->img.resize(rest);
-	};
-	int64_t l;
-	for (;;) {
-		if (pack && sg->img.size() >= ((size_t)1 << 20)) flush(false);
-		if (!r.seek_marker()) { sg->stop = file_end; sg->hard_end = !src->partial; break; }
-		const int64_t mp = r.marker_pos();
-		if (mp >= sg->end) { sg->stop = mp; break; }
-		const size_t img0 = sg->img.size();
-		if ((l = r.fast(sg->img, min_len)) == FxReader::NOT_FAST) l = r.next_to(sg->img, min_len, bulk_threads);
-		/* more of the stream follows these bytes and the reader has used them up: the record may go on there (`last` still holds the
-		 * marker it started with, kseq.h:186-190, so it cannot tell) -- it is left, from its marker on, for the next batch */
-		if (src->partial && !r.fill()) { sg->img.resize(img0); sg->stop = mp; break; }
-		if (l < 0) { sg->stop = file_end; sg->hard_end = true; break; }   /* EOF inside a record, or a truncated FASTQ record: the stream ends (count.c:93) */
-		if (l >= min_len) { ++sg->n_seq; sg->sum_len += l; }
-	}
-	r.close_at();
-	if (pack) flush(true);
-}
-
-/* one window: cut [pos, wend) into segments, parse them on n_thr threads, accept the verified prefix.  Returns the
- * number of accepted segments; *next = where the following window starts; *done = the stream has ended */
-static int parse_window(const ByteSource *fd, int64_t size, int64_t pos, int64_t WIN, int min_len, int n_thr, std::vector<ParSeg> &seg, int64_t *next, bool *done, WinPack *wp)
-{
-	const int64_t wend = std::min(size, pos + WIN), step = (wend - pos + n_thr - 1) / n_thr;
-	int n_seg = 0;
-	for (int i = 0; i < n_thr; ++i) {
-		const int64_t cut = pos + i * step;
-		if (cut >= wend) break;
-		const int64_t st = i == 0 ? pos : guess_record_start(fd, cut, std::min(size, cut + ((int64_t)1 << 18)));
-		if (i && (st < 0 || st >= wend)) continue;
-		if (n_seg && st <= seg[n_seg - 1].start) continue;
-		seg[n_seg].start = st; ++n_seg;
-	}
-	for (int i = 0; i < n_seg; ++i) seg[i].end = i + 1 < n_seg ? seg[i + 1].start : wend;
-	std::vector<std::thread> th;
-	/* few segments (long records: a cut finds no record start nearby): their threads' share of the parser threads strips the long bodies */
-	const int bulk_threads = std::max(1, std::min(n_thr, (int)std::thread::hardware_concurrency()) / std::max(1, n_seg));
-	for (int i = 1; i < n_seg; ++i) th.emplace_back(parse_segment, fd, size, &seg[i], min_len, bulk_threads);
-	parse_segment(fd, size, &seg[0], min_len, bulk_threads);
-	for (auto &t : th) t.join();
-	int64_t at = pos;
-	int n_ok = 0;
-	for (int i = 0; i < n_seg; ++i) {
-		if (seg[i].start != at) break;                           /* wrong guess: the rest of the window is parsed again */
-		++n_ok;
-		at = seg[i].stop;
-		if (seg[i].hard_end) { *done = true; break; }
-	}
-	*next = at;
-	if (fd->pack) {
-		wp->codes.clear(); wp->valid.clear(); wp->n_words.clear(); wp->n_pos = wp->n_seq = 0;
-		for (int i = 0; i < n_ok; ++i) {
-			wp->n_seq += seg[i].n_seq;
-			if (seg[i].valid.empty()) continue;
-			wp->codes.push_back(seg[i].codes.data()); wp->valid.push_back(seg[i].valid.data()); wp->n_words.push_back((int64_t)seg[i].valid.size());
-			wp->n_pos += 32 * (int64_t)seg[i].valid.size();
-		}
-	}
-	return n_ok;
-}
-
-/* the source the parallel parser can take for `fn`, if any: a plain regular file (fx.fd) or a BGZF file, larger than min_size.
- * *own_fd (>= 0) is a descriptor the caller closes afterwards */
-static bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64_t min_size, ByteSource *src, int *own_fd)
-{
-	*own_fd = -1;
-	if (n_thr <= 1) return false;
-	struct stat sb;
-	if (fx.fd >= 0) {
-		if (fstat(fx.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= min_size) return false;
-		src->fd = fx.fd; src->size = sb.st_size; src->bgzf = false;
-		src->map_plain();
-		return true;
-	}
-	if (fn == 0 || strcmp(fn, "-") == 0) return false;
-	const int f = ::open(fn, O_RDONLY);
-	if (f < 0) return false;
-	if (!src->index_bgzf(f) || src->size <= min_size) { ::close(f); src->fd = -1; src->bgzf = false; return false; }
-	*own_fd = f;
-	return true;
-}
-
-/* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
- * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
- * threads already work on the next one. */
-static double g_t_parse_windows = 0, g_t_first_window = 0;    /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one */
-/* A parser thread fills a ring of window sets while the caller's thread hands the finished windows to the sink, in order: two sets for
- * ASCII pieces (the sink copies a window to the device while the next one is parsed), four when the windows are packed -- a new table's
- * first feed waits ~0.25 s for the runtime to come up, time in which the parser gets through 2 GB of file instead of standing still */
-static bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const ImgSink &sink, int64_t *stopped_at = 0, bool *stream_ended = 0)
-{
-	if (stopped_at) *stopped_at = 0;
-	if (stream_ended) *stream_ended = false;
-	const int64_t size = fd->size;
-	if (size <= 0) return true;
-	/* the windows grow from 128 MiB to 1 GiB: the device has its first piece after an eighth of the time a full window takes to parse */
-	const int64_t win_set = env_threads_window();
-	struct WinSet { std::vector<ParSeg> seg; WinPack wp; int n_ok; int64_t next; bool done; };
-	const int NSET = fd->pack ? 4 : 2;
-	std::vector<WinSet> *ring_p = new std::vector<WinSet>(NSET);
-	std::vector<WinSet> &ring = *ring_p;
-	for (auto &w : ring) { w.seg.resize(n_thr); w.n_ok = 0; w.next = 0; w.done = false; }
-	std::mutex mu; std::condition_variable cv;
-	int produced = 0, consumed = 0;
-	bool prod_end = false, abort = false;
-	std::thread producer([&]() {
-		int64_t pos = 0;
-		for (int k = 0; ; ++k) {
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return abort || k - consumed < NSET; }); if (abort) break; }
-			WinSet &w = ring[k % NSET];
-			const int64_t WIN = win_set ? win_set : std::min<int64_t>((int64_t)1 << 30, (int64_t)128 << 20 << std::min(k, 3));
-			const double t = yk_realtime();
-			w.done = false;
-			w.n_ok = parse_window(fd, size, pos, WIN, min_len, n_thr, w.seg, &w.next, &w.done, &w.wp);
-			const double dt = yk_realtime() - t;
-			g_t_parse_windows += dt; if (k == 0) g_t_first_window = dt;
-			/* (a partial source: a window that gets nowhere stands at a record that wants the bytes still to come) */
-			const bool more = !w.done && w.next < size && !(fd->partial && w.next == pos);
-			pos = w.next;
-			{ std::lock_guard<std::mutex> lk(mu); ++produced; if (!more) prod_end = true; }
-			cv.notify_all();
-			if (!more) break;
-		}
-		{ std::lock_guard<std::mutex> lk(mu); prod_end = true; }
-		cv.notify_all();
-	});
-	bool ok = true;
-	for (int k = 0; ; ++k) {
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return produced > k || prod_end; }); if (produced <= k) break; }
-		WinSet &w = ring[k % NSET];
-		if (stopped_at) *stopped_at = w.next;
-		if (stream_ended) *stream_ended = w.done;
-		if (fd->pack) { if (w.n_ok > 0 && (w.wp.n_pos > 0 || w.wp.n_seq > 0)) ok = sink(0, (size_t)w.wp.n_pos, w.wp.n_seq, &w.wp); }
-		else for (int i = 0; i < w.n_ok && ok; ++i) if (!w.seg[i].img.empty() || w.seg[i].n_seq > 0) ok = sink(w.seg[i].img.data(), w.seg[i].img.size(), w.seg[i].n_seq, 0);
-		{ std::lock_guard<std::mutex> lk(mu); ++consumed; if (!ok) abort = true; }
-		cv.notify_all();
-		if (!ok) break;
-	}
-	producer.join();
-	std::thread([ring_p]() { delete ring_p; }).detach();          /* (giving some GB of images back to the system takes ~0.1 s: not in the caller's way) */
-	return ok;
-}
-
-/* an ordinary gzip file: batches of it are inflated by several threads (pgz.h) while the batch before is parsed, by the same window
- * parser, from memory; the record a batch ends in is carried to the front of the next one */
-static bool gz_source(const char *fn, const FxReader &fx, int n_thr, pgz::Reader *z)
-{
-	if (n_thr <= 1 || fx.fd >= 0 || fn == 0 || strcmp(fn, "-") == 0 || yk_knob("YAKAMD_NO_PGZ", 0)) return false;
-	pgz::tune().no_simd = yk_knob("YAKAMD_NO_AVX2", 0) != 0;
-	return z->open(fn, n_thr);
-}
-static bool parse_gz(pgz::Reader *z, int min_len, int n_thr, const ImgSink &sink, bool pack = false)
-{
-	size_t keep = 0;
-	for (bool last = false; !last; ) {
-		uint8_t *p = 0; size_t n = 0;
-		if (!z->next(keep, &p, &n, &last)) { yk_set_error("%s", z->why.c_str()); return false; }
-		ByteSource src;
-		src.set_memory(p, n, !last);
-		src.pack = pack;
-		int64_t stop = 0; bool ended = false;
-		if (!parse_parallel(&src, min_len, n_thr, sink, &stop, &ended)) return false;
-		if (ended) break;                                         /* a truncated record ended the stream (count.c:93) */
-		keep = (size_t)stop;
-	}
-	if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] gzip: %d threads inflated %lu chunks from a searched block start (%lu searched starts not used, %.1f MB decoded by the stitch)\n",
-	                                      z->n_thr, (unsigned long)z->n_search_ok, (unsigned long)z->n_search_bad, z->n_gap_bits / 8e6);
-	return true;
-}
-
-/* ------------------------------------------------------------------------------------------
- * Several GPUs behind yak_count() (replaces the kt_for over prefixes, count.c:129-143).
- * YAKAMD_GPUS = N (a divisor of 1 << pre): GPU r owns the contiguous prefixes [r P / N, (r + 1) P / N) --
- * table, filters and all.  The input is dealt to the GPUs in chunks of YAKAMD_MGPU_CHUNK bytes of sequence:
- * chunk j goes to GPU j % N, which extracts and groups its k-mers by prefix (yakamd_partition_dev); one
- * exchange per round of N chunks then moves every record to the owner of its prefix -- RCCL
- * (ncclGroupStart + ncclSend / ncclRecv pairs over xGMI, one communicator per GPU from ncclCommInitAll),
- * or plain device copies when two ranks share a GPU (YAKAMD_GPU_LIST=0,0: one-GPU test rigs); the owner
- * feeds the slices in chunk order, which is the stream order of the file, so the N-GPU bytes are the
- * 1-GPU bytes.  librccl is opened only when a job asks for several distinct GPUs.
- * ------------------------------------------------------------------------------------------ */
-static bool env_fast_default() { return yk_knob("YAKAMD_FAST", 1) != 0; }   /* the exclusive-ownership path (the only one that takes tagged records) is on */
-
-struct RcclApi {
-	void *lib;
-	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
-	ncclResult_t (*CommDestroy)(ncclComm_t);
-	ncclResult_t (*GroupStart)(void);
-	ncclResult_t (*GroupEnd)(void);
-	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
-	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
-	const char *(*GetErrorString)(ncclResult_t);
-};
-static bool rccl_open(RcclApi *R)
-{
-	memset(R, 0, sizeof(*R));
-	R->lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-	if (!R->lib) R->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-	if (!R->lib) return false;
-#define YK_SYM(f, n) *(void**)&R->f = dlsym(R->lib, n)
-	YK_SYM(CommInitAll, "ncclCommInitAll"); YK_SYM(CommDestroy, "ncclCommDestroy"); YK_SYM(GroupStart, "ncclGroupStart"); YK_SYM(GroupEnd, "ncclGroupEnd");
-	YK_SYM(Send, "ncclSend"); YK_SYM(Recv, "ncclRecv"); YK_SYM(GetErrorString, "ncclGetErrorString");
-#undef YK_SYM
-	return R->CommInitAll && R->CommDestroy && R->GroupStart && R->GroupEnd && R->Send && R->Recv;
-}
-
-/* Ranks own prefix ranges; chunks of the input live in SLOTS, one per distinct device (ranks that share a device -- the sweeps of one device
- * posing as several -- share its chunk, its partition and its buffers: the owner's slice of a chunk on its own device is fed where it lies).
- * Two sets of slot buffers: set x is being partitioned, exchanged and fed by a worker thread while the reader fills set 1 - x. */
-struct MultiJob {
-	int N, P, S;                                               /* ranks, sub-tables, slots */
-	std::vector<int> dev, sdev, slot_of;                       /* device of rank r; device of slot s; slot of rank r */
-	std::vector<hipStream_t> st, cp;                           /* per slot: exchange stream; copy stream of the reader (non-blocking: the fill of the next set must not wait for the kernels of this one) */
-	bool use_rccl;
-	RcclApi R;
-	std::vector<ncclComm_t> comm;                              /* per slot */
-	std::vector<uint8_t*> d_base[2];                           /* [set][slot]: chunk of sequence */
-	std::vector<uint64_t*> d_send[2], d_recv[2];               /* [set][slot]: records grouped by prefix / slices received from the other slots */
-	int64_t chunk, send_words, recv_words;
-	bool ext_base;                                             /* d_base points at the caller's device buffers (yakamd_count_multi_dev) */
-};
-
-/* no filter + a plain file of more than YAKAMD_AUTO_SWEEP_GB (2.5) GB: nearly every k-mer instance may be a key of its own (an assembly),
- * and one pass holds ~70 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
- * prefix ranges (N so that a sweep sees at most ~2.8 G positions of its own: 5 Gb in 2 sweeps, 2.4 s on a device whose memory has been in use
- * before, 2.4 s in 4; round 3 needed 4 -- a rank of 2 held a third copy of its table and 4 bytes of pending counts per slot while its layout
- * was replayed).  YAKAMD_GPUS set to anything switches the rule off */
-static int auto_sweeps(const yak_copt_t *opt, const char *fn)
-{
-	if (fn == 0 || strcmp(fn, "-") == 0 || opt->bf_shift > opt->pre) return 1;
-	const char *g = getenv("YAKAMD_AUTO_SWEEP_GB");
-	const double lim = (g ? atof(g) : 2.5) * 1e9;
-	if (lim <= 0) return 1;
-	struct stat sb;
-	if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode) || (double)sb.st_size <= lim) return 1;
-	unsigned char m[2] = { 0, 0 };
-	const int f = ::open(fn, O_RDONLY);
-	if (f < 0) return 1;
-	const bool gz = ::read(f, m, 2) == 2 && m[0] == 0x1f && m[1] == 0x8b;
-	::close(f);
-	if (gz) return 1;                                           /* compressed: the size says little; the knob is there */
-	int N = 2;
-	while (N < 16 && (double)sb.st_size / N > 2.8e9) N <<= 1;
-	return (1 << opt->pre) % N ? 1 : N;
-}
-
-static int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *fn = 0)
-{
-	const char *e = getenv("YAKAMD_GPUS");
-	if (!e) {
-		const int S = auto_sweeps(opt, fn);
-		if (S <= 1) return 1;
-		int nd = 0;
-		if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
-		const char *dv = getenv("YAKAMD_DEVICE"), *lr = getenv("LOCAL_RANK");
-		const int d = (dv ? atoi(dv) : lr ? atoi(lr) : 0) % nd;
-		dev->assign(S, d);
-		fprintf(stderr, "[M::yak_count] %s: no filter and a large plain file: counting in %d sweeps over prefix ranges on device %d (YAKAMD_GPUS / YAKAMD_AUTO_SWEEP_GB change that)\n", fn, S, d);
-		return S;
-	}
-	const int N = atoi(e);
-	if (N <= 1) return 1;
-	int nd = 0;
-	if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
-	if ((1 << opt->pre) % N) { fprintf(stderr, "[W::yak_count] YAKAMD_GPUS=%d does not divide the %d sub-tables: counting on one GPU\n", N, 1 << opt->pre); return 1; }
-	dev->clear();
-	if (const char *l = getenv("YAKAMD_GPU_LIST")) { for (const char *q = l; *q; ) { dev->push_back(atoi(q) % nd); while (*q && *q != ',') ++q; if (*q) ++q; } }
-	for (int r = (int)dev->size(); r < N; ++r) dev->push_back(r % nd);
-	dev->resize(N);
-	return N;
-}
-
-static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, int64_t chunk_dev = 0, bool tagged_only = false)   /* chunk_dev > 0: the chunks are the caller's device buffers of at most that many bytes */
-{
-	J->N = N; J->P = P; J->dev = dev;
-	J->sdev.clear(); J->slot_of.assign(N, 0);
-	for (int r = 0; r < N; ++r) {
-		int s = -1;
-		for (size_t q = 0; q < J->sdev.size(); ++q) if (J->sdev[q] == dev[r]) s = (int)q;
-		if (s < 0) { s = (int)J->sdev.size(); J->sdev.push_back(dev[r]); }
-		J->slot_of[r] = s;
-	}
-	const int S = J->S = (int)J->sdev.size();
-	J->st.assign(S, 0); J->cp.assign(S, 0);
-	for (int x = 0; x < 2; ++x) { J->d_base[x].assign(S, 0); J->d_send[x].assign(S, 0); J->d_recv[x].assign(S, 0); }
-	const char *c = getenv("YAKAMD_MGPU_CHUNK");
-	J->chunk = c && atoll(c) > 0 ? atoll(c) : (int64_t)1 << 28;
-	if (chunk_dev > 0) J->chunk = chunk_dev;
-	J->chunk = (J->chunk + 4095) & ~(int64_t)4095;
-	J->ext_base = chunk_dev > 0;
-	J->send_words = (tagged_only ? 1 : 2) * J->chunk;          /* one 16-byte record per position at most (8-byte tagged records use half of it) */
-	/* a slot receives, for the ranks it hosts, their share of the S - 1 other chunks: (ranks here / N) each on average; refused beyond 1.5 x that */
-	int most = 0;
-	for (int s = 0; s < S; ++s) { int n_here = 0; for (int r = 0; r < N; ++r) n_here += J->slot_of[r] == s; most = std::max(most, n_here); }
-	J->recv_words = S > 1 ? (int64_t)((double)J->send_words * (S - 1) * most / N * 1.5) + 4096 * N : 0;
-	J->use_rccl = S > 1 && !yk_knob("YAKAMD_MGPU_NO_RCCL", 0);
-	if (S < N) fprintf(stderr, "[M::yak_count] %d ranks on %d device%s: ranks that share a device share its chunks and take turns (their slices are fed where they lie)%s\n",
-	                   N, S, S > 1 ? "s" : "", S == 1 ? "; nothing is exchanged" : "");
-	if (J->use_rccl) {
-		J->comm.assign(S, 0);
-		if (!rccl_open(&J->R)) { fprintf(stderr, "[W::yak_count] librccl.so not found: exchanging with peer copies\n"); J->use_rccl = false; }
-		else { const ncclResult_t r = J->R.CommInitAll(J->comm.data(), S, J->sdev.data()); if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; } }
-	}
-	for (int s = 0; s < S; ++s) {
-		if (hipSetDevice(J->sdev[s]) != hipSuccess || hipStreamCreate(&J->st[s]) != hipSuccess || hipStreamCreateWithFlags(&J->cp[s], hipStreamNonBlocking) != hipSuccess) return false;
-		if (!J->use_rccl) for (int q = 0; q < S; ++q) if (q != s) (void)hipDeviceEnablePeerAccess(J->sdev[q], 0);
-		for (int x = 0; x < 2; ++x) {
-			/* (from the engine's pool: a process that counts again -- a benchmark's steps, the second pass of the filtered protocol -- finds these buffers there
-			 * instead of asking the driver while the pool holds most of the device) */
-			J->d_base[x][s] = J->ext_base ? 0 : (uint8_t*)yk_pool_get((size_t)J->chunk + 4096);
-			J->d_send[x][s] = (uint64_t*)yk_pool_get((size_t)J->send_words * 8);
-			J->d_recv[x][s] = J->recv_words ? (uint64_t*)yk_pool_get((size_t)J->recv_words * 8) : 0;
-			if ((!J->ext_base && !J->d_base[x][s]) || !J->d_send[x][s] || (J->recv_words && !J->d_recv[x][s])) return false;
-		}
-	}
-	(void)hipGetLastError();
-	return true;
-}
-
-static void multi_close(MultiJob *J)
-{
-	for (int s = 0; s < J->S; ++s) {
-		hipSetDevice(J->sdev[s]);
-		for (int x = 0; x < 2; ++x) { if (!J->ext_base) yk_pool_release(J->d_base[x][s]); yk_pool_release(J->d_send[x][s]); yk_pool_release(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
-		if (J->st[s]) { hipStreamDestroy(J->st[s]); J->st[s] = 0; }
-		if (J->cp[s]) { hipStreamDestroy(J->cp[s]); J->cp[s] = 0; }
-		if (J->use_rccl && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
-	}
-}
-
-/* one round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Partition, exchange, feed. */
-static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0, std::string *why)
-{
-	std::mutex why_mu;
-	auto note = [&]() { std::lock_guard<std::mutex> lk(why_mu); if (why && why->empty()) *why = yakamd_last_error(); };   /* called on the thread that failed */
-	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !yk_knob("YAKAMD_MGPU_REC16", 0);   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
-	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
-	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
-	for (int s = 0; s < S; ++s) if (fill[s] * W > J->send_words) { fprintf(stderr, "[E::yak_count] a chunk of %lld positions does not fit the send buffer (%lld words): 16-byte records were not planned for\n", (long long)fill[s], (long long)J->send_words); return false; }
-	std::vector<std::vector<uint64_t> > bst(S, std::vector<uint64_t>(P + 1, 0));
-	std::vector<int64_t> n_rec(S, 0);
-	std::vector<char> ok(std::max(N, S), 1);
-	{	/* every slot groups the k-mers of its chunk by prefix */
-		std::vector<std::thread> th;
-		for (int s = 0; s < S; ++s) th.emplace_back([&, s]() {
-			if (fill[s] <= 0) return;
-			hipSetDevice(J->sdev[s]);
-			n_rec[s] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
-			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
-			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data());
-			if (n_rec[s] < 0) { ok[s] = 0; note(); }
-		});
-		for (auto &t : th) t.join();
-	}
-	for (int s = 0; s < S; ++s) if (!ok[s]) return false;
-	/* receive layout of a slot: for each rank it hosts (rank order), the slices of the other slots' chunks (slot order) */
-	std::vector<std::vector<uint64_t> > roff(N, std::vector<uint64_t>(S, 0));   /* roff[d][s]: where owner d's slice of chunk s lies in its slot's receive buffer (records) */
-	std::vector<uint64_t> used(S, 0);
-	for (int d = 0; d < N; ++d) {
-		const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
-		for (int s = 0; s < S; ++s) { if (s == sd) continue; roff[d][s] = used[sd]; used[sd] += bst[s][hi] - bst[s][lo]; }
-	}
-	for (int s = 0; s < S; ++s) if ((int64_t)(used[s] * W) > J->recv_words) { fprintf(stderr, "[E::yak_count] device %d would receive %llu records in one round: prefixes too unevenly filled for YAKAMD_MGPU_CHUNK\n", J->sdev[s], (unsigned long long)used[s]); return false; }
-	if (S > 1) {
-		if (J->use_rccl) J->R.GroupStart();
-		for (int s = 0; s < S; ++s)
-			for (int d = 0; d < N; ++d) {
-				const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
-				const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
-				if (cnt == 0 || s == sd) continue;
-				const uint64_t *src = J->d_send[x][s] + bst[s][lo] * W;
-				uint64_t *dst = J->d_recv[x][sd] + roff[d][s] * W;
-				if (J->use_rccl) {                                      /* (the current device matches the communicator of every call, as the library's own examples do it) */
-					hipSetDevice(J->sdev[s]);
-					if (J->R.Send(src, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess) ok[0] = 0;
-					hipSetDevice(J->sdev[sd]);
-					if (J->R.Recv(dst, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok[0] = 0;
-				} else {
-					hipSetDevice(J->sdev[sd]);
-					if (hipMemcpyPeerAsync(dst, J->sdev[sd], src, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
-				}
-			}
-		if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
-		for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
-		if (!ok[0] && J->use_rccl) {
-			/* the collective library let the round down: the same slices as plain peer copies, from here on */
-			fprintf(stderr, "[W::yak_count] RCCL exchange failed (%s): peer copies from now on\n", hipGetErrorString(hipGetLastError()));
-			J->use_rccl = false; ok[0] = 1;
-			for (int s = 0; s < S; ++s) for (int q = 0; q < S; ++q) if (q != s) { hipSetDevice(J->sdev[s]); (void)hipDeviceEnablePeerAccess(J->sdev[q], 0); }
-			(void)hipGetLastError();
-			for (int s = 0; s < S; ++s)
-				for (int d = 0; d < N; ++d) {
-					const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
-					const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
-					if (cnt == 0 || s == sd) continue;
-					hipSetDevice(J->sdev[sd]);
-					if (hipMemcpyPeerAsync(J->d_recv[x][sd] + roff[d][s] * W, J->sdev[sd], J->d_send[x][s] + bst[s][lo] * W, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
-				}
-			for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
-		}
-		if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
-	}
-	{	/* every owner takes its slices, in chunk order = stream order; owners that share a device take turns (a feed may count a whole slice of the pass) */
-		std::vector<std::thread> th;
-		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int d = 0; d < N; ++d) if (J->slot_of[d] == sd) {
-			hipSetDevice(J->dev[d]);
-			const int lo = d * (P / N), hi = (d + 1) * (P / N);
-			std::vector<uint64_t> ob(P + 1);
-			for (int s = 0; s < S; ++s) {
-				const uint64_t cnt = bst[s][hi] - bst[s][lo];
-				if (cnt == 0) continue;
-				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[s][q] - bst[s][lo]; }
-				const uint64_t *rec = s == sd ? J->d_send[x][s] + bst[s][lo] * W : J->d_recv[x][sd] + roff[d][s] * W;   /* the slice of the device's own chunk is fed where the partition left it */
-				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s], 0)
-				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s])
-				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
-				if (rc != 0) { ok[d] = 0; note(); }
-			}
-			if (hipStreamSynchronize(yk_ctx_stream(((yak_ch_ext*)e->sub[d])->ctx)) != hipSuccess) ok[d] = 0;   /* the copies out of this set's buffers are done before the set is filled again */
-		} });
-		for (auto &t : th) t.join();
-	}
-	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
-	return true;
-}
-
-static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector<int> &dev);
-static yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t *h0, int N, const std::vector<int> &dev)
-{
-	FxReader fx;
-	if (!fx.open_file(fn)) return 0;
-	const int P = 1 << opt->pre;
-	yak_ch_t *h = h0;
-	const int create_new = h0 ? 0 : 1;
-	if (h0 == 0) {                                             /* N tables, one per rank, each owning its prefix range */
-		h = multi_table_new(opt, N, dev);
-		if (!h) { fx.close_file(); return 0; }
-	}
-	yak_ch_ext *e = (yak_ch_ext*)h;
-	MultiJob J;
-	bool ok = multi_open(&J, N, P, dev);
-	const int S = J.S;
-	const double t_job0 = yk_realtime();
-	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
-	/* the reader fills the chunks of set `cur` while a worker thread partitions, exchanges and feeds the set before it */
-	std::vector<int64_t> fill[2] = { std::vector<int64_t>(S, 0), std::vector<int64_t>(S, 0) };
-	std::vector<uint64_t> t0[2] = { std::vector<uint64_t>(S, 0), std::vector<uint64_t>(S, 0) };
-	std::thread worker;
-	bool worker_ok = true;
-	std::string worker_why;                                    /* yakamd_last_error() is per thread: the round's text comes back with it */
-	int cur = 0;
-	uint64_t t_stream = 0;
-	int64_t n_seq_tot = 0;
-	int g = 0;                                                 /* the slot whose chunk is being filled */
-	auto wait_worker = [&]() { if (worker.joinable()) worker.join(); if (!worker_ok) ok = false; };
-	double t_sink = 0, t_round_wait = 0;                        /* YAKAMD_VERBOSE: where the reader's time goes */
-	/* host -> device through two pinned staging buffers: while one is on its way over the bus the reader copies the next piece into the other (a
-	 * copy from pageable memory is staged by the runtime anyway, but behind a synchronise per piece) */
-	const size_t STG = (size_t)32 << 20;
-	uint8_t *stg[2] = { 0, 0 };
-	/* an event belongs to the device that was current when it was made and can only be recorded on a stream of that device: one per staging
-	 * buffer AND slot, made with the slot's device current; stg_on[i] = the slot whose copy stream holds buffer i's last copy (-1: idle) */
-	std::vector<hipEvent_t> stg_ev[2];
-	int stg_on[2] = { -1, -1 };
-	int stg_i = 0;
-	for (int i = 0; i < 2 && ok; ++i) {
-		ok = hipHostMalloc((void**)&stg[i], STG) == hipSuccess;
-		stg_ev[i].assign(S, (hipEvent_t)0);
-		for (int s = 0; s < S && ok; ++s) { hipSetDevice(J.sdev[s]); ok = hipEventCreateWithFlags(&stg_ev[i][s], hipEventDisableTiming) == hipSuccess; }
-	}
-	auto to_device = [&](int gdev, uint8_t *dst, const char *src, size_t n) -> bool {
-		hipSetDevice(J.sdev[gdev]);
-		for (size_t o = 0; o < n; o += STG) {
-			const size_t m = std::min(STG, n - o);
-			if (stg_on[stg_i] >= 0 && hipEventSynchronize(stg_ev[stg_i][stg_on[stg_i]]) != hipSuccess) return false;
-			memcpy(stg[stg_i], src + o, m);
-			if (hipMemcpyAsync(dst + o, stg[stg_i], m, hipMemcpyHostToDevice, J.cp[gdev]) != hipSuccess || hipEventRecord(stg_ev[stg_i][gdev], J.cp[gdev]) != hipSuccess) return false;
-			stg_on[stg_i] = gdev; stg_i ^= 1;
-		}
-		return true;
-	};
-	auto copies_done = [&]() { for (int s = 0; s < S && ok; ++s) { hipSetDevice(J.sdev[s]); ok = hipStreamSynchronize(J.cp[s]) == hipSuccess; } };
-	auto round = [&]() {
-		const double tw0 = yk_realtime();
-		copies_done();                                          /* the chunks of this set are on their devices */
-		wait_worker();                                          /* at most one round in flight: its set becomes the one to fill next */
-		t_round_wait += yk_realtime() - tw0;
-		if (ok) {
-			const int x = cur;
-			worker = std::thread([&, x]() { std::string why; worker_ok = multi_round(&J, x, e, opt->k, opt->pre, create_new, fill[x], t0[x], &why); if (!worker_ok) worker_why = why; });
-		}
-		cur ^= 1;
-		std::fill(fill[cur].begin(), fill[cur].end(), 0); g = 0;
-	};
-	/* a piece (whole sequences, each followed by '\n') goes to the chunk being filled; a chunk is closed between two
-	 * sequences, or inside one that is longer than a whole chunk */
-	auto take_piece_body = [&](const char *img, size_t n, int64_t ns) -> bool {
-		n_seq_tot += ns;
-		while (n > 0 && ok) {
-			const size_t room = (size_t)(J.chunk - fill[cur][g]);
-			size_t m = n, back = 0;
-			if (n > room) {
-				const void *nl = room ? memrchr(img, '\n', room) : 0;
-				if (nl) m = (size_t)((const char*)nl - img) + 1;
-				else if (fill[cur][g] > 0) { if (++g == S) round(); continue; }
-				else {
-					/* one sequence longer than a whole chunk (a chromosome beyond YAKAMD_MGPU_CHUNK bases): the chunk ends inside it and the
-					 * next one starts k - 1 bases earlier -- the k-mers that end in this chunk are counted here, those that end behind it
-					 * there (a chunk's first k - 1 positions complete no k-mer), and stream positions simply continue */
-					m = room; back = (size_t)opt->k - 1;
-				}
-			}
-			if (fill[cur][g] == 0) t0[cur][g] = t_stream;
-			ok = to_device(g, J.d_base[cur][g] + fill[cur][g], img, m);
-			fill[cur][g] += (int64_t)m;
-			t_stream += m - back; img += m - back; n -= m - back;
-			if (fill[cur][g] == J.chunk || n > 0) { if (++g == S) round(); }
-		}
-		return ok;
-	};
-	auto take_piece = [&](const char *img, size_t n, int64_t ns, const WinPack*) -> bool { const double t0 = yk_realtime(); const bool r = take_piece_body(img, n, ns); t_sink += yk_realtime() - t0; return r; };
-	const int n_thr = parse_threads(opt->n_thread);
-	ByteSource psrc; int psrc_fd = -1;
-	bool par = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd);
-	pgz::Reader gz;
-	if (ok && par) ok = parse_parallel(&psrc, opt->k, n_thr, take_piece) && ok;
-	else if (ok && gz_source(fn, fx, n_thr, &gz)) { par = true; ok = parse_gz(&gz, opt->k, n_thr, take_piece) && ok; }
-	else if (ok) {
-		std::vector<char> piece;
-		int64_t l, ns = 0;
-		for (;;) {
-			if ((l = fx.fast(piece, opt->k)) == FxReader::NOT_FAST) {
-				if ((l = fx.next()) < 0) break;
-				if (l >= opt->k) { piece.insert(piece.end(), fx.seq.begin(), fx.seq.end()); piece.push_back('\n'); }
-			}
-			if (l >= opt->k) ++ns;
-			if (piece.size() >= ((size_t)1 << 24)) { if (!take_piece(piece.data(), piece.size(), ns, 0)) break; piece.clear(); ns = 0; }
-		}
-		if (ok && !piece.empty()) take_piece(piece.data(), piece.size(), ns, 0);
-	}
-	if (ok) { bool any = false; for (int s = 0; s < S; ++s) any = any || fill[cur][s] > 0; if (any) round(); }
-	wait_worker();
-	const double t_fed = yk_realtime() - t_job0;
-	for (int i = 0; i < 2; ++i) {
-		if (stg_on[i] >= 0) (void)hipEventSynchronize(stg_ev[i][stg_on[i]]);
-		for (hipEvent_t e_ : stg_ev[i]) if (e_) (void)hipEventDestroy(e_);
-		if (stg[i]) (void)hipHostFree(stg[i]);
-	}
-	multi_close(&J);                                           /* the chunk and exchange buffers go before the passes finish: memory is tightest there */
-	{	/* every rank finishes its pass: partitions, counting, layout -- side by side; ranks that share a device take turns, so that the
-		 * scratch of only one of them is alive at a time (one device posing as N = the pass in N sweeps over prefix ranges: what lets a
-		 * 5 Gb assembly through 288 GB) */
-		std::vector<int64_t> n_ins(N, 0);
-		std::vector<std::thread> th;
-		std::vector<std::string> why(N);                       /* the error text is per thread: bring it back */
-		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int r = 0; r < N; ++r) if (J.slot_of[r] == sd) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) why[r] = yakamd_last_error(); } });
-		for (auto &t : th) t.join();
-		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) fprintf(stderr, "[E::yak_count] rank %d of %d (device %d): %s\n", r, N, dev[r], why[r].c_str());
-		for (int r = 0; r < N; ++r) { if (n_ins[r] < 0) ok = false; else e->sub[r]->tot += (uint64_t)n_ins[r]; }
-	}
-	multi_tot(h);
-	if (getenv("YAKAMD_VERBOSE") && atoi(getenv("YAKAMD_VERBOSE")) > 0) {
-		fprintf(stderr, "[yak_amd] %d ranks: input read, dealt and fed by %.3f s (%d parser threads; %.3f s inside the sink that copies the pieces to the devices, %.3f s of it waiting for copies and the round before), the ranks' passes finished by %.3f s\n",
-		        N, t_fed, n_thr, t_sink, t_round_wait, yk_realtime() - t_job0);
-		for (int s = 0; s < S; ++s) { hipSetDevice(J.sdev[s]); yk_pool_report("the job"); }
-	}
-	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
-	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? "RCCL exchange" : "peer copies");
-	if (psrc_fd >= 0) ::close(psrc_fd);
-	fx.close_file();
-	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", !worker_why.empty() ? worker_why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
-	return h;
-}
-
-/* a table sharded over N ranks (dev[r] = device of rank r), every rank owning its prefix range */
-static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector<int> &dev)
-{
-	const int P = 1 << opt->pre;
-	yak_ch_ext *e = (yak_ch_ext*)calloc(1, sizeof(*e));
-	e->magic = EXT_MAGIC; e->n_sub = N; e->sub = (yak_ch_t**)calloc(N, sizeof(yak_ch_t*));
-	yak_ch_t *h = &e->pub;
-	h->k = opt->k; h->pre = opt->pre;
-	h->h = (yak_ch1_t*)calloc((size_t)P, sizeof(yak_ch1_t));
-	bool ok = true;
-	for (int r = 0; r < N && ok; ++r) {
-		yk_ctx_next_device(dev[r]);
-		e->sub[r] = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift);
-		ok = e->sub[r] && yakamd_set_shard(e->sub[r], r * (P / N), (r + 1) * (P / N)) == 0;
-	}
-	if (!ok) { for (int r = 0; r < N; ++r) if (e->sub[r]) yak_ch_destroy(e->sub[r]); free(e->sub); free(h->h); free(e); return 0; }
-	e->ctx = 0;                                               /* no context of its own: every yakamd_* entry point refuses a sharded table instead of working on one shard */
-	h->n_hash = e->sub[0]->n_hash; h->n_shift = e->sub[0]->n_shift;
-	for (int p = 0; p < P; ++p) h->h[p].b = e->sub[0]->h[p].b;   /* descriptors only: "has a filter" for callers that look */
-	return h;
-}
-
-/* The same job with its input already on the devices (the benchmark's N-GPU mode; a caller with its own reader): the stream is cut into rounds of
- * one chunk per DEVICE -- chunk s of round b lies at d_chunk[b * S + s] on the s-th distinct device of `dev` (n_bytes[b * S + s] bytes of the base
- * image, at most 2^31 - 4096; 0 = none), and the stream order is round by round, device by device, exactly as yak_count() deals a file.  h0 == 0:
- * a new table sharded over the n_rank ranks (dev[r] = device of rank r; several ranks may share a device) comes back; h0 != 0: its k-mers are counted
- * (count.c:155-157).  exchange_out (may be 0): 1 = RCCL grouped send / recv, 2 = peer copies, 0 = one device, nothing exchanged.  The caller keeps
- * the chunks alive until the call returns */
-extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
-                                            const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out)
-{
-	const int P = 1 << opt->pre, N = n_rank;
-	if (N < 1 || P % N) { fprintf(stderr, "[E::yakamd_count_multi_dev] %d ranks do not divide the %d sub-tables\n", N, P); return 0; }
-	std::vector<int> dev(dev_of_rank, dev_of_rank + N);
-	if (h0) {
-		yak_ch_ext *e0 = (yak_ch_ext*)h0;
-		if (e0->n_sub != N) { fprintf(stderr, "[E::yakamd_count_multi_dev] the table is sharded over %d ranks, not %d\n", e0->n_sub > 0 ? e0->n_sub : 1, N); return 0; }
-		assert(h0->k == opt->k && h0->pre == opt->pre);
-	}
-	const int create_new = h0 ? 0 : 1;
-	yak_ch_t *h = h0 ? h0 : multi_table_new(opt, N, dev);
-	if (!h) return 0;
-	yak_ch_ext *e = (yak_ch_ext*)h;
-	MultiJob J;
-	J.S = 0;
-	int64_t cmax = 4096;
-	{	/* the distinct devices, in rank order: that is the order of the chunks inside a round */
-		std::vector<int> sd;
-		for (int r = 0; r < N; ++r) if (std::find(sd.begin(), sd.end(), dev[r]) == sd.end()) sd.push_back(dev[r]);
-		for (int i = 0; i < n_rounds * (int)sd.size(); ++i) cmax = std::max<int64_t>(cmax, n_bytes[i]);
-	}
-	if (cmax > ((int64_t)1 << 31) - 4096) { fprintf(stderr, "[E::yakamd_count_multi_dev] a chunk holds at most 2^31 - 4096 stream positions\n"); if (!h0) yak_ch_destroy(h); return 0; }
-	const bool tagged_only = create_new && yakamd_tagged_ok(opt->k, opt->pre) && !yk_knob("YAKAMD_MGPU_REC16", 0) && env_fast_default();
-	bool ok = multi_open(&J, N, P, dev, cmax, tagged_only || !create_new);
-	const int S = J.S;
-	yk_realtime();
-	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
-	std::string why;
-	uint64_t t_stream = 0;
-	for (int b = 0; b < n_rounds && ok; ++b) {
-		std::vector<int64_t> fill(S, 0);
-		std::vector<uint64_t> t0(S, 0);
-		for (int s = 0; s < S; ++s) {
-			fill[s] = n_bytes[(size_t)b * S + s];
-			t0[s] = t_stream; t_stream += (uint64_t)fill[s];
-			J.d_base[b & 1][s] = (uint8_t*)d_chunk[(size_t)b * S + s];
-		}
-		ok = multi_round(&J, b & 1, e, opt->k, opt->pre, create_new, fill, t0, &why);
-	}
-	const int exch = S == 1 ? 0 : J.use_rccl ? 1 : 2;
-	for (int x = 0; x < 2; ++x) for (int s = 0; s < S; ++s) J.d_base[x][s] = 0;
-	multi_close(&J);
-	{
-		std::vector<int64_t> n_ins(N, 0);
-		std::vector<std::thread> th;
-		std::vector<std::string> whyr(N);
-		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int r = 0; r < N; ++r) if (J.slot_of[r] == sd) { n_ins[r] = yakamd_pass_end(e->sub[r]); if (n_ins[r] < 0) whyr[r] = yakamd_last_error(); } });
-		for (auto &t : th) t.join();
-		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) { fprintf(stderr, "[E::yakamd_count_multi_dev] rank %d of %d (device %d): %s\n", r, N, dev[r], whyr[r].c_str()); ok = false; }
-		for (int r = 0; r < N; ++r) if (n_ins[r] >= 0) e->sub[r]->tot += (uint64_t)n_ins[r];
-	}
-	multi_tot(h);
-	if (exchange_out) *exchange_out = exch;
-	fprintf(stderr, "[M::%s::%.3f*%.2f] %d rounds of device-resident chunks; %ld distinct k-mers in the hash table (%d ranks, %s)\n", "yakamd_count_multi_dev",
-	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), n_rounds, (long)h->tot, N, exch == 0 ? "one device: nothing exchanged" : exch == 1 ? "RCCL exchange" : "peer copies");
-	if (!ok) { fprintf(stderr, "[E::yakamd_count_multi_dev] %s\n", !why.empty() ? why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
-	return h;
-}
-
-/* reference count.c:147-166 */
 yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 {
 	{
