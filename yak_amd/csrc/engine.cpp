@@ -1827,7 +1827,8 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.rec8_out = 0;                                         /* set below, once the largest sub-table stream is known */
 	if (c->bloom_mode) {
 		if (nowb_plan && (YK_R8_TAG_BITS + s2 >= 64 || np_max >= (1ull << (YK_R8_TAG_BITS + s2)) || env_i64("YAKAMD_REC8_OUT", 1) == 0 || c->nb - 9 - s2 > 8 || c->nb - 9 - s2 < 0)) nowb_plan = false;   /* (16-byte level-2 records are not kept; ranges beyond 256 blocks go to the older tiers) */
-		if (c->bf_virgin && c->nb - 9 - s2 <= (nowb_plan ? 8 : 7)) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
+		const bool lc2_runs = env_i64("YAKAMD_LC2", 1) != 0 && c->n_hash <= 32;   /* (with the block range below: yk_lc2_ok) -- the tier behind k_lc2 works on the filter in memory and needs real zeros */
+		if (c->bf_virgin && lc2_runs && c->nb - 9 - s2 <= (nowb_plan ? 8 : 7)) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
 		else if (bloom_materialise(c)) return -1;
 		c->bf_virgin = false;
 	}
@@ -1864,23 +1865,23 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		sort_tmax = np_max;
 	}
 
-	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0, *d_sba = 0, *d_koff = 0; Rec *d_r2 = 0, *d_ra = 0;
+	Chunk2 *d_chunks = 0; u32 *d_cf = 0, *d_rows2 = 0, *d_segcur = 0, *d_ovf2 = 0, *d_ndist = 0; u64 *d_bbase = 0, *d_sbstart = 0, *d_segbase = 0, *d_sba = 0, *d_koff = 0; Rec *d_r2 = 0, *d_ra = 0;
 	u64 *kc[2] = { 0, 0 }, *tt[2] = { 0, 0 };
 	LcOut lo; lo.kc = 0; lo.T = 0; lo.nsel = 0; lo.lp = 0; lo.nd = 0;
 	u64 *d_scr = 0, *d_scroff = 0;
 	/* every device buffer of this function is released here, whichever way it is left */
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
-		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_segcur); dfree(d_ovf); dfree(d_ovf2); dfree(d_ndist); dfree(d_bbase); dfree(d_sbstart);
+		dfree(d_chunks); dfree(d_cf); dfree(d_rows2); dfree(d_segcur); dfree(d_ovf2); dfree(d_ndist); dfree(d_bbase); dfree(d_sbstart);
 		dfree(d_segbase); dfree(d_r2); dfree(kc[0]); dfree(kc[1]); dfree(tt[0]); dfree(tt[1]); dfree(lo.kc); dfree(lo.T); dfree(lo.nsel); dfree(lo.lp); dfree(lo.nd);
 		dfree(d_scr); dfree(d_scroff); dfree(d_sba); dfree(d_ra); dfree(d_koff);
 	} };
 	if (dmalloc(&d_chunks, chunks.size()) || dmalloc(&d_cf, P + 1) || dmalloc(&d_bbase, P + 1) || dmalloc(&d_rows2, chunks.size() * S2F) ||
-	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf, n_sb) || dmalloc(&d_ovf2, n_sb)) return -1;
+	    dmalloc(&d_sbstart, n_sb + 1) || dmalloc(&d_segcur, P) || dmalloc(&d_ovf2, n_sb)) return -1;
 	if (three ? (dmalloc(&d_ra, n_total) || dmalloc(&d_sba, ((size_t)P << s2a) + 1)) : dmalloc(&d_r2, fp.rec8_out ? (n_total + 1) / 2 : n_total)) return -1;
 	HIPCK(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk2), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_cf, chunk_first.data(), (P + 1) * 4, hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_bbase, bbase.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF, 0, 16, c->st));   /* NOVF, NOVF2 */
+	HIPCK(hipMemsetAsync(c->d_counters + YKC_NOVF2, 0, 8, c->st));
 	std::vector<u64> h_sba;
 	{
 		EvTimer tm(c->st);
@@ -1973,21 +1974,22 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	{
 		EvTimer tm(c->st);
 		if (lc2) yk_launch_lc2(fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, d_ovf2, c->st);
-		else yk_launch_lds_count(0, fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, 0, 0, d_ovf, c->st);
 		c->ms_lds = tm.stop();
 		c->st_cur.ms_insert += c->ms_lds; c->st_cur.ms_dominant_kernel += c->ms_lds; c->st_cur.n_dominant_launches += 1;
 	}
 	HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
 	HIPCK(hipStreamSynchronize(c->st));
-	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] %s: %.2f ms, %llu of %zu sub-buckets passed on\n", lc2 ? "k_lc2" : "lds tier G", c->ms_lds, (unsigned long long)(h_cnt[YKC_NOVF] + h_cnt[YKC_NOVF2]), n_sb);
-	if (h_cnt[YKC_NOVF]) {      /* crowded bloom blocks / un-staged range: the tier with sort arrays */
-		EvTimer tm(c->st);
-		yk_launch_lds_count(1, fp, d_sbstart, lc_rec_in, c->d_bf, img_view(c), lo, c->d_counters, d_ovf, (u32)h_cnt[YKC_NOVF], d_ovf2, c->st);
-		c->st_cur.ms_insert += tm.stop();
-		HIPCK(hipMemcpyAsync(h_cnt, c->d_counters, sizeof(h_cnt), hipMemcpyDeviceToHost, c->st));
-		HIPCK(hipStreamSynchronize(c->st));
+	if (!lc2) {
+		/* k_lc2 does not run this pass (n_hash > 32, sub-buckets that own more filter blocks than it stages, YAKAMD_LC2=0): every sub-bucket of the shard
+		 * goes to the tier behind it */
+		const u32 first = (u32)c->plo << s2, n_all = (u32)(c->phi - c->plo) << s2;
+		std::vector<u32> all(n_all);
+		for (u32 i = 0; i < n_all; ++i) all[i] = first + i;
+		HIPCK(hipMemcpy(d_ovf2, all.data(), (size_t)n_all * 4, hipMemcpyHostToDevice));
+		h_cnt[YKC_NOVF2] = n_all;
 	}
-	if (h_cnt[YKC_NOVF2]) {     /* too many distinct k-mers for LDS: same algorithm on global scratch */
+	if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] %s: %.2f ms, %llu of %zu sub-buckets passed on\n", lc2 ? "k_lc2" : "k_lc2 not run", c->ms_lds, (unsigned long long)h_cnt[YKC_NOVF2], n_sb);
+	if (h_cnt[YKC_NOVF2]) {     /* the same algorithm on tables in global scratch */
 		const u32 n_ovf = (u32)h_cnt[YKC_NOVF2];
 		std::vector<u32> ovf(n_ovf);
 		std::vector<u64> sbs(n_sb + 1), off(n_ovf);
@@ -2020,7 +2022,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	}
 	lap("insert (k_lc2 + tiers)");
 	if (keep2) { c->ret2.d_r2 = d_r2; d_r2 = 0; c->ret2.n_total = n_total; c->ret2.fp = fp; c->ret2.fp.bf_nowb = 0; }
-	dfree(d_r2); dfree(d_ovf); dfree(d_ovf2);
+	dfree(d_r2); dfree(d_ovf2);
 	/* gather the fragments: keys per sub-table, then one contiguous list each */
 	std::vector<u32> m(P, 0);
 	std::vector<u64> ro(P + 1, 0);

@@ -193,8 +193,6 @@ int yk_launch_img_count_rng(const u64 *rec, int cross, const u64 *sbstart, ImgVi
                             u64 *list, u32 *list_n, u32 list_cap, hipStream_t st);
 void yk_launch_part2(const Chunk2 *chunks, int n_chunks, const u32 *chunk_first /*[P+1]*/, const u64 *bbase, FastParams fp, int P,
                      u32 *rows2, u64 *sbstart, Rec *out, hipStream_t st);
-void yk_launch_lds_count(int tier, FastParams fp, const u64 *sbstart, const Rec *rec,
-                         u32 *bloom32, ImgView img, LcOut O, u64 *counters, const u32 *in_list, u32 n_list, u32 *ovf_list, hipStream_t st);
 void yk_launch_lds_count_ovf(FastParams fp, const u64 *sbstart, const Rec *rec,
                              u32 *bloom32, ImgView img, LcOut O, const u32 *ovf_list, u32 n_ovf, const u64 *scr_off,
                              u64 *scr, hipStream_t st);
@@ -236,6 +234,6 @@ void yk_launch_seg_sort_pass2(const u64 *seg_base, const u32 *seg_cnt, int P, co
 #ifdef __cplusplus
 }
 #endif
-enum { YKC_NOVF = 6, YKC_NOVF2 = 7 };
+enum { YKC_NOVF2 = 7 };               /* sub-buckets k_lc2 passed on to the tier behind it */
 
 #endif
