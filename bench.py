@@ -356,7 +356,27 @@ def run_multi_c(a):
         dist.destroy_process_group()
 
 
+def _device_or_retry():
+    """A process that starts within seconds of the exit of one that held a few hundred GB of device memory can find NO device (the driver is still
+    taking that memory back: seen twice in round 5, right behind a 1 Gb-assembly run).  The HIP runtime does not recover inside the process, so the
+    bench starts itself again after a pause, a few times; if the device stays away the configuration's own check fails loudly as before."""
+    import yak_amd
+    try:
+        if yak_amd.lib().yakamd_device_count() >= 1:
+            return
+    except Exception:
+        return
+    n = int(os.environ.get("YAKAMD_BENCH_RETRY", "0"))
+    if n >= 6:
+        return
+    print(f"[bench] no gfx950 device visible yet: starting again in 5 s (attempt {n + 1} of 6)", file=sys.stderr)
+    time.sleep(5)
+    os.environ["YAKAMD_BENCH_RETRY"] = str(n + 1)
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
+
 def main():
+    _device_or_retry()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
