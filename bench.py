@@ -358,21 +358,19 @@ def run_multi_c(a):
 
 def _device_or_retry():
     """A process that starts within seconds of the exit of one that held a few hundred GB of device memory can find NO device (the driver is still
-    taking that memory back: seen twice in round 5, right behind a 1 Gb-assembly run).  The HIP runtime does not recover inside the process, so the
-    bench starts itself again after a pause, a few times; if the device stays away the configuration's own check fails loudly as before."""
-    import yak_amd
-    try:
-        if yak_amd.lib().yakamd_device_count() >= 1:
+    taking that memory back: seen in round 5 right behind 1 Gb-assembly runs).  Asked in a child process, so that this one's import order stays what
+    INTEGRATION.md asks for (torch before libyak_amd.so, in the configurations that use torch): wait and ask again, a few times; if the device stays
+    away the configuration's own check fails loudly as before."""
+    probe = ("import sys; sys.path.insert(0, %r); import yak_amd; sys.exit(0 if yak_amd.lib().yakamd_device_count() >= 1 else 3)" % ROOT)
+    for attempt in range(6):
+        try:
+            rc = subprocess.run([sys.executable, "-c", probe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120).returncode
+        except Exception:
             return
-    except Exception:
-        return
-    n = int(os.environ.get("YAKAMD_BENCH_RETRY", "0"))
-    if n >= 6:
-        return
-    print(f"[bench] no gfx950 device visible yet: starting again in 5 s (attempt {n + 1} of 6)", file=sys.stderr)
-    time.sleep(5)
-    os.environ["YAKAMD_BENCH_RETRY"] = str(n + 1)
-    os.execv(sys.executable, [sys.executable] + sys.argv)
+        if rc != 3:
+            return
+        print(f"[bench] no gfx950 device visible yet: asking again in 5 s (attempt {attempt + 1} of 6)", file=sys.stderr)
+        time.sleep(5)
 
 
 def main():
