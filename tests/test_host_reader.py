@@ -257,6 +257,31 @@ def test_gzip_reader_on_streams_that_are_not_text_or_not_whole(oracle, tmp_path)
                 os.environ["YAKAMD_PARSE_THREADS"] = "4"
                 with pytest.raises(OSError):
                     yak_amd.host_image(fn, 31, fast=True)
+        # what zlib refuses behind a member boundary is refused here too: a second member whose header has the magic but a method other than 8 or
+        # reserved flags ("unknown compression method" / "unknown header flags set"), and a second member whose first match reaches back into the FIRST member's
+        # bytes ("invalid distance too far back": a member starts with an empty window)
+        def bits(*fields):                                        # (value, n_bits, msb_first) packed the deflate way
+            acc = n = 0
+            for v, w, msb in fields:
+                for i in range(w):
+                    acc |= ((v >> (w - 1 - i if msb else i)) & 1) << n; n += 1
+            return acc.to_bytes((n + 7) // 8, "little")
+        reach_back = bits((1, 1, False), (1, 2, False), (0b0000001, 7, True), (0, 5, True), (0, 7, True))     # final fixed block: length 3 at distance 1, end of block
+        hdr = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"
+        small = z(text[:200000])
+        for name, tail in (("method", b"\x1f\x8b\x07" + hdr[3:] + small[10:]), ("flags", b"\x1f\x8b\x08\x20" + hdr[4:] + small[10:]),
+                           ("reach", hdr + reach_back + zlib.crc32(b"\n\n\n").to_bytes(4, "little") + (3).to_bytes(4, "little"))):
+            raw = small + tail
+            with pytest.raises(zlib.error):
+                zlib.decompressobj(31).decompress(small[len(small):] + tail)            # zlib refuses the member by itself ...
+            fn = str(tmp_path / ("second_" + name + ".gz"))
+            open(fn, "wb").write(raw)
+            d = zlib.decompressobj(31)
+            assert d.decompress(raw) == text[:200000] and d.eof and d.unused_data == tail   # ... which is what gzread() meets behind the good one (Python's own gzip module parses headers itself and lets reserved flags pass)
+            for ch, thr in ((1 << 21, 4), (20000, 8), (3000, 3)):
+                yak_amd.gz_tune(ch, 0, -1)
+                with pytest.raises(OSError):
+                    yak_amd.gz_inflate(fn, thr)
         assert yak_amd.gz_inflate(str(tmp_path / "cut.gz")[:-6] + "nope.gz", 4) is None
         open(str(tmp_path / "plain.txt"), "wb").write(text[:100000])
         assert yak_amd.gz_inflate(str(tmp_path / "plain.txt"), 4) is None          # not gzip: the caller keeps its own path

@@ -389,16 +389,18 @@ struct Run {                                                   /* what one decod
 
 /* behind a final block: the member's trailer, then the next member's header, zlib's gz_look()/gz_head() way -- anything that is not a gzip header
  * ends the stream ("trailing garbage is ignored").  `bit` is the bit behind the final block; returns the bit of the next member's first block */
-static bool next_member(const uint8_t *in, size_t n, uint64_t bit, uint32_t *crc, uint32_t *isize, uint64_t *next_bit, bool *trunc)
+static bool next_member(const uint8_t *in, size_t n, uint64_t bit, uint32_t *crc, uint32_t *isize, uint64_t *next_bit, bool *trunc, bool *bad)
 {
 	size_t p = (size_t)((bit + 7) >> 3);
-	*trunc = false;
+	*trunc = *bad = false;
 	if (p + 8 > n) { *trunc = true; return false; }
 	*crc = in[p] | in[p + 1] << 8 | in[p + 2] << 16 | (uint32_t)in[p + 3] << 24;
 	*isize = in[p + 4] | in[p + 5] << 8 | in[p + 6] << 16 | (uint32_t)in[p + 7] << 24;
 	p += 8;
 	*next_bit = (uint64_t)p * 8;
-	if (p + 10 > n || in[p] != 0x1f || in[p + 1] != 0x8b || in[p + 2] != 8 || (in[p + 3] & 0xe0)) return false;
+	if (p + 2 > n || in[p] != 0x1f || in[p + 1] != 0x8b) return false;
+	if (p + 4 <= n && (in[p + 2] != 8 || (in[p + 3] & 0xe0))) { *bad = true; return false; }   /* the magic commits zlib to a member: "unknown compression method" / "unknown header flags set" */
+	if (p + 10 > n) return false;
 	const int flg = in[p + 3];
 	p += 10;
 	if (flg & 4) { if (p + 2 > n) return false; p += 2 + (in[p] | in[p + 1] << 8); }
@@ -474,13 +476,14 @@ static void decode_run(const uint8_t *inp, size_t n, uint64_t bit, uint64_t limi
 		R.end = bit;
 		if (bfinal) {
 			Mark m; m.out_at = O.n; m.crc = m.isize = 0;
-			bool trunc = false;
+			bool trunc = false, bad = false;
 			uint64_t nb = bit;
-			const bool more = next_member(inp, n, bit, &m.crc, &m.isize, &nb, &trunc);
+			const bool more = next_member(inp, n, bit, &m.crc, &m.isize, &nb, &trunc, &bad);
 			if (trunc) { R.rc = D_TRUNC; R.stream_end = true; return; }   /* the trailer is cut: gzread delivers the data and reports the end */
 			R.marks.push_back(m);
 			R.end = bit = nb;
-			O.hist = 0;                                           /* a new member starts with an empty window ... */
+			if (bad) { R.rc = D_DATA; R.stream_end = true; return; }      /* 1f 8b followed by a method / flags zlib refuses */
+			O.hist = (size_t)0 - O.n;                             /* a new member starts with an empty window: o + hist = the bytes of THIS member in front of o (modulo 2^64) ... */
 			if (!more) { R.stream_end = true; return; }
 			if (sizeof(T) == 2) return;                             /* ... which a run of symbols cannot express: the stitch goes on from here, exactly */
 		}
@@ -735,6 +738,7 @@ struct Reader {
 			}
 			pieces.push_back(std::move(pc));
 			pos = w.run.end;
+			if (w.run.rc == D_DATA) { fail("gzip: invalid deflate data"); return; }   /* (only a member header zlib refuses: any other error just ends a run of symbols) */
 			if (w.run.stream_end) ended = true;
 		}
 		if (!ended && !fill_gap(batch_end)) return;

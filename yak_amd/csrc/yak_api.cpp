@@ -429,6 +429,7 @@ struct DumpSink {
 bool DumpSink::put(int dev, hipStream_t st, const uint8_t *d_src, size_t bytes, size_t off)
 {
 	if (bytes == 0) return true;
+	if (hipSetDevice(dev) != hipSuccess) return false;            /* the events below are recorded on `st`: they must be this device's */
 	if (mem) return hipMemcpyAsync(mem + off, d_src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
 	enum { NB = 6, W = 3 };
 	const size_t CH = (size_t)8 << 20, n_ch = (bytes + CH - 1) / CH;
@@ -437,7 +438,7 @@ bool DumpSink::put(int dev, hipStream_t st, const uint8_t *d_src, size_t bytes, 
 	std::lock_guard<std::mutex> lk(mu);
 	for (int i = 0; i < NB; ++i) if (!stage[i] && hipHostMalloc(&stage[i], CH, hipHostMallocPortable) != hipSuccess) { stage[i] = 0; return false; }
 	hipEvent_t ev[NB];
-	for (int i = 0; i < NB; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+	for (int i = 0; i < NB; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { while (i-- > 0) (void)hipEventDestroy(ev[i]); return false; }
 	std::vector<int> issued_v(n_ch, 0), written_v(n_ch, 0);
 	volatile int *issued = issued_v.data(), *written = written_v.data();
 	bool good = true;
@@ -759,7 +760,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 	int64_t par_size = parallel_source(fn, fx, n_thr, 1 << 20, &psrc, &psrc_fd) ? psrc.size : -1;   /* plain or block-gzipped regular file */
 	pgz::Reader *gz_p = new pgz::Reader;
 	pgz::Reader &gz = *gz_p;
-	struct GzDrop { pgz::Reader *p; ~GzDrop() { pgz::Reader *q = p; std::thread([q]() { delete q; }).detach(); } } gz_drop{ gz_p };   /* (its buffers go back to the system behind the caller's back) */
+	struct GzDrop { pgz::Reader *p; ~GzDrop() { pgz::Reader *q = p; yk_reap_later([q]() { delete q; }); } } gz_drop{ gz_p };   /* (its buffers go back to the system behind the caller's back) */
 	const bool use_gz = par_size < 0 && gz_source(fn, fx, n_thr, &gz);   /* an ordinary gzip file */
 	if (use_gz) par_size = 0;
 	int ok = 0;
@@ -779,7 +780,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		const bool pack = !yk_knob("YAKAMD_NO_HOST_PACK", 0);          /* the stream crosses the bus at 0.375 B per base, packed by the threads that parsed it */
 		psrc.pack = pack;
 		double t_sink = 0, t_open_wait = 0;
-		g_t_parse_windows = 0;
+		g_t_parse_windows.store(0, std::memory_order_relaxed);
 		const ImgSink sink = [&](const char *img, size_t img_n, int64_t ns, const WinPack *packed) {
 			const double ts0 = yk_realtime();
 			if (opener.joinable()) { opener.join(); t_open_wait = yk_realtime() - ts0; }
@@ -794,7 +795,7 @@ yak_ch_t *yak_count(const char *fn, const yak_copt_t *opt, yak_ch_t *h0)
 		const double tp0 = yk_realtime();
 		const bool parsed = use_gz ? parse_gz(&gz, opt->k, n_thr, sink, pack) : parse_parallel(&psrc, opt->k, n_thr, sink);
 		if (getenv("YAKAMD_VERBOSE")) fprintf(stderr, "[yak_amd] reader: %.3f s from the first window to the last piece fed; the windows took %.3f s to parse (the first %.3f s), the feeds %.3f s (%.3f s of it waiting for the new table)\n",
-		                                      yk_realtime() - tp0, g_t_parse_windows, g_t_first_window, t_sink, t_open_wait);
+		                                      yk_realtime() - tp0, g_t_parse_windows.load(), g_t_first_window.load(), t_sink, t_open_wait);
 		if (opener.joinable()) opener.join();
 		if (h == 0) { if (psrc_fd >= 0) ::close(psrc_fd); fx.close_file(); return 0; }
 		ok = ok && parsed;
@@ -1017,7 +1018,7 @@ void yak_qv(const yak_qopt_t *opt, const char *fn, const yak_ch_t *ch, int64_t *
 	const int n_thr = parse_threads(opt->n_threads);
 	ByteSource psrc; int psrc_fd = -1;
 	pgz::Reader *gz_p = new pgz::Reader;
-	struct GzDrop { pgz::Reader *p; ~GzDrop() { pgz::Reader *q = p; std::thread([q]() { delete q; }).detach(); } } gz_drop{ gz_p };
+	struct GzDrop { pgz::Reader *p; ~GzDrop() { pgz::Reader *q = p; yk_reap_later([q]() { delete q; }); } } gz_drop{ gz_p };
 	bool parallel = false;
 	if (ok && !opt->print_each && !opt->print_err_kmer) {
 		const ImgSink sink = [&](const char *img, size_t n, int64_t, const WinPack*) {

@@ -16,6 +16,7 @@
 #include <unistd.h>
 #include <cstdarg>
 #include <thread>
+#include <atomic>
 #include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -419,7 +420,10 @@ struct WinPack { std::vector<const void*> codes, valid; std::vector<int64_t> n_w
 /* what takes the parsed pieces, in stream order: the base image (sequences, each followed by '\n'), its bytes, its sequences, and -- when the
  * source asked for it (ByteSource::pack) -- no ASCII image but the packed pieces of a whole window (n = its stream positions), else 0 */
 typedef std::function<bool(const char*, size_t, int64_t, const WinPack*)> ImgSink;
-extern double g_t_parse_windows, g_t_first_window;           /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one */
+extern std::atomic<double> g_t_parse_windows, g_t_first_window;   /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one; statistics of the LAST call when several run at once */
+/* memory handed back behind the caller's back (some GB of images, the inflater's buffers: ~0.1 s of munmap): on a thread that the library joins before it goes --
+ * at exit() or dlclose() -- and not on a detached one, which could still be inside free() while the process tears down or the code is unmapped */
+void yk_reap_later(std::function<void()> f);
 int parse_threads(int n_thread);
 bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64_t min_size, ByteSource *src, int *own_fd);
 bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const ImgSink &sink, int64_t *stopped_at = 0, bool *stream_ended = 0);

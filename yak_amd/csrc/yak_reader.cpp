@@ -3,6 +3,7 @@
  * packer of the base image, the reader of ordinary gzip files (pgz.h).  The record reader itself (FxReader) and the byte source are in yak_host.h.
  */
 #include "yak_host.h"
+#include <memory>
 
 
 /* ------------------------------------------------------------------------------------------
@@ -246,7 +247,23 @@ bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64_t min_
 /* calls sink(image bytes, n_bytes, n_seq) for consecutive pieces of the input, in order; false if sink failed.
  * Two sets of segment buffers: while the sink consumes one window (copy to the device + kernels), the parser
  * threads already work on the next one. */
-double g_t_parse_windows = 0, g_t_first_window = 0;    /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one */
+namespace {
+struct Reaper {
+	struct Job { std::thread t; std::shared_ptr<std::atomic<bool>> done; };
+	std::mutex mu; std::vector<Job> jobs;
+	void later(std::function<void()> f) {
+		std::lock_guard<std::mutex> g(mu);
+		for (size_t i = 0; i < jobs.size(); ) if (jobs[i].done->load(std::memory_order_acquire)) { jobs[i].t.join(); jobs[i] = std::move(jobs.back()); jobs.pop_back(); } else ++i;
+		auto done = std::make_shared<std::atomic<bool>>(false);
+		jobs.push_back(Job{ std::thread([f, done]() { f(); done->store(true, std::memory_order_release); }), done });
+	}
+	~Reaper() { for (Job &j : jobs) if (j.t.joinable()) j.t.join(); }
+};
+Reaper g_reaper;                                                /* destroyed -- its threads joined -- when the process exits or the library is closed */
+}
+void yk_reap_later(std::function<void()> f) { g_reaper.later(std::move(f)); }
+
+std::atomic<double> g_t_parse_windows{0}, g_t_first_window{0};    /* YAKAMD_VERBOSE: wall time of the window parses (they overlap the sink), of the first one */
 /* A parser thread fills a ring of window sets while the caller's thread hands the finished windows to the sink, in order: two sets for
  * ASCII pieces (the sink copies a window to the device while the next one is parsed), four when the windows are packed -- a new table's
  * first feed waits ~0.25 s for the runtime to come up, time in which the parser gets through 2 GB of file instead of standing still */
@@ -276,7 +293,7 @@ bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const ImgSink 
 			w.done = false;
 			w.n_ok = parse_window(fd, size, pos, WIN, min_len, n_thr, w.seg, &w.next, &w.done, &w.wp);
 			const double dt = yk_realtime() - t;
-			g_t_parse_windows += dt; if (k == 0) g_t_first_window = dt;
+			g_t_parse_windows.store(g_t_parse_windows.load(std::memory_order_relaxed) + dt, std::memory_order_relaxed); if (k == 0) g_t_first_window.store(dt, std::memory_order_relaxed);
 			/* (a partial source: a window that gets nowhere stands at a record that wants the bytes still to come) */
 			const bool more = !w.done && w.next < size && !(fd->partial && w.next == pos);
 			pos = w.next;
@@ -300,7 +317,7 @@ bool parse_parallel(const ByteSource *fd, int min_len, int n_thr, const ImgSink 
 		if (!ok) break;
 	}
 	producer.join();
-	std::thread([ring_p]() { delete ring_p; }).detach();          /* (giving some GB of images back to the system takes ~0.1 s: not in the caller's way) */
+	yk_reap_later([ring_p]() { delete ring_p; });                 /* (giving some GB of images back to the system takes ~0.1 s: not in the caller's way) */
 	return ok;
 }
 
