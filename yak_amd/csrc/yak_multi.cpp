@@ -40,6 +40,20 @@ static bool rccl_open(RcclApi *R)
 	return R->CommInitAll && R->CommDestroy && R->GroupStart && R->GroupEnd && R->Send && R->Recv;
 }
 
+/* The communicators of a device list are made once per process and kept: ncclCommInitAll over 8 GPUs takes of the order of a second and the
+ * first grouped send / recv of a pair sets its channels up, while a counting job of this size takes less than a second -- a process that counts
+ * again (the benchmark's steps, the second pass of the filtered protocol, a server) finds them here.  One job at a time holds them; a job that
+ * finds them taken makes its own and destroys them when it is done. */
+struct CommCache {
+	std::mutex mu;
+	bool opened, have_lib, busy;
+	RcclApi R;
+	std::vector<int> devs;
+	std::vector<ncclComm_t> comm;
+	CommCache() : opened(false), have_lib(false), busy(false) {}
+};
+static CommCache g_cc;
+
 /* Ranks own prefix ranges; chunks of the input live in SLOTS, one per distinct device (ranks that share a device -- the sweeps of one device
  * posing as several -- share its chunk, its partition and its buffers: the owner's slice of a chunk on its own device is fed where it lies).
  * Two sets of slot buffers: set x is being partitioned, exchanged and fed by a worker thread while the reader fills set 1 - x. */
@@ -50,6 +64,7 @@ struct MultiJob {
 	bool use_rccl;
 	RcclApi R;
 	std::vector<ncclComm_t> comm;                              /* per slot */
+	bool comm_cached;                                          /* they are g_cc's: handed back, not destroyed */
 	std::vector<uint8_t*> d_base[2];                           /* [set][slot]: chunk of sequence */
 	std::vector<uint64_t*> d_send[2], d_recv[2];               /* [set][slot]: records grouped by prefix / slices received from the other slots */
 	int64_t chunk, send_words, recv_words;
@@ -132,10 +147,22 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, i
 	J->use_rccl = S > 1 && !yk_knob("YAKAMD_MGPU_NO_RCCL", 0);
 	if (S < N) fprintf(stderr, "[M::yak_count] %d ranks on %d device%s: ranks that share a device share its chunks and take turns (their slices are fed where they lie)%s\n",
 	                   N, S, S > 1 ? "s" : "", S == 1 ? "; nothing is exchanged" : "");
+	J->comm_cached = false;
 	if (J->use_rccl) {
 		J->comm.assign(S, 0);
-		if (!rccl_open(&J->R)) { fprintf(stderr, "[W::yak_count] librccl.so not found: exchanging with peer copies\n"); J->use_rccl = false; }
-		else { const ncclResult_t r = J->R.CommInitAll(J->comm.data(), S, J->sdev.data()); if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; } }
+		std::lock_guard<std::mutex> lk(g_cc.mu);
+		if (!g_cc.opened) { g_cc.have_lib = rccl_open(&g_cc.R); g_cc.opened = true; }
+		J->R = g_cc.R;
+		if (!g_cc.have_lib) { fprintf(stderr, "[W::yak_count] librccl.so not found: exchanging with peer copies\n"); J->use_rccl = false; }
+		else if (!g_cc.busy && g_cc.devs == J->sdev && !g_cc.comm.empty()) { J->comm = g_cc.comm; J->comm_cached = g_cc.busy = true; }
+		else {
+			const ncclResult_t r = J->R.CommInitAll(J->comm.data(), S, J->sdev.data());
+			if (r != ncclSuccess) { fprintf(stderr, "[W::yak_count] ncclCommInitAll: %s; exchanging with peer copies\n", J->R.GetErrorString ? J->R.GetErrorString(r) : "error"); J->use_rccl = false; }
+			else if (!g_cc.busy) {       /* these become the process's (those of another device list go) */
+				for (ncclComm_t c_ : g_cc.comm) if (c_) J->R.CommDestroy(c_);
+				g_cc.comm = J->comm; g_cc.devs = J->sdev; J->comm_cached = g_cc.busy = true;
+			}
+		}
 	}
 	for (int s = 0; s < S; ++s) {
 		if (hipSetDevice(J->sdev[s]) != hipSuccess || hipStreamCreate(&J->st[s]) != hipSuccess || hipStreamCreateWithFlags(&J->cp[s], hipStreamNonBlocking) != hipSuccess) return false;
@@ -160,8 +187,9 @@ static void multi_close(MultiJob *J)
 		for (int x = 0; x < 2; ++x) { if (!J->ext_base) yk_pool_release(J->d_base[x][s]); yk_pool_release(J->d_send[x][s]); yk_pool_release(J->d_recv[x][s]); J->d_base[x][s] = 0; J->d_send[x][s] = 0; J->d_recv[x][s] = 0; }
 		if (J->st[s]) { hipStreamDestroy(J->st[s]); J->st[s] = 0; }
 		if (J->cp[s]) { hipStreamDestroy(J->cp[s]); J->cp[s] = 0; }
-		if (J->use_rccl && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
+		if (!J->comm_cached && s < (int)J->comm.size() && J->comm[s]) { J->R.CommDestroy(J->comm[s]); J->comm[s] = 0; }
 	}
+	if (J->comm_cached) { std::lock_guard<std::mutex> lk(g_cc.mu); g_cc.busy = false; J->comm_cached = false; }
 }
 
 /* one round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Partition, exchange, feed. */
@@ -222,6 +250,10 @@ static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int c
 			/* the collective library let the round down: the same slices as plain peer copies, from here on */
 			fprintf(stderr, "[W::yak_count] RCCL exchange failed (%s): peer copies from now on\n", hipGetErrorString(hipGetLastError()));
 			J->use_rccl = false; ok[0] = 1;
+			if (J->comm_cached) {                                       /* nobody is handed these again (left as they are: destroying a communicator with a failed operation in it may hang) */
+				std::lock_guard<std::mutex> lk(g_cc.mu);
+				g_cc.comm.clear(); g_cc.devs.clear(); g_cc.busy = false; J->comm_cached = false; J->comm.assign(S, 0);
+			}
 			for (int s = 0; s < S; ++s) for (int q = 0; q < S; ++q) if (q != s) { hipSetDevice(J->sdev[s]); (void)hipDeviceEnablePeerAccess(J->sdev[q], 0); }
 			(void)hipGetLastError();
 			for (int s = 0; s < S; ++s)
