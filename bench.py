@@ -862,7 +862,9 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc, pmc_src = {}, None
-    for cand_ in (("r05_pmc_traffic_nofilter.json", "r04_pmc_traffic_nofilter.json") if a.bf_shift == 0 else ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    default_cfg = world == 1 and not a.no_retain and ((a.reads == 10_000_000 and a.bf_shift in (37, 0)) or (a.reads == 30_000_000 and a.bf_shift == 37))     # (the counter passes were taken on these commands, no other)
+    for cand_ in (("r05_pmc_traffic_30m.json",) if a.reads == 30_000_000 else ("r05_pmc_traffic_nofilter.json", "r04_pmc_traffic_nofilter.json") if a.bf_shift == 0 else
+                  ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand_)))
             pmc_src = "profiles/" + cand_
@@ -871,15 +873,14 @@ def main():
             pass
     for k_ in kern:
         keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
-        cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if a.reads == 10_000_000 and world == 1 and a.bf_shift in (37, 0) and not a.no_retain else []
-        steps_pmc = max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))     # k_lc2 (any template variant) runs once per step: the steps of the profiled command
+        cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if default_cfg else []
+        steps_pmc = 1 if a.reads == 30_000_000 else max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))     # k_lc2 (any template variant) runs once per step: the steps of the profiled command
         k_["traffic_bytes"] = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for v in cand) if cand else None
         # how busy the HBM really is while this kernel (group) runs: counter bytes / its time / peak
         k_["hbm_util"] = (k_["traffic_bytes"] / (k_["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (k_["traffic_bytes"] and k_["ms"] > 0) else None
-    default_cfg = a.reads == 10_000_000 and world == 1 and a.bf_shift in (37, 0) and not a.no_retain     # (the counter passes were taken on these commands, no other)
     step_traffic = None
     if default_cfg and pmc:                                       # every kernel of one protocol step, whatever its name
-        steps_pmc = max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))
+        steps_pmc = 1 if a.reads == 30_000_000 else max(1, sum(v["launches"] for n_, v in pmc.items() if n_.startswith("k_lc2") and isinstance(v, dict) and "launches" in v))
         step_traffic = sum(v["launches"] / steps_pmc * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"])
                            for v in pmc.values() if isinstance(v, dict) and "launches" in v)
     # the pass and the step as a whole against the same roof: SURVEY 8(d)'s algorithmic bytes of every instance

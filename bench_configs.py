@@ -144,6 +144,8 @@ def run_cfg4_sweeps(a, yak_amd):
     if not all(v for v in verify.values() if isinstance(v, bool)):
         raise SystemExit(f"FAILED: {verify}")
     by = 32.0 * inst
+    # counter bytes of ONE job: the profiled command (`--no-verify`: the two chunkings, no warm-up) runs two
+    roof_t = _roof_traffic({}, f"cfg4_{a.contigs}x{a.contig_len}_sweeps{a.sweeps}", dt, scale={"": 0.5})
     return {"metric": "distinct k-mers counted/sec (k=21), yak count on an assembly (no filter, singletons kept), file-inclusive, pass in sweeps over prefix ranges",
             "value": tot / dt, "unit": "distinct k-mers/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": dt * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -153,7 +155,8 @@ def run_cfg4_sweeps(a, yak_amd):
             "first_job_ms": FIRST.get("ms"), "first_job_note": "the first yak_count() of the process: beyond the ~112 GB the driver hands out at once, device memory costs ~30 ms per GB the first time (tests/tools/mb/mb_malloc.hip, profiles/r05_mb_malloc.txt)",
             "peak_hbm_bytes": FIRST.get("peak"),
             "roofline": {"bound": "hbm", "kernel": "whole yak_count() call (parse + sweeps)", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_instance": 32.0},
+                         "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": roof_t["traffic"], "hbm_util": roof_t["hbm_util"],
+                         "traffic_source": (roof_t["traffic_source"] + "; half of the profiled command's two jobs") if roof_t["traffic_source"] else None, "algorithmic_bytes_per_instance": 32.0},
             "verify": verify}
 
 
