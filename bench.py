@@ -360,19 +360,25 @@ def run_multi_c(a):
 
 
 def _device_or_retry():
-    """A process that starts within seconds of the exit of one that held a few hundred GB of device memory can find NO device (the driver is still
-    taking that memory back: seen in round 5 right behind 1 Gb-assembly runs).  Asked in a child process, so that this one's import order stays what
-    INTEGRATION.md asks for (torch before libyak_amd.so, in the configurations that use torch): wait and ask again, a few times; if the device stays
-    away the configuration's own check fails loudly as before."""
-    probe = ("import sys; sys.path.insert(0, %r); import yak_amd; sys.exit(0 if yak_amd.lib().yakamd_device_count() >= 1 else 3)" % ROOT)
-    for attempt in range(6):
+    """A process that starts within seconds of the exit of another one that used the device (seen in round 5 right behind 1 Gb-assembly runs, and once right
+    behind a 15 s pytest run) can find NO device: `No HIP GPUs are available` from torch, an empty device list from the HIP runtime -- and the runtime keeps
+    that answer for the life of the process.  So the question is asked in a CHILD process first (torch, then libyak_amd.so: the import order INTEGRATION.md
+    asks for), again every 5 s for up to a minute while the answer is no or the child fails; if the device stays away, the configuration's own check fails
+    loudly as before."""
+    probe = ("import sys; sys.path.insert(0, %r)\n"
+             "import torch\n"
+             "ok = torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+             "if ok: torch.cuda.init()\n"
+             "import yak_amd\n"
+             "sys.exit(0 if ok and yak_amd.lib().yakamd_device_count() >= 1 else 3)\n" % ROOT)
+    for attempt in range(12):
         try:
-            rc = subprocess.run([sys.executable, "-c", probe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120).returncode
+            rc = subprocess.run([sys.executable, "-c", probe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180).returncode
         except Exception:
             return
-        if rc != 3:
+        if rc == 0:
             return
-        print(f"[bench] no gfx950 device visible yet: asking again in 5 s (attempt {attempt + 1} of 6)", file=sys.stderr)
+        print(f"[bench] no gfx950 device visible yet (probe exit code {rc}): asking again in 5 s (attempt {attempt + 1} of 12)", file=sys.stderr)
         time.sleep(5)
 
 
