@@ -377,3 +377,56 @@ def test_gzip_reader_randomised(seed, tmp_path):
             assert yak_amd.gz_inflate(fn, rnd.choice([1, 2, 3, 8, 13])) == want
     finally:
         yak_amd.gz_tune(1 << 20, 4 << 20, 64 << 20)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gzip_reader_on_damaged_streams_follows_zlib(seed, tmp_path):
+    """one to three flipped bits anywhere in a one-member and a many-member file, 120 damaged files per seed: whatever zlib makes of the stream decides --
+    it inflates to the end (damage in a header field nobody checks, behind the last member): the same bytes; it ends early without an error (trailing bytes
+    that are no member): the same bytes; it reports an error (data, CRC32, ISIZE, a refused member header): the reader fails, it never hands out other bytes"""
+    import zlib
+    import yak_amd
+    rnd = random.Random(9100 + seed)
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGT") for _ in range(100)), "".join(chr(33 + rnd.randrange(41)) for _ in range(100))) for i in range(1500)).encode()
+    forms = [gzip.compress(text, 6), b"".join(gzip.compress(text[i:i + 70000], 5) for i in range(0, len(text), 70000))]
+
+    def gzread(raw):
+        """(bytes, state) the way gzread() goes through members: 'ok', 'trunc' (the input ends inside a member: what there is is delivered), 'error'"""
+        out, data, first = b"", raw, True
+        while data:
+            d = zlib.decompressobj(31)
+            try:
+                out += d.decompress(data)
+            except zlib.error:
+                if not first and not (len(data) >= 2 and data[0] == 0x1f and data[1] == 0x8b):
+                    return out, "ok"                                   # not a member: trailing garbage, ignored
+                return out, "error"
+            if not d.eof:
+                return out, "trunc"
+            data, first = d.unused_data, False
+        return out, "ok"
+    try:
+        for it in range(120):
+            raw = bytearray(rnd.choice(forms))
+            for _ in range(rnd.choice([1, 1, 1, 2, 3])):
+                raw[rnd.randrange(len(raw))] ^= 1 << rnd.randrange(8)
+            raw = bytes(raw)
+            want, state = gzread(raw)
+            fn = str(tmp_path / "d.gz")
+            open(fn, "wb").write(raw)
+            ch, thr = rnd.choice([(1 << 21, 4), (20000, 8), (3000, 3)])
+            yak_amd.gz_tune(ch, 0, -1)
+            try:
+                got, err = yak_amd.gz_inflate(fn, thr), None
+            except OSError as e:
+                got, err = None, str(e)
+            if raw[:3] != b"\x1f\x8b\x08" or raw[3] & 0xe0:
+                assert got is None                                     # the first header is not one the reader takes (the caller's zlib path reports it)
+            elif state == "ok":
+                assert got == want, (seed, it, ch, err)
+            elif state == "trunc":
+                assert got == want or err is not None, (seed, it, ch)
+            else:
+                assert err is not None, (seed, it, ch, None if got is None else len(got))
+    finally:
+        yak_amd.gz_tune(1 << 20, 4 << 20, 64 << 20)
