@@ -383,7 +383,8 @@ def _device_or_retry():
 
 
 def main():
-    _device_or_retry()
+    if int(os.environ.get("RANK", "0")) == 0 or "--driver" in sys.argv:   # (under torch.distributed.run only rank 0 drives the devices, the others wait at its barrier -- unless `--driver torch` gives every rank its own)
+        _device_or_retry()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
