@@ -352,7 +352,7 @@ def run_multi_c(a):
                         "algorithmic_bytes_per_instance": by / max(1, inst / (2 if bf else 1))},
            "cpu_baseline": None, "cpu_baseline_note": "timed at N = 1 only (rank 0, bounded sample of the N = 1 workload): the `--gpus 1` line carries it",
            "scaling_note": f"weak: {per_gpu} reads per GPU at every N > 1 (8 GPUs = BASELINE configs[2]); the `--gpus 1` line is configs[1] (10 M reads, filtered protocol), a different "
-                           "job -- ONE rank's share of the 8-GPU job on one GPU is `--config cfg3shard` (profiles/r05_bench_cfg3shard.json: 0.61 s, the exchange not in it)",
+                           "job -- ONE rank's share of the 8-GPU job on one GPU is `--config cfg3shard` (profiles/r05_bench_cfg3shard.json: 0.51 s, the exchange not in it)",
            "verify": verify}
     print(json.dumps(out))
     if world > 1:

@@ -1613,10 +1613,11 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	lap("k_replay part + load", 0, bmaxS, &tl);
 	for (size_t k = 0; k < n_steps; ++k) {
 		u32 bd = 0, bp = 0; bool any_d = false, any_p = false;
+		int p_lo = P, p_hi = 0;                                      /* the sub-tables that place in this step: a shard's are a contiguous range of the P */
 		for (int p = 0; p < P; ++p) {
 			const R2Act &a = acts[k * P + p];
 			if (a.kind == 2) { any_d = true; bd = std::max(bd, a.bits); }
-			else if (a.kind == 1) { any_p = true; bp = std::max(bp, a.bits); }
+			else if (a.kind == 1) { any_p = true; bp = std::max(bp, a.bits); p_lo = std::min(p_lo, p); p_hi = p + 1; }
 		}
 		const R2Act *da = d_acts + k * P;
 		if (any_d) {
@@ -1631,7 +1632,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st);
 			lap("double (fused rounds)", k, bd, &tl);
 		}
-		if (any_p) { yk_r2_place(d_tabs, da, P, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, c->st); lap("place", k, bp, &tl); }
+		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, c->st); lap("place", k, bp, &tl); }
 	}
 	u64 *img_k = 0;                                               /* the new image, once it is certain */
 	if (inplace) {
