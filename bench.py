@@ -425,6 +425,8 @@ def main():
     a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
     if a.knob:                                                    # the library is loaded once per process: one place serves every mode below
+        if a.config in ("cfg3shard", "cfg4", "cfg5"):
+            import torch                                          # (these modes hold their inputs in torch tensors: torch finds no device if the library's HIP runtime is up first)
         import yak_amd
         for kv in a.knob:
             name, _, val = kv.partition("=")

@@ -1407,11 +1407,11 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	std::vector<u32> trail(P, 0);
 	std::vector<u64> lp_host(P, 0);
 	u32 *d_m = 0, *d_trail = 0; u64 *d_ro = 0, *d_lp2 = 0;
-	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
+	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *USED = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
 	ReplayTask *d_tasks = 0; R2Tab *d_tabs = 0; R2Act *d_acts = 0; R2Load *d_ld = 0; R2Pub *d_pub = 0;
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
 		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so);
-		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
+		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(USED); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
 	} };
 	if (d_lastput) {
 		if (dmalloc(&d_m, P) || dmalloc(&d_trail, P) || dmalloc(&d_ro, P) || dmalloc(&d_lp2, P)) return -1;
@@ -1592,7 +1592,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	const u32 spill_cap = (u32)std::min<u64>(1u << 28, std::max<u64>(1u << 20, tot2 / 16));   /* also the list of long runs of a doubling round */
 	u64 n_keys = 0;
 	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
-	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
+	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&USED, tot2 / 32 + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
 	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 4 * (size_t)P) || dmalloc(&misc, 4)) return -1;
 	HIPCK(hipMemcpyAsync(d_tabs, tabs.data(), P * sizeof(R2Tab), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_acts, acts.data(), acts.size() * sizeof(R2Act), hipMemcpyHostToDevice, c->st));
@@ -1600,7 +1600,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemsetAsync(misc, 0, 16, c->st));
 	u32 *d_fail = misc, *d_nspill = misc + 1;
-	yk_r2_load(d_tabs, d_ld, P, bmaxS, nk, c->d_keys, K0, K1, c->st);
+	yk_r2_load(d_tabs, d_ld, P, bmaxS, nk, c->d_keys, K0, K1, USED, c->st);
 	const bool prof = env_i64("YAKAMD_VERBOSE", 0) > 1;
 	auto lap = [&](const char *what, size_t k, u32 bits, double *t0) {
 		if (!prof) return;
@@ -1621,18 +1621,18 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 		}
 		const R2Act *da = d_acts + k * P;
 		if (any_d) {
-			yk_r2_dinit(d_tabs, da, P, bd, K0, K1, TAG, OCC, c->st);
-			lap("dinit", k, bd, &tl);
+			yk_r2_binit(d_tabs, da, P, bd, OCC, USED, c->st);
+			lap("binit", k, bd, &tl);
 			int n_dbl = 0;
 			for (int p = 0; p < P; ++p) n_dbl += acts[k * P + p].kind == 2;
-			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, Fc, Fc + 2 * P, d_fail, c->st);
+			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, USED, Fc, Fc + 2 * P, d_fail, c->st);
 			lap("dsmall", k, bd, &tl);
 			/* the rounds from there on in one launch: a workgroup per sub-table walks its rounds behind workgroup barriers.  A sub-table that does
 			 * not reach its end raises `fail` (read once, after the last step: whatever the later steps then do is thrown away with the buffers) */
-			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, Fc, Fc + P, d_fail, c->st);
+			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, USED, Fc, Fc + P, d_fail, c->st);
 			lap("double (fused rounds)", k, bd, &tl);
 		}
-		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, c->st); lap("place", k, bp, &tl); }
+		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, USED, c->st); lap("place", k, bp, &tl); }
 	}
 	u64 *img_k = 0;                                               /* the new image, once it is certain */
 	if (inplace) {
