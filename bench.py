@@ -872,14 +872,21 @@ def main():
     # (profiles/r01k_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
     pmc, pmc_src = {}, None
     default_cfg = world == 1 and not a.no_retain and ((a.reads == 10_000_000 and a.bf_shift in (37, 0)) or (a.reads == 30_000_000 and a.bf_shift == 37))     # (the counter passes were taken on these commands, no other)
-    for cand_ in (("r05_pmc_traffic_30m.json",) if a.reads == 30_000_000 else ("r05_pmc_traffic_nofilter.json", "r04_pmc_traffic_nofilter.json") if a.bf_shift == 0 else
-                  ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    for cand_ in (("r06_pmc_traffic_30m.json", "r05_pmc_traffic_30m.json") if a.reads == 30_000_000 else ("r06_pmc_traffic_nofilter.json", "r05_pmc_traffic_nofilter.json", "r04_pmc_traffic_nofilter.json") if a.bf_shift == 0 else
+                  ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand_)))
             pmc_src = "profiles/" + cand_
             break
         except Exception:
             pass
+    # the counter bytes belong to the device code they were measured on: another tree -> no traffic figure (a stale constant would say nothing about this build)
+    k_now = yak_amd.kernels_sha16()
+    k_on = (pmc.get("_measured_on") or {}).get("kernels_sha16") if pmc else None
+    traffic_note = None
+    if pmc and k_on != k_now:
+        traffic_note = f"{pmc_src} was measured on kernels {k_on}, this tree builds {k_now}: traffic is null until the counter passes are taken again (tests/tools/final_r06.sh)"
+        pmc = {}
     for k_ in kern:
         keys_ = [x for x in k_["kernel"].split(" (")[0].replace("*", "").split(" + ")]
         cand = [v for n_, v in pmc.items() if any(n_.startswith(key) for key in keys_) and isinstance(v, dict) and "launches" in v] if default_cfg else []
@@ -931,7 +938,8 @@ def main():
                      "frac": (step_gbs / HBM_PEAK_GBS) if step_gbs else None,
                      "traffic": step_traffic,
                      "hbm_util": (step_traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None,
-                     "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summed over the kernels of one step; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)") if step_traffic else None,
+                     "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summed over the kernels of one step; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes)") if step_traffic else traffic_note,
+                     "kernels_sha16": k_now, "traffic_measured_on_kernels_sha16": k_on,
                      "algorithmic_bytes_per_step": b_step,
                      "model": "SURVEY 8(d): bloom mode pass 1 = 16 + 128 + 16 f_ins bytes per instance (the reference touches a 64-byte bloom block per instance; "
                               "this design stages every bloom range once in LDS instead, so the 128 is a credit, not traffic), pass 2 = 16 + 8 + 8 f_hit; "

@@ -43,7 +43,7 @@ def pmc_step_traffic(name, scale=None, only=None):
     """HBM bytes of ONE step of a configuration from its committed rocprofv3 counter passes (profiles/r04_pmc_traffic_<name>.json: FETCH_SIZE x 2 as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, of a `--steps 1 --warmup 0 --no-verify` run of that very command): (bytes, source) or (None, None)"""
     d = None
-    for rnd in ("r05", "r04"):                                 # the latest round that profiled this configuration
+    for rnd in ("r06", "r05", "r04"):                          # the latest round that profiled this configuration
         fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{name}.json")
         try:
             d = json.load(open(fn))
@@ -52,11 +52,15 @@ def pmc_step_traffic(name, scale=None, only=None):
             pass
     if d is None:
         return None, None
+    import yak_amd
+    on, now = (d.get("_measured_on") or {}).get("kernels_sha16"), yak_amd.kernels_sha16()
+    if on != now:                                             # counter bytes of other kernels than the ones that run: not this build's traffic
+        return None, f"profiles/{rnd}_pmc_traffic_{name}.json was measured on kernels {on}, this tree builds {now}: no traffic figure until the counter passes are taken again"
     def w(k_):                                                # cfg3shard: the stand-ins for the peers' GPUs partition 7 of 8 chunks on this device
         return next((f for pre, f in (scale or {}).items() if k_.startswith(pre)), 1.0)
     by = sum(w(k_) * v["launches"] * (v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"]) for k_, v in d.items()
              if isinstance(v, dict) and "launches" in v and (only is None or k_.startswith(only)))
-    return by, f"profiles/{rnd}_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE)"
+    return by, f"profiles/{rnd}_pmc_traffic_{name}.json (every kernel of one step; FETCH_SIZE x2 + WRITE_SIZE; measured on kernels {on})"
 
 
 def _roof_traffic(roof, name, seconds, scale=None, only=None):
@@ -64,6 +68,8 @@ def _roof_traffic(roof, name, seconds, scale=None, only=None):
     roof["traffic"] = by
     roof["hbm_util"] = (by / seconds / 1e9 / HBM_PEAK_GBS) if by else None
     roof["traffic_source"] = src
+    import yak_amd
+    roof["kernels_sha16"] = yak_amd.kernels_sha16()
     return roof
 
 

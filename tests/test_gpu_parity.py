@@ -317,6 +317,7 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_LC2_WGS="3"), dict(YAKAMD_YTAG="0"), dict(YAKAMD_YTAG="0", YAKAMD_OWN_LDS="18500", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="5"), dict(YAKAMD_R2_SMALL_F="16"), dict(YAKAMD_R2_SMALL_F="1024"),
                                  dict(YAKAMD_REC8="0"), dict(YAKAMD_REC8_OUT="0"), dict(YAKAMD_REC8_OUT="0", YAKAMD_BATCH="16384"), dict(YAKAMD_BATCH="8192", YAKAMD_S2_BITS="3"),
                                  dict(YAKAMD_R2_SMALL_BITS="5"), dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_R2_SMALL_BITS="7", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_REPLAY2="0"),
+                                 dict(YAKAMD_R2_SMALL_BITS="5", YAKAMD_R2_SEG_LOG="10", YAKAMD_R2_PPART_G="3"), dict(YAKAMD_R2_SMALL_BITS="6", YAKAMD_R2_SEG_LOG="10", YAKAMD_R2_PPART_G="16", YAKAMD_R2_DBL="64"),
                                  dict(YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"), dict(YAKAMD_FAST_BUDGET="1100000", YAKAMD_BATCH="65536"),
                                  dict(YAKAMD_FAST_BUDGET="40000000", YAKAMD_BATCH="1048576"),
                                  dict(YAKAMD_S2_BITS="0", YAKAMD_OVF_SCRATCH_WORDS="200000"), dict(YAKAMD_SLICE_SB="1", YAKAMD_BATCH="65536"),
@@ -332,7 +333,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "key_owning_count_32_slot_ranges", "key_owning_count_cross_sweep", "key_owning_count_short_list", "three_tier_lds_kernels", "three_tier_lds_kernels_crowded",
                               "lc2_three_persistent_workgroups", "pass2_plain_hashes", "pass2_plain_hashes_cross_sweep", "replay_prefix_16", "replay_prefix_1024",
                               "rec16_records", "tagged_in_rec16_out", "tagged_in_rec16_out_multibatch", "tagged_multibatch_s2_3",
-                              "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices",
+                              "streaming_replay_from_32_slots", "streaming_replay_1k_slot_segments", "streaming_replay_2k_slot_segments", "k_replay_only",
+                              "streaming_replay_keys_grouped_by_3_workgroups", "streaming_replay_keys_grouped_by_16_workgroups_6_wave_doubling", "pass_in_slices", "pass_in_single_batch_slices", "pass_in_two_slices",
                               "lds_overflow_to_global_in_groups", "slices_cut_by_sub_bucket_load",
                               "level2_two_sweeps", "level2_two_sweeps_plain_second_multibatch", "level2_two_sweeps_rec16_out", "level2_two_sweeps_rec16_in",
                               "level2_two_sweeps_16k_sub_buckets", "flat_gather", "flat_gather_multibatch", "one_workgroup_per_sub_table_gather",
@@ -373,10 +375,12 @@ def test_low_complexity_bursts(env, ya, oracle, synth, monkeypatch, knob):
 @pytest.mark.parametrize("env", [dict(), dict(YAKAMD_REPLAY_LDS="0"), dict(YAKAMD_REPLAY_LDS="8192"), dict(YAKAMD_REPLAY_LDS="8192", YAKAMD_PAR_REPLAY="0"),
                                  dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="10"), dict(YAKAMD_COUNT_OWN="0", YAKAMD_COUNT_LDS="0", YAKAMD_RNG_LOG="7", YAKAMD_XLIST_CAP="100"),
                                  dict(YAKAMD_R2_SMALL_BITS="10", YAKAMD_R2_SEG_LOG="11"), dict(YAKAMD_R2_SMALL_BITS="9", YAKAMD_R2_SEG_LOG="10"), dict(YAKAMD_REPLAY2="0"),
+                                 dict(YAKAMD_R2_SMALL_BITS="9", YAKAMD_R2_SEG_LOG="10", YAKAMD_R2_PPART_G="4"), dict(YAKAMD_R2_SMALL_BITS="8", YAKAMD_R2_SEG_LOG="11", YAKAMD_R2_DBL="62"), dict(YAKAMD_R2_SMALL_BITS="8", YAKAMD_R2_SEG_LOG="11", YAKAMD_R2_DBL="54"),
                                  dict(YAKAMD_OWN_LDS="30000", YAKAMD_OWN_MAXRB="12"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64"), dict(YAKAMD_OWN_LDS="21000", YAKAMD_OWN_MAXRB="12", YAKAMD_XLIST_CAP="64", YAKAMD_YTAG="0"), dict(YAKAMD_R2_SMALL_F="32"), dict(YAKAMD_REPLAY_LDS="32768"),
                                  dict(YAKAMD_REPLAY_LDS="2048"), dict(YAKAMD_REPLAY_LDS="1024", YAKAMD_REPLAY_THREADS="256"), dict(YAKAMD_REPLAY_LDS="2048", YAKAMD_DBG="256")],
                          ids=["lds_ranks", "global_ranks", "lds_16bit_ranks", "serial_doubling", "pass2_by_slot_ranges", "pass2_ranges_list_overflow",
                               "streaming_replay_2k_slot_segments", "streaming_replay_from_512_slots_1k_slot_segments", "k_replay_for_16k_slots",
+                              "streaming_replay_keys_grouped_by_4_workgroups", "doubling_6_waves_2_walks", "doubling_5_waves_4_walks",
                               "pass2_key_owning_ranges", "pass2_key_owning_ranges_list_overflow", "pass2_key_owning_ranges_plain_hashes", "replay_prefix_32", "lds_keys_for_small_stages",
                               "segmented_lds_ranks", "segmented_lds_ranks_small", "global_ranks_for_large_stages"])
 def test_replay_variants_on_large_subtables(env, ya, oracle, synth, monkeypatch, knob):

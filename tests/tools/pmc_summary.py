@@ -27,6 +27,13 @@ for k in sorted(ft, key=lambda k: -fns[k]):
     n = fc[k]
     res[k] = {"launches": n, "fetch_bytes_per_launch_x2_corrected": 2.0 * ft[k] / n, "write_bytes_per_launch": wt.get(k, 0.0) / max(1, wc.get(k, n))}
     rows.append((k, n, fns[k] / 1e6, ft[k] / 1e9, 2 * ft[k] / 1e9, wt.get(k, 0.0) / 1e9))
+# the device code these bytes were measured on (bench.py reports them only while the tree it runs from still has this value)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+try:
+    import yak_amd
+    res["_measured_on"] = {"kernels_sha16": yak_amd.kernels_sha16()}
+except Exception as e:
+    res["_measured_on"] = {"kernels_sha16": None, "error": str(e)}
 json.dump(res, open(out + "_pmc_traffic.json", "w"), indent=1)
 with open(out + "_pmc_hbm_bytes.csv", "w") as f:
     f.write("kernel,calls,total_ms,FETCH_SIZE_raw_GB,FETCH_SIZE_x2_GB,WRITE_SIZE_GB\n")

@@ -433,3 +433,15 @@ def host_image(fn, min_len=0, fast=True):
     data = C.string_at(out, n)
     C.CDLL(None).free(out)
     return data
+
+
+def kernels_sha16():
+    """sha256 (first 16 hex digits) over the device code the library is built from (csrc/kernels.hip, kern_*.inc, yk_device.h): the counter passes under
+    profiles/ carry the value they were measured on, and bench.py reports `roofline.traffic` only while it equals the value of the tree it runs from."""
+    import glob, hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(d, "kern_*.inc")) + [os.path.join(d, "kernels.hip"), os.path.join(d, "yk_device.h")]):
+        h.update(os.path.basename(fn).encode() + b"\0")
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]

@@ -1407,11 +1407,11 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	std::vector<u32> trail(P, 0);
 	std::vector<u64> lp_host(P, 0);
 	u32 *d_m = 0, *d_trail = 0; u64 *d_ro = 0, *d_lp2 = 0;
-	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *USED = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
+	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *USED = 0, *pcnt = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
 	ReplayTask *d_tasks = 0; R2Tab *d_tabs = 0; R2Act *d_acts = 0; R2Load *d_ld = 0; R2Pub *d_pub = 0;
 	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
 		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so);
-		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(USED); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
+		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(USED); dfree(pcnt); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
 	} };
 	if (d_lastput) {
 		if (dmalloc(&d_m, P) || dmalloc(&d_trail, P) || dmalloc(&d_ro, P) || dmalloc(&d_lp2, P)) return -1;
@@ -1594,6 +1594,10 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
 	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&USED, tot2 / 32 + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
 	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 4 * (size_t)P) || dmalloc(&misc, 4)) return -1;
+	/* few large sub-tables (a shard): the keys of a stage are grouped by G workgroups per sub-table instead of one (YAKAMD_R2_PPART_G: tests) */
+	int ppG = (int)std::min<int64_t>(16, std::max<int64_t>(1, env_i64("YAKAMD_R2_PPART_G", n_large <= 512 ? 1024 / std::max<u32>(1, n_large) : 1)));
+	if ((size_t)P * ppG > (64u << 10)) ppG = 1;                   /* (the counters are indexed by sub-table: 4 KB per sub-table and share) */
+	if (ppG > 1 && dmalloc(&pcnt, (size_t)P * ppG * 1024)) return -1;
 	HIPCK(hipMemcpyAsync(d_tabs, tabs.data(), P * sizeof(R2Tab), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_acts, acts.data(), acts.size() * sizeof(R2Act), hipMemcpyHostToDevice, c->st));
 	HIPCK(hipMemcpyAsync(d_ld, ld.data(), P * sizeof(R2Load), hipMemcpyHostToDevice, c->st));
@@ -1632,7 +1636,7 @@ static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_
 			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, USED, Fc, Fc + P, d_fail, c->st);
 			lap("double (fused rounds)", k, bd, &tl);
 		}
-		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, USED, c->st); lap("place", k, bp, &tl); }
+		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, USED, pcnt, ppG, c->st); lap("place", k, bp, &tl); }
 	}
 	u64 *img_k = 0;                                               /* the new image, once it is certain */
 	if (inplace) {
@@ -1803,23 +1807,32 @@ static int fast_finish(yakamd_ctx *c, bool last)
 		            env_i64("YAKAMD_RETAIN2", 1) != 0 && env_i64("YAKAMD_BF_DEFER", 1) != 0 && env_i64("YAKAMD_LC2", 1) != 0 && env_i64("YAKAMD_LC2_NOSTAGE", 1) != 0;
 		for (auto &k : c->kept) nowb_plan = nowb_plan && k.owned;
 	}
-	const int lb_max = nowb_plan ? 8 : 7;                          /* log2 blocks a sub-bucket may own: k_lc2 stages at most 128; without a stage its table gives every block >= 4 home slots */
-	int s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
-	if (c->bloom_mode && s2 < c->nb - 9 - lb_max && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - lb_max;
-	s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
 	/* one sweep of the level-2 scatter takes up to 2^11 sub-buckets (2^13 in sweeps over the chunk); beyond that -- the share of an N-GPU job's rank:
 	 * 128 sub-tables of 69 M instances each -- the partition takes two sweeps (p3): the high bits first into {hash, rank} records, then 2^p3_low
 	 * sub-buckets inside every group.  2^18 sub-buckets per sub-table bound the per-sub-bucket arrays */
 	const int p3_min = (int)env_i64("YAKAMD_P3_MIN", 13), p3_low = (int)std::min<int64_t>(11, std::max<int64_t>(1, env_i64("YAKAMD_P3_LOW", 11)));
-	if (s2 > 18) s2 = 18;
-	if (s2 < 0) s2 = 0;
-	if (c->bloom_mode) {
-		if (s2 > c->nb - 9) s2 = c->nb - 9;                  /* a sub-bucket owns whole 512-bit blocks ... */
-		if (s2 < c->nb - 9 - 20) s2 = c->nb - 9 - 20;        /* ... and at most 2^20 of them (sort-key packing) */
+	int s2 = 0, s2a = 0, s2b = 0;
+	bool three = false;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		const int lb_max = nowb_plan ? 8 : 7;                      /* log2 blocks a sub-bucket may own: k_lc2 stages at most 128; without a stage its table gives every block >= 4 home slots */
+		s2 = n_total ? ceil_log2_u64((n_total / (u64)(c->phi - c->plo) + per_sb - 1) / per_sb) : 0;
+		if (c->bloom_mode && s2 < c->nb - 9 - lb_max && n_total / (u64)(c->phi - c->plo) > 600) s2 = c->nb - 9 - lb_max;
+		s2 = (int)env_i64("YAKAMD_S2_BITS", s2);
+		if (s2 > 18) s2 = 18;
+		if (s2 < 0) s2 = 0;
+		if (c->bloom_mode) {
+			if (s2 > c->nb - 9) s2 = c->nb - 9;              /* a sub-bucket owns whole 512-bit blocks ... */
+			if (s2 < c->nb - 9 - 20) s2 = c->nb - 9 - 20;    /* ... and at most 2^20 of them (sort-key packing) */
+		}
+		three = s2 > p3_min;
+		if (!three && s2 > 13) s2 = 13;
+		s2a = three ? std::min(11, std::max(std::min(4, s2 - 1), s2 - p3_low)) : 0; s2b = s2 - s2a;   /* the first sweep keeps >= 16 groups: the write-combining scatter wants >= 4 bits */
+		/* the plan without a filter stage falls when the pass cannot keep its level-2 records after all (16-byte records are not kept; ranges beyond 256 blocks
+		 * go to the tier behind k_lc2).  s2 was sized for 256 blocks per sub-bucket then: it is chosen again for the 128 a stage holds (the
+		 * first choice stayed, k_lc2 refused the 256-block ranges and the whole pass went through the global-scratch tier) */
+		if (nowb_plan && c->bloom_mode && (YK_R8_TAG_BITS + s2 >= 64 || np_max >= (1ull << (YK_R8_TAG_BITS + s2)) || env_i64("YAKAMD_REC8_OUT", 1) == 0 || c->nb - 9 - s2 > 8 || c->nb - 9 - s2 < 0)) { nowb_plan = false; continue; }
+		break;
 	}
-	const bool three = s2 > p3_min;
-	if (!three && s2 > 13) s2 = 13;
-	const int s2a = three ? std::min(11, std::max(std::min(4, s2 - 1), s2 - p3_low)) : 0, s2b = s2 - s2a;   /* the first sweep keeps >= 16 groups: the write-combining scatter wants >= 4 bits */
 	if (three && s2b > 13) return fail("level-2 partition: 2^%d sub-buckets per sub-table cannot be split into two sweeps", s2);
 	fp.s2_bits = s2; fp.s2_tot = s2;
 	fp.sw = c->bloom_mode ? c->nb - 9 : s2; fp.ssh = fp.sw - s2;
@@ -1827,7 +1840,6 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	fp.rec8_in = fmt_in; fp.tb = YK_R8_TAG_BITS + s2;
 	fp.rec8_out = 0;                                         /* set below, once the largest sub-table stream is known */
 	if (c->bloom_mode) {
-		if (nowb_plan && (YK_R8_TAG_BITS + s2 >= 64 || np_max >= (1ull << (YK_R8_TAG_BITS + s2)) || env_i64("YAKAMD_REC8_OUT", 1) == 0 || c->nb - 9 - s2 > 8 || c->nb - 9 - s2 < 0)) nowb_plan = false;   /* (16-byte level-2 records are not kept; ranges beyond 256 blocks go to the older tiers) */
 		const bool lc2_runs = env_i64("YAKAMD_LC2", 1) != 0 && c->n_hash <= 32;   /* (with the block range below: yk_lc2_ok) -- the tier behind k_lc2 works on the filter in memory and needs real zeros */
 		if (c->bf_virgin && lc2_runs && c->nb - 9 - s2 <= (nowb_plan ? 8 : 7)) fp.bf_virgin = 1;   /* LDS-staged ranges: skip the read, write every block of the shard (yakamd_set_shard refuses to move the shard afterwards) */
 		else if (bloom_materialise(c)) return -1;
@@ -1969,7 +1981,12 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	 * yak_ch_destroy_bf usually comes next (main.c:55); whatever reads the filter first rebuilds it (bloom_undefer).  nowb_plan said so before the
 	 * partition (sub-buckets of up to 256 blocks, no stage in LDS); with the stage (a plan that was off) the bits are kept in LDS and dropped */
 	fp.bf_nowb = keep2 && fp.bf_virgin && env_i64("YAKAMD_BF_DEFER", 1) != 0 && env_i64("YAKAMD_LC2", 1) != 0 && c->n_hash <= 32;
-	if (nowb_plan && !fp.bf_nowb) return fail("internal: the records of a pass planned without a filter stage are not kept");
+	if (nowb_plan && !fp.bf_nowb) {
+		/* the two predicates (nowb_plan before the partition, keep2 behind it) disagree: the sub-buckets own up to 256 filter blocks, which only the
+		 * kernel without a stage takes.  Not a reason to fail the pass: the filter gets its real zeros and the tier behind k_lc2 counts on it in memory */
+		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] a pass planned without a filter stage does not keep its records after all: filter materialised, sub-buckets to the global-scratch tier\n");
+		if (fp.bf_virgin) { if (c->d_bf) HIPCK(hipMemsetAsync(c->d_bf, 0, c->bf_words * 4, c->st)); fp.bf_virgin = 0; }   /* (c->bf_virgin is off already: bloom_materialise would do nothing) */
+	}
 	const bool lc2 = yk_lc2_ok(fp) != 0;
 	if (!lc2) fp.bf_nowb = 0;
 	{

@@ -205,7 +205,7 @@ void yk_r2_binit(const R2Tab *tabs, const R2Act *acts, int P, u32 bmax, u32 *OCC
 void yk_r2_dsmall(const R2Tab *tabs, const R2Act *acts, int P, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *USED, u32 *Fcur, u32 *Gcur, u32 *fail, hipStream_t st);
 int yk_r2_double(const R2Tab *tabs, const R2Act *acts, int P, int n_dbl, u64 *K0, u64 *K1, u32 *TAG, u32 *OCC, u32 *USED, const u32 *Fin, u32 *Fout, u32 *fail, hipStream_t st);
 void yk_r2_place(const R2Tab *tabs, const R2Act *acts, int P, int p0, int np, u32 bmax, u64 *K0, u64 *K1, const u64 *kc, u64 *pk, u32 *pr, u32 *seg_start,
-                 u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, u32 *img_u, const u32 *USED, hipStream_t st);
+                 u32 *head, u64 *spill, u32 *spill_n, u32 spill_cap, u32 *fail, u32 *img_u, const u32 *USED, u32 *pcnt, int G, hipStream_t st);
 void yk_r2_load(const R2Tab *tabs, const R2Load *ld, int P, u32 bmax, const u64 *src1, const u64 *src2, u64 *K0, u64 *K1, u32 *USED, hipStream_t st);
 void yk_r2_trail(const u64 *lastput, const u64 *rec_t, const u64 *rec_off, const u32 *m, int P, u32 *out, hipStream_t st);
 void yk_r2_publish(const R2Tab *tabs, const R2Pub *pub, int P, u32 bmax, const u64 *K0, const u64 *K1, u64 *nk, u32 *nu, hipStream_t st);
