@@ -23,8 +23,8 @@ yak_amd/yak_reader.o: $(CSRC)/yak_reader.cpp $(HOSTDEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 yak_amd/yak_multi.o: $(CSRC)/yak_multi.cpp $(HOSTDEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/engine.o yak_amd/yak_api.o yak_amd/yak_reader.o yak_amd/yak_multi.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-Bsymbolic -o $@ $^ -lz
+yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/engine.o yak_amd/yak_api.o yak_amd/yak_reader.o yak_amd/yak_multi.o $(CSRC)/libyak_amd.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-Bsymbolic -Wl,--version-script=$(CSRC)/libyak_amd.map -o $@ $(filter %.o,$^) -lz
 
 yak_amd/yak-amd: $(CSRC)/main.c include/yak.h yak_amd/libyak_amd.so
 	gcc -O2 -Wall -Iinclude $(CSRC)/main.c -o $@ -Lyak_amd -lyak_amd -Wl,-rpath,'$$ORIGIN' -lz

@@ -115,7 +115,7 @@ def _ref_count(fq, bits, threads, k=K):
     return dt, (int(m[-1]) if m else 0)
 
 
-def cpu_baseline(n_reads, genome, bf_shift, threads, t1_reads=500_000):
+def cpu_baseline(n_reads, genome, bf_shift, threads, t1_reads=500_000, err=None):
     """The reference itself (oracle/_ref/yak, compiled in the build container, carried as a prebuilt file) on
     the SAME reads as the device run (tools/yaksynth writes them as FASTQ: same seed, same order), all host
     cores; plus a -t1 figure on a stated fraction.  Without the prebuilt reference: the oracle port (1 core)
@@ -126,13 +126,15 @@ def cpu_baseline(n_reads, genome, bf_shift, threads, t1_reads=500_000):
         if pyoracle.have_ref():
             fq = os.path.join(tmp, "s.fq")
             subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-n", str(n_reads), "-l", str(READ_LEN),
-                                   "-g", str(genome), "-s", "42", "-t", str(min(threads, 32)), "-o", fq])
+                                   "-g", str(genome), "-s", "42", "-t", str(min(threads, 32)), "-o", fq] + (["-e", str(err)] if err is not None else []))
             dt, tot = _ref_count(fq, bf_shift, threads)
             inst = n_reads * (READ_LEN - K + 1) * (2 if bf_shift else 1)
             out = {"value": tot / dt, "unit": "distinct k-mers/s", "cores": threads, "kind": "reference",
                    "kmer_instances_per_s": inst / dt, "seconds": round(dt, 2),
                    "sample": f"yak count -k{K}" + (f" -b{bf_shift}" if bf_shift else "") + f" -t{threads} on the SAME {n_reads} x {READ_LEN} bp reads as the device run "
                              f"(tools/yaksynth -g {genome} -s 42 written as FASTQ, file in page cache), " + ("both passes" if bf_shift else "one pass")}
+            if t1_reads <= 0:
+                return out
             # one core: a fraction of the reads (same genome), the filter scaled with the instances
             f1 = os.path.join(tmp, "s1.fq")
             subprocess.check_call(["head", "-n", str(4 * t1_reads), fq], stdout=open(f1, "wb"))
@@ -214,11 +216,13 @@ def run_multi_c(a):
         raise SystemExit("no gfx950 device: refusing to run (no CPU fallback)")
     N = a.gpus
     devs = [r % n_dev for r in range(N)]                     # fewer devices than ranks: ranks share them (a one-GPU box posing as N)
-    sdev = []
+    own_slots = any(kv.partition("=")[0] == "YAKAMD_MGPU_SLOT_PER_RANK" and int(kv.partition("=")[2]) for kv in a.knob)
+    sdev = []                                                # a slot per distinct device -- or, under the library's test switch, per rank (ranks that share a device then exchange as if they did not)
     for d in devs:
-        if d not in sdev:
+        if own_slots or d not in sdev:
             sdev.append(d)
     S = len(sdev)
+    n_distinct = len(set(sdev))
     genome = 5 * per_gpu * N
     rec_len = READ_LEN + 1
     # the job's reads, dealt in rounds of one chunk per device (chunk c = round * S + device: the job's own read numbering, as yak_count() deals a file)
@@ -281,8 +285,9 @@ def run_multi_c(a):
         _, tot = step()
     sync_all(); barrier()
     dt = time.perf_counter() - t0
+    exch_timed = exch.value                                  # how the timed steps exchanged (the verification runs behind them are jobs of their own)
     # what a device needs at its peak: the library's buffers in use (tables, records, exchange) + the input chunks this harness keeps resident on it
-    in_bytes = {d: sum(bufs[i_].numel() for i_ in range(len(bufs)) if sdev[i_ % S] == d) for d in sdev}
+    in_bytes = {d: sum(bufs[i_].numel() for i_ in range(n_rounds * S) if sdev[i_ % S] == d) for d in sdev}
     peak = {d: int(L.yakamd_peak_bytes(d, 0)) + in_bytes[d] for d in sdev}
     hbm_total = {d: torch.cuda.mem_get_info(d)[1] for d in sdev}
     if any(peak[d] > 0.9 * hbm_total[d] for d in sdev):
@@ -328,9 +333,62 @@ def run_multi_c(a):
         verify = dict(verify or {}, job_yak_md5=md5_n, one_table_yak_md5=md5_1, equals_one_table=md5_n == md5_1)
         if md5_n != md5_1:
             raise SystemExit("FAILED: the sharded job's .yak differs from the single table's")
-    barrier()
     ms = dt / a.steps * 1e3
+    # ---- the same per-GPU workload on ONE device in this process: per_gpu reads (G = 5 x reads: 30x as the job), all 1024 sub-tables, the same
+    # driver with one rank -- the N = 1 point of THIS curve (the `--gpus 1` line of the driver's sweep is configs[1], a different job)
+    weak_base = None
+    if not a.no_weak_base:
+        del d_chunk
+        bufs.clear()                                         # the job's chunks go before the base's are made (a one-GPU box holds N ranks' input)
+        torch.cuda.empty_cache()
+        g1 = 5 * per_gpu
+        nr1 = -(-per_gpu // chunk_reads)
+        b1, p1, s1 = [], [], []
+        for b in range(nr1):
+            n_reads = min(chunk_reads, per_gpu - b * chunk_reads)
+            t = torch.empty(max(16, n_reads * rec_len), dtype=torch.uint8, device=f"cuda:{sdev[0]}")
+            syn.yaksynth_reads(h_buf.data_ptr(), n_reads, READ_LEN, g1, 42, err, 0.0005, b * chunk_reads, threads)
+            t[:n_reads * rec_len].copy_(h_buf[:n_reads * rec_len])
+            torch.cuda.synchronize(sdev[0])
+            b1.append(t); p1.append(t.data_ptr()); s1.append(n_reads * rec_len)
+        dc1, nb1, dv1 = (C.c_void_p * nr1)(*p1), (C.c_int64 * nr1)(*s1), (C.c_int * 1)(sdev[0])
+
+        def step1():
+            h = L.yakamd_count_multi_dev(C.byref(opt), None, 1, dv1, nr1, dc1, nb1, None)
+            if not h:
+                raise RuntimeError("yakamd_count_multi_dev (weak base): " + yak_amd._err())
+            if bf > 0:
+                L.yak_ch_destroy_bf(h); L.yak_ch_clear(h, 1)
+                if not L.yakamd_count_multi_dev(C.byref(opt), h, 1, dv1, nr1, dc1, nb1, None):
+                    raise RuntimeError("yakamd_count_multi_dev (weak base, count pass): " + yak_amd._err())
+                L.yak_ch_shrink(h, 2, 1023, 1)
+            torch.cuda.synchronize(sdev[0])
+            tot1 = h.contents.tot
+            L.yak_ch_destroy(h)
+            return tot1
+        step1()
+        tb = time.perf_counter()
+        for _ in range(a.steps):
+            tot1 = step1()
+        ms1 = (time.perf_counter() - tb) / a.steps * 1e3
+        weak_base = {"ms_per_step": ms1, "value": tot1 / (ms1 / 1e3), "unit": "distinct k-mers/s", "n_gpus": 1, "device": sdev[0], "steps": a.steps, "reads": per_gpu, "final_distinct": tot1,
+                     "kmer_instances_per_s": per_gpu * (READ_LEN - K + 1) * (2 if bf else 1) / (ms1 / 1e3),
+                     "workload": f"the per-GPU share of the job as a job of its own: {per_gpu} x {READ_LEN} bp reads (G={g1}, e={err * 100:g}%), all {P} sub-tables on device {sdev[0]}, "
+                                 "same driver (yakamd_count_multi_dev, one rank), timed in this process right behind the job",
+                     "base_ms_over_job_ms": ms1 / ms,
+                     "note": "weak scaling: with N devices the job does N x this work; base_ms_over_job_ms = 1 is linear" +
+                             (f" (here the {N} ranks share {n_distinct} device(s): the job does {N // n_distinct} x the base's work per device, so {n_distinct / N:.3g} is this box's ceiling)" if n_distinct < N else "")}
+        del b1
+    barrier()
+    cpu_base = None
+    if not a.no_cpu_baseline:
+        # the reference itself on a bounded sample of the per-GPU workload (same generator, same error rate, 30x), all host cores of this box
+        n_cpu = min(per_gpu, 4_000_000)
+        cpu_base = cpu_baseline(n_cpu, 5 * n_cpu, bf, min(os.cpu_count() or 8, 32), t1_reads=0, err=err)
+        cpu_base["sample_note"] = f"bounded sample: {n_cpu} of the {per_gpu} reads a GPU takes, genome scaled with it (G = 5 x reads) so that the coverage, and with it the share of repeated k-mers, is the job's"
     by = (32.0 if bf == 0 else 16.0 + 128.0 + 16.0 + 16.0 + 8.0 + 8.0) * (inst / (2 if bf else 1))
+    import bench_configs
+    traffic, traffic_src = bench_configs.pmc_step_traffic(f"multi_{N}x{per_gpu}" + (f"_b{bf}" if bf else ""))
     out = {"metric": "distinct k-mers counted/sec (k=31), prefix-sharded over the GPUs of one node, .yak bit-exact",
            "value": tot / (dt / a.steps), "unit": "distinct k-mers/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -342,17 +400,24 @@ def run_multi_c(a):
                                   "8-byte tagged records to the owner of their prefix",
                       "driver": "C: yakamd_count_multi_dev (libyak_amd.so), one process holding all devices; torch only allocates the input buffers",
                       "exchange": {0: "none (all ranks on one device: slices are fed where the partition left them)", 1: "RCCL grouped ncclSend/ncclRecv (one round per chunk set)",
-                                   2: "hipMemcpyPeerAsync peer copies (RCCL unavailable or switched off)"}.get(exch.value, "?"),
+                                   2: "hipMemcpyPeerAsync peer copies (RCCL unavailable, switched off, or a round it failed)",
+                                   3: "grouped ncclSend/ncclRecv call pattern served by the library's in-process test rig (slots on one device)"}.get(exch_timed, "?"),
                       "devices": devs, "rounds": n_rounds},
            "kmer_instances_per_s": inst / (dt / a.steps), "final_distinct": tot,
            "input_generation_s_not_timed": round(gen_s, 2), "first_job_ms": first_ms,
            "peak_hbm_bytes_per_device": {str(d): peak[d] for d in sdev}, "peak_hbm_note": "library buffers in use at their high-water mark (yakamd_peak_bytes: tables, records, exchange buffers; the pool's idle ranges are not in it) + the input chunks resident on the device; the job refuses to report above 0.9 of the device's memory",
            "roofline": {"bound": "hbm", "kernel": "whole job step (partition + exchange + per-rank count + exact layout), all GPUs", "achieved": by / (dt / a.steps) / 1e9,
-                        "peak": HBM_PEAK_GBS * S, "unit": "GB/s", "frac": by / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * S), "traffic": None,
+                        "peak": HBM_PEAK_GBS * n_distinct, "unit": "GB/s", "frac": by / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * n_distinct), "traffic": traffic,
+                        "traffic_per_device": (traffic / n_distinct) if traffic else None,
+                        "hbm_util": (traffic / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * n_distinct)) if traffic else None,
+                        "traffic_source": (traffic_src + "; the counter passes ran this command with all ranks on ONE device (the only box there is): the bytes of every rank's kernels, "
+                                           "summed; records that cross xGMI are not in them") if traffic else (traffic_src or "no counter pass of this command (N, reads per GPU) under profiles/"),
+                        "kernels_sha16": yak_amd.kernels_sha16(),
                         "algorithmic_bytes_per_instance": by / max(1, inst / (2 if bf else 1))},
-           "cpu_baseline": None, "cpu_baseline_note": "timed at N = 1 only (rank 0, bounded sample of the N = 1 workload): the `--gpus 1` line carries it",
-           "scaling_note": f"weak: {per_gpu} reads per GPU at every N > 1 (8 GPUs = BASELINE configs[2]); the `--gpus 1` line is configs[1] (10 M reads, filtered protocol), a different "
-                           "job -- ONE rank's share of the 8-GPU job on one GPU is `--config cfg3shard` (profiles/r05_bench_cfg3shard.json: 0.51 s, the exchange not in it)",
+           "weak_base": weak_base, "cpu_baseline": cpu_base,
+           "scaling_note": f"weak: {per_gpu} reads per GPU at every N > 1 (8 GPUs = BASELINE configs[2]); `weak_base` is the N = 1 point of this curve, measured in this process "
+                           "(the `--gpus 1` line of a sweep is configs[1], 10 M reads through the filtered protocol: a different job); ONE rank's share of the 8-GPU job on one GPU is "
+                           "`--config cfg3shard`",
            "verify": verify}
     print(json.dumps(out))
     if world > 1:
@@ -406,6 +471,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-weak-base", action="store_true", help="N > 1: skip the one-device run of the per-GPU workload (`weak_base`)")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="a test switch of the library (yakamd_test_set); tests force code paths with it")
     ap.add_argument("--force-exchange", action="store_true", help="run the sharded (all-to-all) data path even on 1 GPU")
     ap.add_argument("--exchange16", action="store_true", help="N > 1: exchange 16-byte {hash, position} records instead of 8-byte tagged ones")

@@ -165,7 +165,7 @@ void yakamd_debug_counters(uint32_t *out4);
  * device groups its chunk's k-mers by prefix, one RCCL grouped send / recv per round (or peer copies, or nothing on one device) moves them to their
  * owners, each rank counts its prefix range.  h0 == 0: returns a new table sharded over n_rank ranks (every yak_ch_* entry point takes it);
  * h0 != 0 (a table this call made): counts the chunks' k-mers that are in it (count.c:155-157) and returns h0.  NULL on failure.
- * *exchange_out (may be NULL): 0 nothing exchanged (one device), 1 RCCL, 2 peer copies */
+ * *exchange_out (may be NULL): 0 nothing exchanged (one device), 1 RCCL, 2 peer copies, 3 the library's in-process test rig (test switch YAKAMD_MGPU_LOOPBACK) */
 yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
                                  const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out);
 

@@ -49,7 +49,12 @@ def run(tmp, reads, genome, tag):
 
 
 def main():
-    tmp = next((a for a in sys.argv[1:] if not a.startswith("--")), "/tmp/cfg3")
+    """gen_golden_cfg3.py [tmpdir] [--ranges lo:hi,lo:hi]: two ranges per run fit the 62 GB of the build container (a rank's 128 tables of 8 Mi slots are
+    8.6 GB); the ranges of a run are merged into what tests/golden/cfg3_full.json already holds.  Round 6 added the six ranks that rounds 5 left out."""
+    global RANGES
+    tmp = next((a for a in sys.argv[1:] if not a.startswith("--") and ":" not in a), "/tmp/cfg3")
+    if "--ranges" in sys.argv:
+        RANGES = [tuple(int(x) for x in r.split(":")) for r in sys.argv[sys.argv.index("--ranges") + 1].split(",")]
     os.makedirs(tmp, exist_ok=True)
     # the procedure against `yko count -R` (the oracle's prefix-range mode, which reproduces the reference's md5 at 2 Gb: cfg45_full.json) on 1 M reads
     small = run(tmp, 1_000_000, 5_000_000, "small")
@@ -69,7 +74,15 @@ def main():
            "produced_by": "oracle/yko_synth (the oracle over the generated stream; checked against `yko count -R` at 1 M reads by this script)",
            "procedure_check_1M_reads": small,
            "ranges": run(tmp, READS, G, "cfg3")}
-    json.dump(res, open(os.path.join(ROOT, "tests", "golden", "cfg3_full.json"), "w"), indent=1)
+    out_fn = os.path.join(ROOT, "tests", "golden", "cfg3_full.json")
+    try:
+        old = json.load(open(out_fn))
+        if all(old.get(k_) == res[k_] for k_ in ("reads", "read_len", "genome", "seed", "err", "nrate", "k", "pre")):
+            for name, sec in (("ranges", old.get("ranges", {})), ("procedure_check_1M_reads", old.get("procedure_check_1M_reads", {}))):
+                merged = dict(sec); merged.update(res[name]); res[name] = dict(sorted(merged.items(), key=lambda kv: int(kv[0].split(":")[0])))
+    except (OSError, ValueError):
+        pass
+    json.dump(res, open(out_fn, "w"), indent=1)
     print(json.dumps(res["ranges"], indent=1))
 
 

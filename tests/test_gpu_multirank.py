@@ -19,7 +19,9 @@ def run_bench(args, nproc=1, port=29547):
     if nproc > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py")] + args
-    out = subprocess.run(cmd, check=True, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT).stdout.decode()
+    r = subprocess.run(cmd, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    out = r.stdout.decode()
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
@@ -56,3 +58,25 @@ def test_bench_n_gpus_runs_the_librarys_own_driver(n, bf, extra):
     assert r["n_gpus"] == n and r["verify"]["equals_one_table"] and r["final_distinct"] > 0
     assert r["config"]["driver"].startswith("C: yakamd_count_multi_dev") and r["config"]["exchange"].startswith("none")
     assert r["config"]["bf_shift"] == bf and r["config"]["reads_per_gpu"] == 150000
+
+
+@pytest.mark.parametrize("knobs,exchange", [(["YAKAMD_MGPU_LOOPBACK=1"], "grouped ncclSend/ncclRecv call pattern served"), (["YAKAMD_MGPU_LOOPBACK=1", "YAKAMD_MGPU_NO_OVERLAP=1"], "grouped"),
+                                            (["YAKAMD_MGPU_LOOPBACK=1", "YAKAMD_MGPU_LOOPBACK_FAIL=3"], "hipMemcpyPeerAsync"), (["YAKAMD_MGPU_NO_RCCL=1"], "hipMemcpyPeerAsync")],
+                         ids=["loopback_overlapped", "loopback_stage_by_stage", "a_failed_group_repeats_as_peer_copies", "peer_copies"])
+def test_bench_n_gpus_with_a_slot_per_rank_runs_the_exchange(knobs, exchange):
+    """the device-resident driver with every rank a slot of its own on device 0 (YAKAMD_MGPU_SLOT_PER_RANK): rounds of two chunks, the partition of round
+    b + 1 overlapped with the exchange and feed of round b, records crossing between the slots' send and receive buffers -- and the sharded table's bytes
+    still equal ONE table's (bench.py --job-md5 fails loudly otherwise).  The line carries weak_base, cpu_baseline and (null without a counter pass of
+    this very command) roofline.traffic with its source."""
+    args = ["--gpus", "2", "--reads", "150000", "--batch-reads", "40000", "--steps", "1", "--warmup", "0", "--job-md5", "--knob", "YAKAMD_MGPU_SLOT_PER_RANK=1"]
+    for kv in knobs:
+        args += ["--knob", kv]
+    r = run_bench(args, nproc=2, port=29611 + len(knobs) + len(exchange))
+    assert r["n_gpus"] == 2 and r["verify"]["equals_one_table"] and r["final_distinct"] > 0
+    assert r["config"]["exchange"].startswith(exchange), r["config"]["exchange"]
+    assert r["config"]["rounds"] == 4
+    wb = r["weak_base"]
+    assert wb["reads"] == 150000 and wb["ms_per_step"] > 0 and wb["final_distinct"] > 0 and wb["base_ms_over_job_ms"] > 0
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
+    assert "traffic" in r["roofline"] and r["roofline"]["traffic_source"]

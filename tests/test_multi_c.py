@@ -87,6 +87,30 @@ def test_a_sequence_longer_than_a_chunk_is_split_with_an_overlap(reads):
             assert open(got, "rb").read() == open(want, "rb").read(), (args, budget)
 
 
+RIG = {"loopback": ["YAKAMD_MGPU_LOOPBACK=1"], "loopback_round_2_fails": ["YAKAMD_MGPU_LOOPBACK=1", "YAKAMD_MGPU_LOOPBACK_FAIL=2"], "peer_copies": ["YAKAMD_MGPU_NO_RCCL=1"]}
+
+
+@pytest.mark.parametrize("rig", sorted(RIG))
+@pytest.mark.parametrize("n_gpu,args,inp", [(2, ["-k31", "-b24"], "fq"), (4, ["-k31"], "fq"), (2, ["-k21", "-b22", "-t1"], "fa"), (2, ["-k41", "-b24"], "fq")],
+                         ids=["2_reads_b24", "4_reads_nofilter", "2_contigs_stream_reader", "2_k41_rec16"])
+def test_slots_on_one_device_exchange_like_distinct_devices(rig, n_gpu, args, inp, reads):
+    """YAKAMD_MGPU_SLOT_PER_RANK (test switch): the N ranks on device 0 each get a slot of their own -- chunk, send and receive buffers, exchange and copy
+    streams, staging events per slot -- and every round EXCHANGES between the slots, the code a box with several GPUs runs (S > 1: receive layout, grouped
+    ncclSend / ncclRecv, the repeat of a failed round as peer copies, feeds out of the receive buffers).  `loopback`: the grouped calls are served by the
+    library's in-process rig, which fails a group whose receives do not find sends of the same count in posting order (what hangs the real library);
+    `loopback_round_2_fails`: the second group fails without moving a byte and the round, and all later ones, go as peer copies; `peer_copies`: no collective
+    library at all.  The .yak bytes are the oracle's."""
+    want, got = os.path.join(reads["dir"], "one6.yak"), os.path.join(reads["dir"], "multi6.yak")
+    subprocess.run([YKO, "count"] + args + ["-o", want, reads[inp]], check=True, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, YAKAMD_GPUS=str(n_gpu), YAKAMD_GPU_LIST=",".join(["0"] * n_gpu), YAKAMD_MGPU_CHUNK="150000")
+    x = [a for kv in ["YAKAMD_MGPU_SLOT_PER_RANK=1"] + RIG[rig] for a in ("-X", kv)]
+    r = subprocess.run([YAM] + x + ["count"] + args + ["-o", got, reads[inp]], check=True, env=env, stderr=subprocess.PIPE)
+    said = {"loopback": b"in-process test rig", "loopback_round_2_fails": b"peer copies from now on", "peer_copies": b"peer copies)"}[rig]
+    assert said in r.stderr, r.stderr[-1500:]
+    assert b"nothing exchanged" not in r.stderr
+    assert open(got, "rb").read() == open(want, "rb").read()
+
+
 def test_multi_gpu_on_distinct_devices(reads):
     """two REAL devices (the staging events of yak_count_multi belong to one device each; with ranks sharing device 0, as every
     other test here runs them, an event made on the wrong device goes unnoticed).  Skipped on a one-GPU box."""

@@ -1112,8 +1112,15 @@ static int64_t partition_dev(int k, int pre, const void *d_bases, int64_t n_byte
 	const int n_blk = yk_xpart_blocks(n_bytes);
 	u32 *d_rows = 0; u64 *d_partial = 0, *d_bstart = 0;
 	if (dmalloc(&d_rows, NB * (size_t)n_blk) || dmalloc(&d_partial, NB * yk_part_groups()) || dmalloc(&d_bstart, NB + 1)) return -1;
-	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_out, hash_only, 0);
-	const hipError_t e = hipMemcpy(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost);
+	/* on a stream of its own, not the null stream (which waits for, and holds up, every other stream of the device): a multi-GPU job partitions the
+	 * chunks of its next round while the owners' streams take in the round before */
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	hipStream_t ps = stream_get(dev);
+	yk_launch_xpart((const uint8_t*)d_bases, 0, n_bytes, 0, k, pre, 0, 1 << pre, pre, d_rows, d_partial, d_bstart, (Rec*)d_out, hash_only, ps);
+	hipError_t e = hipMemcpyAsync(h_bstart, d_bstart, (NB + 1) * 8, hipMemcpyDeviceToHost, ps);
+	if (e == hipSuccess) e = hipStreamSynchronize(ps);
+	stream_put(dev, ps);
 	dfree(d_rows); dfree(d_partial); dfree(d_bstart);
 	if (e != hipSuccess) { fail("partition: %s", hipGetErrorString(e)); return -1; }
 	return (int64_t)h_bstart[NB];

@@ -40,6 +40,71 @@ static bool rccl_open(RcclApi *R)
 	return R->CommInitAll && R->CommDestroy && R->GroupStart && R->GroupEnd && R->Send && R->Recv;
 }
 
+/* Test rig (YAKAMD_MGPU_LOOPBACK, a test switch): the same seven entry points served by copies on the devices of this process, so that the whole grouped
+ * send / recv call pattern of a round -- who sends what to whom, in which order, on which stream -- runs where no second GPU (or no xGMI) is: every
+ * ncclRecv of a group must find the ncclSend of its peer with the SAME count, in posting order per (sender, receiver) pair, exactly what the real
+ * library requires (a mismatch there is a hang; here it is ncclInvalidArgument).  The copy of a pair is ordered behind the sender's stream and ahead of
+ * both streams' later work through events, as a real transfer is.  YAKAMD_MGPU_LOOPBACK_FAIL = r (r >= 1) makes the r-th ncclGroupEnd of the process
+ * fail without moving anything: the branch that repeats a round as peer copies. */
+struct LoopComm { int rank, n, dev; };
+struct LoopOp { const void *src; void *dst; size_t cnt; int from, to, dev; hipStream_t st; };
+static std::mutex g_loop_mu;
+static std::vector<LoopOp> g_loop_send, g_loop_recv;
+static int g_loop_groups = 0;
+static ncclResult_t loop_init_all(ncclComm_t *c, int n, const int *dev) { for (int i = 0; i < n; ++i) { LoopComm *l = new LoopComm; l->rank = i; l->n = n; l->dev = dev[i]; c[i] = (ncclComm_t)l; } return ncclSuccess; }
+static ncclResult_t loop_destroy(ncclComm_t c) { delete (LoopComm*)c; return ncclSuccess; }
+static ncclResult_t loop_group_start(void) { std::lock_guard<std::mutex> lk(g_loop_mu); g_loop_send.clear(); g_loop_recv.clear(); return ncclSuccess; }
+static ncclResult_t loop_send(const void *p, size_t cnt, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st)
+{
+	LoopComm *l = (LoopComm*)c;
+	if (t != ncclUint64 || peer < 0 || peer >= l->n || peer == l->rank) return ncclInvalidArgument;
+	std::lock_guard<std::mutex> lk(g_loop_mu);
+	g_loop_send.push_back(LoopOp{ p, 0, cnt, l->rank, peer, l->dev, st });
+	return ncclSuccess;
+}
+static ncclResult_t loop_recv(void *p, size_t cnt, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st)
+{
+	LoopComm *l = (LoopComm*)c;
+	if (t != ncclUint64 || peer < 0 || peer >= l->n || peer == l->rank) return ncclInvalidArgument;
+	std::lock_guard<std::mutex> lk(g_loop_mu);
+	g_loop_recv.push_back(LoopOp{ 0, p, cnt, peer, l->rank, l->dev, st });
+	return ncclSuccess;
+}
+static ncclResult_t loop_group_end(void)
+{
+	std::lock_guard<std::mutex> lk(g_loop_mu);
+	++g_loop_groups;
+	if (yk_knob("YAKAMD_MGPU_LOOPBACK_FAIL", 0) == g_loop_groups) { g_loop_send.clear(); g_loop_recv.clear(); return ncclSystemError; }
+	if (g_loop_send.size() != g_loop_recv.size()) return ncclInvalidArgument;
+	std::vector<char> taken(g_loop_send.size(), 0);
+	ncclResult_t res = ncclSuccess;
+	for (const LoopOp &r : g_loop_recv) {
+		size_t i = 0;
+		while (i < g_loop_send.size() && (taken[i] || g_loop_send[i].from != r.from || g_loop_send[i].to != r.to)) ++i;    /* the pair's sends in posting order */
+		if (i == g_loop_send.size() || g_loop_send[i].cnt != r.cnt) { res = ncclInvalidArgument; break; }
+		const LoopOp &sn = g_loop_send[i];
+		taken[i] = 1;
+		hipEvent_t posted = 0, moved = 0;
+		if (hipSetDevice(sn.dev) != hipSuccess || hipEventCreateWithFlags(&posted, hipEventDisableTiming) != hipSuccess || hipEventRecord(posted, sn.st) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+		if (hipSetDevice(r.dev) != hipSuccess || hipStreamWaitEvent(r.st, posted, 0) != hipSuccess
+		    || hipMemcpyPeerAsync(r.dst, r.dev, sn.src, sn.dev, r.cnt * 8, r.st) != hipSuccess
+		    || hipEventCreateWithFlags(&moved, hipEventDisableTiming) != hipSuccess || hipEventRecord(moved, r.st) != hipSuccess
+		    || hipStreamWaitEvent(sn.st, moved, 0) != hipSuccess) res = ncclUnhandledCudaError;          /* the send buffer is the sender's again once its stream has passed this point */
+		if (posted) (void)hipEventDestroy(posted);                  /* (released by the runtime when the work that refers to them is done) */
+		if (moved) (void)hipEventDestroy(moved);
+		if (res != ncclSuccess) break;
+	}
+	g_loop_send.clear(); g_loop_recv.clear();
+	return res;
+}
+static const char *loop_error_string(ncclResult_t r) { return r == ncclSuccess ? "no error" : r == ncclInvalidArgument ? "loopback rig: a receive without the matching send" : "loopback rig: error"; }
+static void loop_open(RcclApi *R)
+{
+	memset(R, 0, sizeof(*R));
+	R->CommInitAll = loop_init_all; R->CommDestroy = loop_destroy; R->GroupStart = loop_group_start; R->GroupEnd = loop_group_end;
+	R->Send = loop_send; R->Recv = loop_recv; R->GetErrorString = loop_error_string;
+}
+
 /* The communicators of a device list are made once per process and kept: ncclCommInitAll over 8 GPUs takes of the order of a second and the
  * first grouped send / recv of a pair sets its channels up, while a counting job of this size takes less than a second -- a process that counts
  * again (the benchmark's steps, the second pass of the filtered protocol, a server) finds them here.  One job at a time holds them; a job that
@@ -61,7 +126,7 @@ struct MultiJob {
 	int N, P, S;                                               /* ranks, sub-tables, slots */
 	std::vector<int> dev, sdev, slot_of;                       /* device of rank r; device of slot s; slot of rank r */
 	std::vector<hipStream_t> st, cp;                           /* per slot: exchange stream; copy stream of the reader (non-blocking: the fill of the next set must not wait for the kernels of this one) */
-	bool use_rccl;
+	bool use_rccl, loopback;                                   /* loopback: the test rig above stands in for the collective library */
 	RcclApi R;
 	std::vector<ncclComm_t> comm;                              /* per slot */
 	bool comm_cached;                                          /* they are g_cc's: handed back, not destroyed */
@@ -125,9 +190,13 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, i
 {
 	J->N = N; J->P = P; J->dev = dev;
 	J->sdev.clear(); J->slot_of.assign(N, 0);
+	/* test switch: every rank a slot of its own although ranks share a device -- chunk, send and receive buffers, streams and staging events per slot, and
+	 * an exchange between slots (copies on the one device stand in for the wire): everything a box with several GPUs runs, on a box with one */
+	const bool own_slots = yk_knob("YAKAMD_MGPU_SLOT_PER_RANK", 0) != 0;
+	bool dup_dev = false;
 	for (int r = 0; r < N; ++r) {
 		int s = -1;
-		for (size_t q = 0; q < J->sdev.size(); ++q) if (J->sdev[q] == dev[r]) s = (int)q;
+		for (size_t q = 0; q < J->sdev.size(); ++q) if (J->sdev[q] == dev[r]) { if (own_slots) dup_dev = true; else s = (int)q; }
 		if (s < 0) { s = (int)J->sdev.size(); J->sdev.push_back(dev[r]); }
 		J->slot_of[r] = s;
 	}
@@ -144,11 +213,17 @@ static bool multi_open(MultiJob *J, int N, int P, const std::vector<int> &dev, i
 	int most = 0;
 	for (int s = 0; s < S; ++s) { int n_here = 0; for (int r = 0; r < N; ++r) n_here += J->slot_of[r] == s; most = std::max(most, n_here); }
 	J->recv_words = S > 1 ? (int64_t)((double)J->send_words * (S - 1) * most / N * 1.5) + 4096 * N : 0;
-	J->use_rccl = S > 1 && !yk_knob("YAKAMD_MGPU_NO_RCCL", 0);
+	const bool loopback = S > 1 && yk_knob("YAKAMD_MGPU_LOOPBACK", 0) != 0;   /* test switch: the collective calls served inside the process (above) */
+	J->loopback = loopback;
+	J->use_rccl = S > 1 && !yk_knob("YAKAMD_MGPU_NO_RCCL", 0) && (loopback || !dup_dev);   /* (the real library refuses a device twice in one list) */
 	if (S < N) fprintf(stderr, "[M::yak_count] %d ranks on %d device%s: ranks that share a device share its chunks and take turns (their slices are fed where they lie)%s\n",
 	                   N, S, S > 1 ? "s" : "", S == 1 ? "; nothing is exchanged" : "");
 	J->comm_cached = false;
-	if (J->use_rccl) {
+	if (J->use_rccl && loopback) {
+		J->comm.assign(S, 0);
+		loop_open(&J->R);
+		J->R.CommInitAll(J->comm.data(), S, J->sdev.data());
+	} else if (J->use_rccl) {
 		J->comm.assign(S, 0);
 		std::lock_guard<std::mutex> lk(g_cc.mu);
 		if (!g_cc.opened) { g_cc.have_lib = rccl_open(&g_cc.R); g_cc.opened = true; }
@@ -192,104 +267,145 @@ static void multi_close(MultiJob *J)
 	if (J->comm_cached) { std::lock_guard<std::mutex> lk(g_cc.mu); g_cc.busy = false; J->comm_cached = false; }
 }
 
-/* one round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Partition, exchange, feed. */
-static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0, std::string *why)
+/* One round on buffer set x: chunk s (fill[s] bytes, stream offset t0[s]) sits in slot s.  Three stages -- partition, exchange, feed -- that a caller
+ * may run one after the other (multi_round) or overlapped round against round (yakamd_count_multi_dev: the partition of round b + 1 runs while round b
+ * is on the wire and fed; the two buffer sets make that safe: set x is not touched again before the feed of the round that used it has returned). */
+struct RoundPlan {
+	bool tagged; int W;                                         /* 8-byte tagged records; words per record */
+	std::vector<int64_t> fill; std::vector<uint64_t> t0;
+	std::vector<std::vector<uint64_t> > bst;                    /* [slot][P + 1]: where the records of prefix p start in the slot's send buffer */
+	std::vector<std::vector<uint64_t> > roff;                   /* [rank][slot]: where owner d's slice of chunk s lies in its slot's receive buffer (records) */
+	std::string why; std::mutex why_mu;
+	void note() { std::lock_guard<std::mutex> lk(why_mu); if (why.empty()) why = yakamd_last_error(); }   /* called on the thread that failed (the text is per thread) */
+};
+
+/* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
+static bool round_tagged(MultiJob *J, yak_ch_ext *e, int k, int pre, int create_new)
 {
-	std::mutex why_mu;
-	auto note = [&]() { std::lock_guard<std::mutex> lk(why_mu); if (why && why->empty()) *why = yakamd_last_error(); };   /* called on the thread that failed */
-	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !yk_knob("YAKAMD_MGPU_REC16", 0);   /* 8-byte tagged records: half the exchange; every owner must still be on the exclusive-ownership path */
+	bool tagged = create_new && yakamd_tagged_ok(k, pre) && !yk_knob("YAKAMD_MGPU_REC16", 0);
 	for (int r = 0; r < J->N && tagged; ++r) tagged = e->sub[r] && yakamd_pass_fast(e->sub[r]);
-	const int N = J->N, P = J->P, S = J->S, W = create_new && !tagged ? 2 : 1;      /* words per record: {hash, position}, or one (tagged record / bare hash) */
-	for (int s = 0; s < S; ++s) if (fill[s] * W > J->send_words) { fprintf(stderr, "[E::yak_count] a chunk of %lld positions does not fit the send buffer (%lld words): 16-byte records were not planned for\n", (long long)fill[s], (long long)J->send_words); return false; }
-	std::vector<std::vector<uint64_t> > bst(S, std::vector<uint64_t>(P + 1, 0));
-	std::vector<int64_t> n_rec(S, 0);
-	std::vector<char> ok(std::max(N, S), 1);
-	{	/* every slot groups the k-mers of its chunk by prefix */
-		std::vector<std::thread> th;
-		for (int s = 0; s < S; ++s) th.emplace_back([&, s]() {
-			if (fill[s] <= 0) return;
-			hipSetDevice(J->sdev[s]);
-			n_rec[s] = tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
-			         : create_new ? yakamd_partition_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data())
-			                      : yakamd_partition_hashes_dev(k, pre, J->d_base[x][s], fill[s], J->d_send[x][s], bst[s].data());
-			if (n_rec[s] < 0) { ok[s] = 0; note(); }
-		});
-		for (auto &t : th) t.join();
-	}
+	return tagged;
+}
+
+/* every slot groups the k-mers of its chunk by prefix (its own stream: nothing here waits for, or holds up, the owners' streams) */
+static bool round_partition(MultiJob *J, int x, int k, int pre, int create_new, RoundPlan *R)
+{
+	const int P = J->P, S = J->S;
+	R->W = create_new && !R->tagged ? 2 : 1;                    /* {hash, position}, or one word (tagged record / bare hash) */
+	for (int s = 0; s < S; ++s) if (R->fill[s] * R->W > J->send_words) { fprintf(stderr, "[E::yak_count] a chunk of %lld positions does not fit the send buffer (%lld words): 16-byte records were not planned for\n", (long long)R->fill[s], (long long)J->send_words); return false; }
+	R->bst.assign(S, std::vector<uint64_t>(P + 1, 0));
+	std::vector<char> ok(S, 1);
+	std::vector<std::thread> th;
+	for (int s = 0; s < S; ++s) th.emplace_back([&, s]() {
+		if (R->fill[s] <= 0) return;
+		hipSetDevice(J->sdev[s]);
+		const int64_t n = R->tagged ? yakamd_partition_tagged_dev(k, pre, J->d_base[x][s], R->fill[s], J->d_send[x][s], R->bst[s].data())
+		                : create_new ? yakamd_partition_dev(k, pre, J->d_base[x][s], R->fill[s], J->d_send[x][s], R->bst[s].data())
+		                             : yakamd_partition_hashes_dev(k, pre, J->d_base[x][s], R->fill[s], J->d_send[x][s], R->bst[s].data());
+		if (n < 0) { ok[s] = 0; R->note(); }
+	});
+	for (auto &t : th) t.join();
 	for (int s = 0; s < S; ++s) if (!ok[s]) return false;
-	/* receive layout of a slot: for each rank it hosts (rank order), the slices of the other slots' chunks (slot order) */
-	std::vector<std::vector<uint64_t> > roff(N, std::vector<uint64_t>(S, 0));   /* roff[d][s]: where owner d's slice of chunk s lies in its slot's receive buffer (records) */
+	return true;
+}
+
+/* the slices of every chunk go to the slots of the ranks that own their prefixes.  Receive layout of a slot: for each rank it hosts (rank order), the
+ * slices of the other slots' chunks (slot order) */
+static bool round_exchange(MultiJob *J, int x, RoundPlan *R)
+{
+	const int N = J->N, P = J->P, S = J->S, W = R->W;
+	const std::vector<std::vector<uint64_t> > &bst = R->bst;
+	R->roff.assign(N, std::vector<uint64_t>(S, 0));
 	std::vector<uint64_t> used(S, 0);
 	for (int d = 0; d < N; ++d) {
 		const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
-		for (int s = 0; s < S; ++s) { if (s == sd) continue; roff[d][s] = used[sd]; used[sd] += bst[s][hi] - bst[s][lo]; }
+		for (int s = 0; s < S; ++s) { if (s == sd) continue; R->roff[d][s] = used[sd]; used[sd] += bst[s][hi] - bst[s][lo]; }
 	}
 	for (int s = 0; s < S; ++s) if ((int64_t)(used[s] * W) > J->recv_words) { fprintf(stderr, "[E::yak_count] device %d would receive %llu records in one round: prefixes too unevenly filled for YAKAMD_MGPU_CHUNK\n", J->sdev[s], (unsigned long long)used[s]); return false; }
-	if (S > 1) {
-		if (J->use_rccl) J->R.GroupStart();
+	if (S <= 1) return true;
+	bool ok = true;
+	auto peer_copies = [&]() {
 		for (int s = 0; s < S; ++s)
 			for (int d = 0; d < N; ++d) {
 				const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
 				const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
 				if (cnt == 0 || s == sd) continue;
-				const uint64_t *src = J->d_send[x][s] + bst[s][lo] * W;
-				uint64_t *dst = J->d_recv[x][sd] + roff[d][s] * W;
-				if (J->use_rccl) {                                      /* (the current device matches the communicator of every call, as the library's own examples do it) */
-					hipSetDevice(J->sdev[s]);
-					if (J->R.Send(src, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess) ok[0] = 0;
-					hipSetDevice(J->sdev[sd]);
-					if (J->R.Recv(dst, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok[0] = 0;
-				} else {
-					hipSetDevice(J->sdev[sd]);
-					if (hipMemcpyPeerAsync(dst, J->sdev[sd], src, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
-				}
+				hipSetDevice(J->sdev[sd]);
+				if (hipMemcpyPeerAsync(J->d_recv[x][sd] + R->roff[d][s] * W, J->sdev[sd], J->d_send[x][s] + bst[s][lo] * W, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok = false;
 			}
-		if (J->use_rccl && J->R.GroupEnd() != ncclSuccess) ok[0] = 0;
-		for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
-		if (!ok[0] && J->use_rccl) {
+	};
+	auto wait_streams = [&]() { for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok = false; } };
+	if (J->use_rccl) {
+		J->R.GroupStart();
+		for (int s = 0; s < S; ++s)
+			for (int d = 0; d < N; ++d) {
+				const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
+				const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
+				if (cnt == 0 || s == sd) continue;
+				/* (the current device matches the communicator of every call, as the library's own examples do it) */
+				hipSetDevice(J->sdev[s]);
+				if (J->R.Send(J->d_send[x][s] + bst[s][lo] * W, cnt, ncclUint64, sd, J->comm[s], J->st[s]) != ncclSuccess) ok = false;
+				hipSetDevice(J->sdev[sd]);
+				if (J->R.Recv(J->d_recv[x][sd] + R->roff[d][s] * W, cnt, ncclUint64, s, J->comm[sd], J->st[sd]) != ncclSuccess) ok = false;
+			}
+		if (J->R.GroupEnd() != ncclSuccess) ok = false;
+		wait_streams();
+		if (!ok) {
 			/* the collective library let the round down: the same slices as plain peer copies, from here on */
 			fprintf(stderr, "[W::yak_count] RCCL exchange failed (%s): peer copies from now on\n", hipGetErrorString(hipGetLastError()));
-			J->use_rccl = false; ok[0] = 1;
-			if (J->comm_cached) {                                       /* nobody is handed these again (left as they are: destroying a communicator with a failed operation in it may hang) */
-				std::lock_guard<std::mutex> lk(g_cc.mu);
-				g_cc.comm.clear(); g_cc.devs.clear(); g_cc.busy = false; J->comm_cached = false; J->comm.assign(S, 0);
-			}
-			for (int s = 0; s < S; ++s) for (int q = 0; q < S; ++q) if (q != s) { hipSetDevice(J->sdev[s]); (void)hipDeviceEnablePeerAccess(J->sdev[q], 0); }
+			J->use_rccl = false; ok = true;
+			/* nobody is handed these communicators again, and nobody destroys them (a communicator with a failed operation in it may hang in its destructor) */
+			if (J->comm_cached) { std::lock_guard<std::mutex> lk(g_cc.mu); g_cc.comm.clear(); g_cc.devs.clear(); g_cc.busy = false; J->comm_cached = false; }
+			J->comm.assign(S, 0);
+			for (int s = 0; s < S; ++s) for (int q = 0; q < S; ++q) if (J->sdev[q] != J->sdev[s]) { hipSetDevice(J->sdev[s]); (void)hipDeviceEnablePeerAccess(J->sdev[q], 0); }
 			(void)hipGetLastError();
-			for (int s = 0; s < S; ++s)
-				for (int d = 0; d < N; ++d) {
-					const int lo = d * (P / N), hi = (d + 1) * (P / N), sd = J->slot_of[d];
-					const uint64_t cnt = (bst[s][hi] - bst[s][lo]) * W;
-					if (cnt == 0 || s == sd) continue;
-					hipSetDevice(J->sdev[sd]);
-					if (hipMemcpyPeerAsync(J->d_recv[x][sd] + roff[d][s] * W, J->sdev[sd], J->d_send[x][s] + bst[s][lo] * W, J->sdev[s], cnt * 8, J->st[sd]) != hipSuccess) ok[0] = 0;
-				}
-			for (int s = 0; s < S; ++s) { hipSetDevice(J->sdev[s]); if (hipStreamSynchronize(J->st[s]) != hipSuccess) ok[0] = 0; }
+			peer_copies();
+			wait_streams();
 		}
-		if (!ok[0]) { fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n"); return false; }
+	} else {
+		peer_copies();
+		wait_streams();
 	}
-	{	/* every owner takes its slices, in chunk order = stream order; owners that share a device take turns (a feed may count a whole slice of the pass) */
-		std::vector<std::thread> th;
-		for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int d = 0; d < N; ++d) if (J->slot_of[d] == sd) {
-			hipSetDevice(J->dev[d]);
-			const int lo = d * (P / N), hi = (d + 1) * (P / N);
-			std::vector<uint64_t> ob(P + 1);
-			for (int s = 0; s < S; ++s) {
-				const uint64_t cnt = bst[s][hi] - bst[s][lo];
-				if (cnt == 0) continue;
-				for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[s][q] - bst[s][lo]; }
-				const uint64_t *rec = s == sd ? J->d_send[x][s] + bst[s][lo] * W : J->d_recv[x][sd] + roff[d][s] * W;   /* the slice of the device's own chunk is fed where the partition left it */
-				const int rc = tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s], 0)
-				             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), t0[s], (uint64_t)fill[s])
-				                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
-				if (rc != 0) { ok[d] = 0; note(); }
-			}
-			if (hipStreamSynchronize(yk_ctx_stream(((yak_ch_ext*)e->sub[d])->ctx)) != hipSuccess) ok[d] = 0;   /* the copies out of this set's buffers are done before the set is filled again */
-		} });
-		for (auto &t : th) t.join();
-	}
+	if (!ok) fprintf(stderr, "[E::yak_count] exchange between the GPUs failed\n");
+	return ok;
+}
+
+/* every owner takes its slices, in chunk order = stream order; owners that share a slot take turns (a feed may count a whole slice of the pass) */
+static bool round_feed(MultiJob *J, int x, yak_ch_ext *e, int create_new, RoundPlan *R)
+{
+	const int N = J->N, P = J->P, S = J->S, W = R->W;
+	const std::vector<std::vector<uint64_t> > &bst = R->bst;
+	std::vector<char> ok(N, 1);
+	std::vector<std::thread> th;
+	for (int sd = 0; sd < S; ++sd) th.emplace_back([&, sd]() { for (int d = 0; d < N; ++d) if (J->slot_of[d] == sd) {
+		hipSetDevice(J->dev[d]);
+		const int lo = d * (P / N), hi = (d + 1) * (P / N);
+		std::vector<uint64_t> ob(P + 1);
+		for (int s = 0; s < S; ++s) {
+			const uint64_t cnt = bst[s][hi] - bst[s][lo];
+			if (cnt == 0) continue;
+			for (int p = 0; p <= P; ++p) { const int q = p < lo ? lo : p > hi ? hi : p; ob[p] = bst[s][q] - bst[s][lo]; }
+			const uint64_t *rec = s == sd ? J->d_send[x][s] + bst[s][lo] * W : J->d_recv[x][sd] + R->roff[d][s] * W;   /* the slice of the slot's own chunk is fed where the partition left it */
+			const int rc = R->tagged ? yakamd_feed_partitioned_tagged_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), R->t0[s], (uint64_t)R->fill[s], 0)
+			             : create_new ? yakamd_feed_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data(), R->t0[s], (uint64_t)R->fill[s])
+			                          : yakamd_count_partitioned_dev(e->sub[d], rec, (int64_t)cnt, ob.data());
+			if (rc != 0) { ok[d] = 0; R->note(); }
+		}
+		if (hipStreamSynchronize(yk_ctx_stream(((yak_ch_ext*)e->sub[d])->ctx)) != hipSuccess) ok[d] = 0;   /* the copies out of this set's buffers are done before the set is filled again */
+	} });
+	for (auto &t : th) t.join();
 	for (int r = 0; r < N; ++r) if (!ok[r]) return false;
 	return true;
+}
+
+static bool multi_round(MultiJob *J, int x, yak_ch_ext *e, int k, int pre, int create_new, const std::vector<int64_t> &fill, const std::vector<uint64_t> &t0, std::string *why)
+{
+	RoundPlan R;
+	R.fill = fill; R.t0 = t0;
+	R.tagged = round_tagged(J, e, k, pre, create_new);
+	const bool ok = round_partition(J, x, k, pre, create_new, &R) && round_exchange(J, x, &R) && round_feed(J, x, e, create_new, &R);
+	if (!ok && why && why->empty()) *why = R.why;
+	return ok;
 }
 
 static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector<int> &dev);
@@ -433,7 +549,7 @@ yak_ch_t *yak_count_multi(const char *fn, const yak_copt_t *opt, yak_ch_t *h0, i
 		for (int s = 0; s < S; ++s) { hipSetDevice(J.sdev[s]); yk_pool_report("the job"); }
 	}
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %ld sequences in total; %ld distinct k-mers in the hash table (%d GPUs, %s)\n", "yak_count",
-	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? "RCCL exchange" : "peer copies");
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), (long)n_seq_tot, (long)h->tot, N, S == 1 ? "one device: nothing exchanged" : J.use_rccl ? (J.loopback ? "grouped send / recv served by the in-process test rig" : "RCCL exchange") : "peer copies");
 	if (psrc_fd >= 0) ::close(psrc_fd);
 	fx.close_file();
 	if (!ok) { fprintf(stderr, "[E::yak_count] %s\n", !worker_why.empty() ? worker_why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
@@ -466,7 +582,7 @@ static yak_ch_t *multi_table_new(const yak_copt_t *opt, int N, const std::vector
  * one chunk per DEVICE -- chunk s of round b lies at d_chunk[b * S + s] on the s-th distinct device of `dev` (n_bytes[b * S + s] bytes of the base
  * image, at most 2^31 - 4096; 0 = none), and the stream order is round by round, device by device, exactly as yak_count() deals a file.  h0 == 0:
  * a new table sharded over the n_rank ranks (dev[r] = device of rank r; several ranks may share a device) comes back; h0 != 0: its k-mers are counted
- * (count.c:155-157).  exchange_out (may be 0): 1 = RCCL grouped send / recv, 2 = peer copies, 0 = one device, nothing exchanged.  The caller keeps
+ * (count.c:155-157).  exchange_out (may be 0): 1 = RCCL grouped send / recv, 2 = peer copies, 3 = the grouped calls served by the in-process test rig, 0 = one device, nothing exchanged.  The caller keeps
  * the chunks alive until the call returns */
 extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0, int n_rank, const int *dev_of_rank, int n_rounds,
                                             const void *const *d_chunk, const int64_t *n_bytes, int *exchange_out)
@@ -476,13 +592,17 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 	std::vector<int> dev(dev_of_rank, dev_of_rank + N);
 	if (h0) {
 		yak_ch_ext *e0 = (yak_ch_ext*)h0;
-		if (e0->n_sub != N) { fprintf(stderr, "[E::yakamd_count_multi_dev] the table is sharded over %d ranks, not %d\n", e0->n_sub > 0 ? e0->n_sub : 1, N); return 0; }
+		if ((e0->n_sub > 1 ? e0->n_sub : 1) != N) { fprintf(stderr, "[E::yakamd_count_multi_dev] the table is sharded over %d ranks, not %d\n", e0->n_sub > 1 ? e0->n_sub : 1, N); return 0; }
 		assert(h0->k == opt->k && h0->pre == opt->pre);
 	}
 	const int create_new = h0 ? 0 : 1;
-	yak_ch_t *h = h0 ? h0 : multi_table_new(opt, N, dev);
+	yak_ch_t *h = h0;
+	if (!h && N == 1) { yk_ctx_next_device(dev[0]); h = yak_ch_init(opt->k, opt->pre, opt->bf_n_hash, opt->bf_shift); }   /* one rank: an ordinary table on that device (the same driver: rounds of chunks, partition, feed) */
+	else if (!h) h = multi_table_new(opt, N, dev);
 	if (!h) return 0;
-	yak_ch_ext *e = (yak_ch_ext*)h;
+	yak_ch_ext *e = (yak_ch_ext*)h, one_rank;
+	yak_ch_t *only[1] = { h };
+	if (N == 1) { memset(&one_rank, 0, sizeof(one_rank)); one_rank.n_sub = 1; one_rank.sub = only; e = &one_rank; }   /* the rounds address the owners as e->sub[rank] */
 	MultiJob J;
 	J.S = 0;
 	int64_t cmax = 4096;
@@ -499,17 +619,35 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 	for (int r = 0; r < N && ok; ++r) ok = yakamd_pass_begin(e->sub[r], create_new) == 0;
 	std::string why;
 	uint64_t t_stream = 0;
-	for (int b = 0; b < n_rounds && ok; ++b) {
-		std::vector<int64_t> fill(S, 0);
-		std::vector<uint64_t> t0(S, 0);
+	/* rounds overlapped: while round b is exchanged and fed (this thread), a second thread partitions round b + 1 into the other buffer set, on the
+	 * slots' partition streams.  Set (b + 1) & 1 was last used by round b - 1, whose feed has returned; whether round b + 1 uses tagged records is
+	 * settled before its partition starts, i.e. before the feed of round b can take an owner off the exclusive-ownership path -- such a pass fails at
+	 * the feed of round b + 1 with the engine's own message, it does not mix formats.  YAKAMD_MGPU_NO_OVERLAP (test switch): one stage after the other. */
+	const bool overlap = !yk_knob("YAKAMD_MGPU_NO_OVERLAP", 0);
+	RoundPlan R[2];
+	auto prepare = [&](int b) {
+		RoundPlan &r = R[b & 1];
+		r.fill.assign(S, 0); r.t0.assign(S, 0); r.why.clear();
 		for (int s = 0; s < S; ++s) {
-			fill[s] = n_bytes[(size_t)b * S + s];
-			t0[s] = t_stream; t_stream += (uint64_t)fill[s];
+			r.fill[s] = n_bytes[(size_t)b * S + s];
+			r.t0[s] = t_stream; t_stream += (uint64_t)r.fill[s];
 			J.d_base[b & 1][s] = (uint8_t*)d_chunk[(size_t)b * S + s];
 		}
-		ok = multi_round(&J, b & 1, e, opt->k, opt->pre, create_new, fill, t0, &why);
+		r.tagged = round_tagged(&J, e, opt->k, opt->pre, create_new);
+	};
+	std::thread part;
+	bool part_ok = true;
+	auto start_partition = [&](int b) { part = std::thread([&, b]() { part_ok = round_partition(&J, b & 1, opt->k, opt->pre, create_new, &R[b & 1]); }); };
+	if (ok && n_rounds > 0) { prepare(0); start_partition(0); }
+	for (int b = 0; b < n_rounds && ok; ++b) {
+		if (part.joinable()) part.join();
+		ok = part_ok;
+		if (ok && b + 1 < n_rounds) { prepare(b + 1); start_partition(b + 1); if (!overlap) { part.join(); ok = part_ok; } }
+		ok = ok && round_exchange(&J, b & 1, &R[b & 1]) && round_feed(&J, b & 1, e, create_new, &R[b & 1]);
+		if (!ok && why.empty()) why = !R[b & 1].why.empty() ? R[b & 1].why : R[(b + 1) & 1].why;
 	}
-	const int exch = S == 1 ? 0 : J.use_rccl ? 1 : 2;
+	if (part.joinable()) part.join();
+	const int exch = S == 1 ? 0 : J.use_rccl ? (J.loopback ? 3 : 1) : 2;
 	for (int x = 0; x < 2; ++x) for (int s = 0; s < S; ++s) J.d_base[x][s] = 0;
 	multi_close(&J);
 	{
@@ -521,10 +659,10 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 		for (int r = 0; r < N; ++r) if (n_ins[r] < 0) { fprintf(stderr, "[E::yakamd_count_multi_dev] rank %d of %d (device %d): %s\n", r, N, dev[r], whyr[r].c_str()); ok = false; }
 		for (int r = 0; r < N; ++r) if (n_ins[r] >= 0) e->sub[r]->tot += (uint64_t)n_ins[r];
 	}
-	multi_tot(h);
+	if (N > 1) multi_tot(h);
 	if (exchange_out) *exchange_out = exch;
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %d rounds of device-resident chunks; %ld distinct k-mers in the hash table (%d ranks, %s)\n", "yakamd_count_multi_dev",
-	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), n_rounds, (long)h->tot, N, exch == 0 ? "one device: nothing exchanged" : exch == 1 ? "RCCL exchange" : "peer copies");
+	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), n_rounds, (long)h->tot, N, exch == 0 ? "one device: nothing exchanged" : exch == 1 ? "RCCL exchange" : exch == 3 ? "grouped send / recv served by the in-process test rig" : "peer copies");
 	if (!ok) { fprintf(stderr, "[E::yakamd_count_multi_dev] %s\n", !why.empty() ? why.c_str() : yakamd_last_error()); if (!h0) yak_ch_destroy(h); return 0; }
 	return h;
 }
