@@ -296,8 +296,8 @@ def run_multi_c(a):
     verify = None
     gfn = os.path.join(ROOT, "tests", "golden", "cfg3_full.json")
     if bf == 0 and not a.no_verify and os.path.exists(gfn) and P % N == 0:
-        # BASELINE configs[2] itself (600 M reads, any N that divides the pinned ranges): the oracle counted the whole stream for sub-tables [0, 128) and
-        # [640, 768) (tests/gen_golden_cfg3.py); the job's bytes at those sub-tables must be the oracle's
+        # BASELINE configs[2] itself (600 M reads, any N that divides the pinned ranges): the oracle counted the whole stream for all eight ranges of 128
+        # sub-tables (tests/gen_golden_cfg3.py: the whole table, 41 GB of .yak bytes); the job's bytes at every one of them must be the oracle's
         g = json.load(open(gfn))
         if (per_gpu * N, genome, PRE, K) == (g["reads"], g["genome"], g["pre"], g["k"]):
             h, _ = step(keep=True)
@@ -461,7 +461,7 @@ def main():
                     help="BASELINE.json configuration: cfg2 = configs[1] (default, the metric's workload); nofilter = same reads, no bloom filter, one pass; "
                          "cfg4 = configs[3], yak count -k21 on a synthetic assembly (long contigs, singletons kept); cfg5 = configs[4], lookup-only path of yak qv")
     ap.add_argument("--of", type=int, default=8, help="cfg3shard: GPUs of the job whose rank 0 is measured on this one GPU (BASELINE configs[2]: 8)")
-    ap.add_argument("--rank", type=int, default=0, help="cfg3shard: which of the --of ranks (it owns sub-tables [rank * 1024 / of, (rank + 1) * 1024 / of); ranks 0 and 5 of the 600 M-read job are pinned on the oracle: tests/golden/cfg3_full.json)")
+    ap.add_argument("--rank", type=int, default=0, help="cfg3shard: which of the --of ranks (it owns sub-tables [rank * 1024 / of, (rank + 1) * 1024 / of); all eight ranks of the 600 M-read job are pinned on the oracle: tests/golden/cfg3_full.json)")
     ap.add_argument("--contigs", type=int, default=50, help="cfg4: number of contigs")
     ap.add_argument("--contig-len", type=int, default=100_000_000, help="cfg4: bases per contig")
     ap.add_argument("--sweeps", type=int, default=1, help="cfg4: > 1 = count through yak_count() in that many sweeps over prefix ranges (sizes beyond one pass: --contigs 50 --sweeps 8 = 5 Gb)")
@@ -491,7 +491,7 @@ def main():
     a.bf_shift_given = any(x == "--bf-shift" or x.startswith("--bf-shift=") for x in sys.argv[1:])
     maybe_spawn(a)
     if a.knob:                                                    # the library is loaded once per process: one place serves every mode below
-        if a.config in ("cfg3shard", "cfg4", "cfg5"):
+        if a.config in ("cfg3shard", "cfg4", "cfg5") or a.gpus > 1:
             import torch                                          # (these modes hold their inputs in torch tensors: torch finds no device if the library's HIP runtime is up first)
         import yak_amd
         for kv in a.knob:

@@ -432,7 +432,7 @@ def run_cfg3shard(a, torch, yak_amd):
               "sum_hist_equals_tot": sum(hist) == tot, "largest_subtable_slots": max(c_ for c_, _ in caps), "distinct": tot}
     if share is not None:
         verify["share_md5"], verify["share_bytes"] = share
-        # the oracle counted the whole 600 M-read stream for the sub-tables of ranks 0 and 5 (tests/gen_golden_cfg3.py -> tests/golden/cfg3_full.json;
+        # the oracle counted the whole 600 M-read stream for the sub-tables of every rank of eight (tests/gen_golden_cfg3.py -> tests/golden/cfg3_full.json;
         # its own check at 1 M reads is on record too): a rank's share must be those bytes
         gfn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cfg3_full.json")
         if bf == 0 and os.path.exists(gfn):

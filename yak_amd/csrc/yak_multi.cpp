@@ -637,16 +637,24 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 	};
 	std::thread part;
 	bool part_ok = true;
-	auto start_partition = [&](int b) { part = std::thread([&, b]() { part_ok = round_partition(&J, b & 1, opt->k, opt->pre, create_new, &R[b & 1]); }); };
+	double t_part = 0, t_wait = 0, t_exch = 0, t_feed = 0;        /* YAKAMD_VERBOSE: the partition thread's time; this thread's wait for it, exchange, feed */
+	auto start_partition = [&](int b) { part = std::thread([&, b]() { const double t0 = yk_realtime(); part_ok = round_partition(&J, b & 1, opt->k, opt->pre, create_new, &R[b & 1]); t_part += yk_realtime() - t0; }); };
+	const double t_rounds0 = yk_realtime();
 	if (ok && n_rounds > 0) { prepare(0); start_partition(0); }
 	for (int b = 0; b < n_rounds && ok; ++b) {
+		double t0 = yk_realtime();
 		if (part.joinable()) part.join();
 		ok = part_ok;
 		if (ok && b + 1 < n_rounds) { prepare(b + 1); start_partition(b + 1); if (!overlap) { part.join(); ok = part_ok; } }
-		ok = ok && round_exchange(&J, b & 1, &R[b & 1]) && round_feed(&J, b & 1, e, create_new, &R[b & 1]);
+		t_wait += yk_realtime() - t0; t0 = yk_realtime();
+		ok = ok && round_exchange(&J, b & 1, &R[b & 1]);
+		t_exch += yk_realtime() - t0; t0 = yk_realtime();
+		ok = ok && round_feed(&J, b & 1, e, create_new, &R[b & 1]);
+		t_feed += yk_realtime() - t0;
 		if (!ok && why.empty()) why = !R[b & 1].why.empty() ? R[b & 1].why : R[(b + 1) & 1].why;
 	}
 	if (part.joinable()) part.join();
+	const double t_rounds = yk_realtime() - t_rounds0;
 	const int exch = S == 1 ? 0 : J.use_rccl ? (J.loopback ? 3 : 1) : 2;
 	for (int x = 0; x < 2; ++x) for (int s = 0; s < S; ++s) J.d_base[x][s] = 0;
 	multi_close(&J);
@@ -660,6 +668,11 @@ extern "C" yak_ch_t *yakamd_count_multi_dev(const yak_copt_t *opt, yak_ch_t *h0,
 		for (int r = 0; r < N; ++r) if (n_ins[r] >= 0) e->sub[r]->tot += (uint64_t)n_ins[r];
 	}
 	if (N > 1) multi_tot(h);
+	if (yk_knob("YAKAMD_VERBOSE", 0) > 0) {
+		fprintf(stderr, "[yak_amd] %d rounds in %.3f s (%s): partitions %.3f s on their thread; this thread waited %.3f s for them, exchanged for %.3f s, fed for %.3f s; the ranks' passes finished by %.3f s\n",
+		        n_rounds, t_rounds, overlap ? "partition of round b + 1 under exchange and feed of round b" : "stage by stage", t_part, t_wait, t_exch, t_feed, yk_realtime() - t_rounds0);
+		for (int s = 0; s < S; ++s) if (s == 0 || J.sdev[s] != J.sdev[s - 1]) { hipSetDevice(J.sdev[s]); yk_pool_report("the job"); }
+	}
 	if (exchange_out) *exchange_out = exch;
 	fprintf(stderr, "[M::%s::%.3f*%.2f] %d rounds of device-resident chunks; %ld distinct k-mers in the hash table (%d ranks, %s)\n", "yakamd_count_multi_dev",
 	        yk_realtime(), yk_cputime() / (yk_realtime() + 1e-9), n_rounds, (long)h->tot, N, exch == 0 ? "one device: nothing exchanged" : exch == 1 ? "RCCL exchange" : exch == 3 ? "grouped send / recv served by the in-process test rig" : "peer copies");
