@@ -389,6 +389,12 @@ def run_multi_c(a):
     by = (32.0 if bf == 0 else 16.0 + 128.0 + 16.0 + 16.0 + 8.0 + 8.0) * (inst / (2 if bf else 1))
     import bench_configs
     traffic, traffic_src = bench_configs.pmc_step_traffic(f"multi_{N}x{per_gpu}" + (f"_b{bf}" if bf else ""))
+    if traffic is None and (N, per_gpu, bf) == (8, 75_000_000, 0):
+        # BASELINE configs[2] itself: no box holds eight ranks' jobs on one device, so the counter passes of ONE rank's share (--config cfg3shard: its own
+        # partition, every feed, its pass; the stand-ins for the peers' partitions scaled out) stand for each of the eight
+        t1, src1 = bench_configs.pmc_step_traffic("cfg3shard", scale={"k_xpart": 1.0 / 8, "k_part_": 1.0 / 8})
+        if t1:
+            traffic, traffic_src = 8 * t1, "8 x one rank's share, " + src1
     out = {"metric": "distinct k-mers counted/sec (k=31), prefix-sharded over the GPUs of one node, .yak bit-exact",
            "value": tot / (dt / a.steps), "unit": "distinct k-mers/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
