@@ -14,7 +14,11 @@ cli: yak_amd/yak-amd
 
 yak_amd/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/kern_*.inc) $(CSRC)/yk_device.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-yak_amd/engine.o: $(CSRC)/engine.cpp $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
+yak_amd/engine.o: $(CSRC)/engine.cpp $(CSRC)/engine_int.h $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+yak_amd/layout.o: $(CSRC)/layout.cpp $(CSRC)/engine_int.h $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+yak_amd/pool.o: $(CSRC)/pool.cpp $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 HOSTDEPS = $(CSRC)/yak_host.h $(CSRC)/pgz.h $(CSRC)/engine.h $(CSRC)/yk_device.h include/yak.h include/yak_amd.h
 yak_amd/yak_api.o: $(CSRC)/yak_api.cpp $(HOSTDEPS)
@@ -23,7 +27,7 @@ yak_amd/yak_reader.o: $(CSRC)/yak_reader.cpp $(HOSTDEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 yak_amd/yak_multi.o: $(CSRC)/yak_multi.cpp $(HOSTDEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/engine.o yak_amd/yak_api.o yak_amd/yak_reader.o yak_amd/yak_multi.o $(CSRC)/libyak_amd.map
+yak_amd/libyak_amd.so: yak_amd/kernels.o yak_amd/pool.o yak_amd/engine.o yak_amd/layout.o yak_amd/yak_api.o yak_amd/yak_reader.o yak_amd/yak_multi.o $(CSRC)/libyak_amd.map
 	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-Bsymbolic -Wl,--version-script=$(CSRC)/libyak_amd.map -o $@ $(filter %.o,$^) -lz
 
 yak_amd/yak-amd: $(CSRC)/main.c include/yak.h yak_amd/libyak_amd.so

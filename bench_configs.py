@@ -104,7 +104,10 @@ def run_cfg4_sweeps(a, yak_amd):
     try:
         subprocess.check_call([os.path.join(ROOT, "tools", "yaksynth"), "-T", "-n", str(a.contigs), "-l", str(a.contig_len), "-s", "42", "-w", "60", "-t", str(threads), "-o", fa])
         inst = a.contigs * (a.contig_len - K + 1)
-        os.environ["YAKAMD_GPUS"] = str(a.sweeps); os.environ["YAKAMD_GPU_LIST"] = ",".join(["0"] * a.sweeps)
+        own_rule = a.sweeps == 0                               # no --sweeps: yak_count() picks the number itself (yak_multi.cpp auto_sweeps), as it does for a user's `yak count`
+        if not own_rule:
+            os.environ["YAKAMD_GPUS"] = str(a.sweeps); os.environ["YAKAMD_GPU_LIST"] = ",".join(["0"] * a.sweeps)
+        sweeps_seen = []
         res = []
         g = _gold(f"cfg4_{a.contigs}x{a.contig_len}")
         # two chunkings of the stream (the result must not depend on it: the first one is the timed run), then -- where a golden exists for this
@@ -122,6 +125,7 @@ def run_cfg4_sweeps(a, yak_amd):
             hist = (C.c_int64 * 1024)()
             L.yak_ch_hist(h, hist, 1)
             tot = h.contents.tot
+            sweeps_seen.append(int(L.yakamd_last_sweeps()))
             FIRST.setdefault("ms", dt * 1e3)
             FIRST["peak"] = max(FIRST.get("peak", 0), int(L.yakamd_peak_bytes(0, 0)))
             if len(warm_s) < n_warm:
@@ -136,7 +140,9 @@ def run_cfg4_sweeps(a, yak_amd):
             res.append((dt, tot, list(hist), md5))
             L.yak_ch_destroy(h)
         for k_ in ("YAKAMD_GPUS", "YAKAMD_GPU_LIST", "YAKAMD_MGPU_CHUNK"):
-            del os.environ[k_]
+            os.environ.pop(k_, None)
+        if own_rule:
+            a.sweeps = sweeps_seen[n_warm]                     # of the timed job
     finally:
         subprocess.call(["rm", "-rf", tmp])
     dt, tot, hist, _ = res[0]
@@ -156,9 +162,9 @@ def run_cfg4_sweeps(a, yak_amd):
             "value": tot / dt, "unit": "distinct k-mers/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": dt * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"yak count -k{K} -t{threads} on a synthetic assembly FASTA: {a.contigs} contigs x {a.contig_len} bp (tools/yaksynth -T, seed 42), no filter, "
-                                   f"yak_count() in {a.sweeps} sweeps over prefix ranges on one device (YAKAMD_GPUS={a.sweeps}, YAKAMD_GPU_LIST=0,...)", "k": K, "pre": PRE, "bf_shift": 0},
+                                   f"yak_count() in {a.sweeps} sweeps over prefix ranges on one device " + ("(the library's own rule for a process that does not own the device memory of fewer sweeps yet: YAKAMD_COLD_GB)" if own_rule else f"(YAKAMD_GPUS={a.sweeps}, YAKAMD_GPU_LIST=0,...)"), "k": K, "pre": PRE, "bf_shift": 0, "sweeps_of_every_job": sweeps_seen},
             "kmer_instances_per_s": inst / dt, "final_distinct": tot, "seconds_second_chunking": res[1][0], "seconds_jobs_before_the_timed_one": [round(x, 3) for x in warm_s],
-            "first_job_ms": FIRST.get("ms"), "first_job_note": "the first yak_count() of the process: beyond the ~112 GB the driver hands out at once, device memory costs ~30 ms per GB the first time (tests/tools/mb/mb_malloc.hip, profiles/r05_mb_malloc.txt)",
+            "first_job_ms": FIRST.get("ms"), "first_job_note": "the first yak_count() of the process: beyond the ~112-160 GB the driver hands out at once, device memory costs ~30 ms per GB the first time (tests/tools/mb/mb_malloc.hip, mb_vmm5.hip; profiles/r05_mb_malloc.txt, r06_mb_vmm5.txt)",
             "peak_hbm_bytes": FIRST.get("peak"),
             "roofline": {"bound": "hbm", "kernel": "whole yak_count() call (parse + sweeps)", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": by / dt / 1e9 / HBM_PEAK_GBS, "traffic": roof_t["traffic"], "hbm_util": roof_t["hbm_util"],
@@ -168,10 +174,9 @@ def run_cfg4_sweeps(a, yak_amd):
 
 def run_cfg4(a, torch, yak_amd):
     if a.sweeps == 1 and a.contigs * a.contig_len > 2_500_000_000:
-        a.sweeps = 2                                           # beyond one pass's memory: the library's own rule (yak_api.cpp auto_sweeps: at most 2.8 GB of input per sweep) --
-        while a.sweeps < 16 and a.contigs * a.contig_len / a.sweeps > 2.8e9:
-            a.sweeps *= 2                                      # the default 50 x 100 Mb = BASELINE configs[3] runs in 2
-    if a.sweeps > 1:
+        a.sweeps = 0                                           # beyond one pass's memory: yak_count() on the FASTA, the library's own rule picks the sweeps (yak_multi.cpp auto_sweeps:
+                                                               # the default 50 x 100 Mb = BASELINE configs[3] runs in 8 in a process that does not own the memory yet, in 2 in one that does)
+    if a.sweeps != 1:
         return run_cfg4_sweeps(a, yak_amd)
     K = 21
     L = yak_amd.lib()

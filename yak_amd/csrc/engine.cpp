@@ -24,22 +24,10 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
-#include "yk_device.h"
-#include "engine.h"
+#include "engine_int.h"
 
 static thread_local char g_err[512] = "";
 
-static int fail(const char *fmt, ...)
-{
-	va_list ap;
-	va_start(ap, fmt);
-	vsnprintf(g_err, sizeof(g_err), fmt, ap);
-	va_end(ap);
-	fprintf(stderr, "[E::yak_amd] %s\n", g_err);
-	return -1;
-}
-
-#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
 extern "C" const char *yakamd_last_error(void) { return g_err; }
 int yk_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); fprintf(stderr, "[E::yak_amd] %s\n", g_err); return -1; }
@@ -56,450 +44,9 @@ extern "C" int yakamd_device_count(void)
 	return ok;
 }
 
-static double now_ms()
-{
-	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-/* Run-time settings.  The environment reaches the few a user has a reason to touch; every other name is a test
- * switch -- it forces a code path that sizes or shapes of input would otherwise select -- and only yakamd_test_set() (tests/conftest.py's
- * `knobs`, `yak-amd -X name=value`, `bench.py --knob name=value`) reaches those.  A value set through the hook wins over the environment. */
-static std::mutex g_knob_mu;
-static std::map<std::string, int64_t> g_knob;
-static bool knob_is_public(const char *name)
-{
-	static const char *const pub[] = { "YAKAMD_VERBOSE", "YAKAMD_DEVICE", "YAKAMD_GPUS", "YAKAMD_GPU_LIST", "YAKAMD_AUTO_SWEEP_GB", "YAKAMD_MGPU_CHUNK", "YAKAMD_MGPU_NO_RCCL",
-	                                   "YAKAMD_BATCH", "YAKAMD_FAST_BUDGET", "YAKAMD_NO_RETAIN", "YAKAMD_RETAIN_GB", "YAKAMD_PARSE_THREADS", "YAKAMD_PARSE_WINDOW",
-	                                   "YAKAMD_NO_LIBDEFLATE", "YAKAMD_NO_PGZ", "YAKAMD_NO_HOST_PACK" };
-	for (const char *q : pub) if (strcmp(q, name) == 0) return true;
-	return false;
-}
-int64_t yk_knob(const char *name, int64_t dflt)
-{
-	{
-		std::lock_guard<std::mutex> lk(g_knob_mu);
-		if (!g_knob.empty()) { auto it = g_knob.find(name); if (it != g_knob.end()) return it->second; }
-	}
-	if (!knob_is_public(name)) return dflt;
-	const char *s = getenv(name);
-	return s && *s ? atoll(s) : dflt;
-}
-extern "C" void yakamd_test_set(const char *name, int64_t value) { std::lock_guard<std::mutex> lk(g_knob_mu); g_knob[name] = value; }
-extern "C" void yakamd_test_reset(void) { std::lock_guard<std::mutex> lk(g_knob_mu); g_knob.clear(); }
-static inline int64_t env_i64(const char *name, int64_t dflt) { return yk_knob(name, dflt); }
-
-static inline int ceil_log2_u64(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
-
-/* khashl resize target (reference khashl.h:155-158): bits for a requested slot count */
-static inline u32 kh_bits_for(u32 want)
-{
-	u32 lg = 0, x = want;
-	while ((x >>= 1) != 0) ++lg;
-	if (want & (want - 1)) ++lg;
-	return lg > 2 ? lg : 2;
-}
-
-/* Device memory pool.  A counting job allocates and frees tens of GB per pass (bloom filters, partition buffers, table arenas); on ROCm a
- * hipMalloc costs ~27 ms per GB (measured: 97 GB in 2.7 s) and a hipFree of that size about as much, so freed memory is kept and handed out
- * again.  The driver's allocations are the pool's SUPERBLOCKS; a freed range joins the free ranges next to it inside its superblock, and a
- * request is carved from the best-fitting free range: the 97 GB a slice's first partition sweep used serve, once freed, the two 48 GB arrays of
- * the counting stage, and the next, shorter slice finds its buffers inside the longer one's.  Small requests (< 64 MB) only take ranges of about
- * their own size, so that they never pin a large superblock.  Beyond the cap (three quarters of the HBM idle) the superblocks that are
- * entirely free go back to the driver, least recently used first.  YAKAMD_POOL=0 disables it; a failed allocation drops every free
- * superblock and retries. */
-#include <map>
-#include <mutex>
-#include <unordered_map>
-struct DevPool {
-	std::mutex mu;
-	struct Super { size_t size; u64 stamp; };
-	std::map<char*, Super> supers;                     /* by base address */
-	std::map<char*, size_t> free_at;                   /* free ranges by start address (never spanning two superblocks) */
-	std::multimap<size_t, char*> free_sz;              /* the same ranges by length */
-	std::unordered_map<void*, size_t> live;            /* ranges handed out */
-	size_t cached = 0;                                 /* bytes in free ranges */
-	size_t in_use = 0, peak_in_use = 0;                /* bytes handed out, and their high-water mark (yakamd_peak_bytes) */
-	u64 clock = 0;
-	/* what the driver was asked for (YAKAMD_VERBOSE prints it: a job whose buffers do not come out of the pool pays ~27 ms per GB) */
-	u64 n_malloc = 0, n_release = 0, n_trim = 0; double gb_malloc = 0, ms_malloc = 0, ms_release = 0;
-	/* the tier of large buffers (>= VM_MIN): physical chunks of VM_CH bytes behind virtual ranges, see vm_alloc */
-	struct VmRange { size_t size; std::vector<hipMemGenericAllocationHandle_t> h; u64 stamp; };
-	std::map<char*, VmRange> vm_live, vm_idle;         /* ranges handed out / mapped and idle, by address */
-	std::multimap<size_t, char*> vm_idle_sz;           /* the idle ranges by length */
-	std::vector<hipMemGenericAllocationHandle_t> vm_spare;   /* chunks mapped nowhere */
-	size_t vm_cached = 0, vm_phys = 0, vm_dead_va = 0; /* bytes idle (ranges + spare chunks); bytes of chunks obtained from the driver and not given back; bytes of address space left behind by unmapped ranges */
-	bool vm_off = false;                               /* a virtual-memory call failed: large buffers come from superblocks like the small ones */
-	u64 n_vm_new = 0, n_vm_reuse = 0, n_vm_remap = 0, n_vm_create = 0; double ms_vm_map = 0, ms_vm_create = 0;
-};
-static DevPool g_pool[16];
-static DevPool &pool_here() { int d = 0; (void)hipGetDevice(&d); return g_pool[d & 15]; }
-static const size_t POOL_SPLIT_MIN = (size_t)64 << 20;
-
-static std::map<char*, DevPool::Super>::iterator pool_super_of(DevPool &P, char *p)
-{
-	auto it = P.supers.upper_bound(p);
-	return it == P.supers.begin() ? P.supers.end() : std::prev(it);
-}
-static void pool_range_drop(DevPool &P, std::map<char*, size_t>::iterator it)
-{
-	auto r = P.free_sz.equal_range(it->second);
-	for (auto q = r.first; q != r.second; ++q) if (q->second == it->first) { P.free_sz.erase(q); break; }
-	P.cached -= it->second;
-	P.free_at.erase(it);
-}
-static void pool_range_add(DevPool &P, char *p, size_t n)
-{
-	/* join the neighbours inside the same superblock */
-	auto su = pool_super_of(P, p);
-	char *lo = su->first, *hi = su->first + su->second.size;
-	auto nx = P.free_at.lower_bound(p);
-	if (nx != P.free_at.end() && nx->first == p + n && nx->first < hi) { n += nx->second; pool_range_drop(P, nx); }
-	auto pv = P.free_at.lower_bound(p);
-	if (pv != P.free_at.begin()) { --pv; if (pv->first + pv->second == p && pv->first >= lo) { p = pv->first; n += pv->second; pool_range_drop(P, pv); } }
-	P.free_at[p] = n; P.free_sz.insert({ n, p }); P.cached += n;
-	su->second.stamp = ++P.clock;
-}
-/* give the entirely free superblocks back to the driver, least recently used first, until at most `keep` bytes stay idle */
-static void pool_release(DevPool &P, size_t keep)
-{
-	while (P.cached > keep) {
-		std::map<char*, DevPool::Super>::iterator best = P.supers.end();
-		for (auto it = P.supers.begin(); it != P.supers.end(); ++it) {
-			auto f = P.free_at.find(it->first);
-			if (f == P.free_at.end() || f->second != it->second.size) continue;
-			if (best == P.supers.end() || it->second.stamp < best->second.stamp) best = it;
-		}
-		if (best == P.supers.end()) break;
-		pool_range_drop(P, P.free_at.find(best->first));
-		{ const double t0 = now_ms(); (void)hipFree(best->first); P.ms_release += now_ms() - t0; ++P.n_release; }
-		P.supers.erase(best);
-	}
-}
-static void pool_trim(DevPool &P) { ++P.n_trim; pool_release(P, 0); }
-
-/* Large buffers: fungible memory.  A superblock that is free but of the wrong size is useless to the next request -- the 5 Gb assembly obtained 329 GB
- * from the driver for 188 GB in use (buffers of 22-90 GB that do not fit the ranges earlier ones left; one out-of-memory trim on the way gave 115 GB
- * back that were then obtained again), and the driver charges ~30 ms per GB beyond the first ~112 GB of a process (tests/tools/mb/mb_malloc.hip).  So a
- * request of VM_MIN bytes or more gets a virtual range of its own, backed by physical chunks of VM_CH bytes (hipMemCreate / hipMemMap).  A freed range
- * stays mapped (the next request of that size takes it as it is: the steady state of a benchmark's steps costs nothing); a request that finds no idle
- * range of its size takes the chunks of idle ranges, least recently used first, and maps them into a fresh range -- 0.1 ms per GB
- * (tests/tools/mb/mb_vmm.hip: map 5 us per chunk, access 0.02 ms per GB, unmap 0.06 ms per GB; fills and random probes run as on hipMalloc memory) -- and
- * only what is still missing is created.  The driver is asked for the high-water mark of the buffers in use, rounded to chunks, and never for the
- * same memory twice.  YAKAMD_POOL_VM=0 (test switch), or any failing virtual-memory call, sends large buffers to the superblocks instead. */
-static const size_t VM_CH = (size_t)256 << 20, VM_MIN = (size_t)1 << 30;
-static void vm_idle_drop(DevPool &P, std::map<char*, DevPool::VmRange>::iterator it)
-{
-	auto r = P.vm_idle_sz.equal_range(it->second.size);
-	for (auto q = r.first; q != r.second; ++q) if (q->second == it->first) { P.vm_idle_sz.erase(q); break; }
-	P.vm_idle.erase(it);
-}
-/* an idle range gives its chunks up.  A buffer may be freed while the last kernel that uses it is still queued (the next user comes behind it on the
- * stream, as with any stream-ordered allocator); memory that is about to leave its addresses must not have such work pending: `synced` makes the first
- * unmap of a call wait for the device -- requests that find their range idle never get here */
-static void vm_unmap_idle(DevPool &P, std::map<char*, DevPool::VmRange>::iterator it, bool *synced)
-{
-	if (!*synced) { (void)hipDeviceSynchronize(); *synced = true; }
-	(void)hipMemUnmap(it->first, it->second.size);
-	/* The addresses are NOT given back (hipMemAddressFree): with this runtime (ROCm 7.2.0) kernels that touch a range whose addresses had been reserved, mapped,
-	 * unmapped and freed before fault or hang -- a 1 Gb assembly counted twice in one process died in k_r2_place of the second job, on ranges that were alive
-	 * and whose contents did not matter (every buffer pre-filled: same fault), while the same job with the addresses kept runs and writes the reference's
-	 * bytes (profiles/r06_experiments.txt e7).  Address space is plentiful (47 bits); only requests that find no idle range of their size consume any */
-	P.vm_dead_va += it->second.size;
-	for (auto h : it->second.h) P.vm_spare.push_back(h);
-	vm_idle_drop(P, it);
-}
-static std::map<char*, DevPool::VmRange>::iterator vm_lru(DevPool &P)
-{
-	auto best = P.vm_idle.end();
-	for (auto it = P.vm_idle.begin(); it != P.vm_idle.end(); ++it) if (best == P.vm_idle.end() || it->second.stamp < best->second.stamp) best = it;
-	return best;
-}
-/* idle memory of the tier back to the driver until at most `keep` bytes of it stay: spare chunks first, then idle ranges, least recently used first */
-static void vm_release(DevPool &P, size_t keep)
-{
-	const double t0 = now_ms();
-	bool synced = false;
-	while (P.vm_cached > keep) {
-		if (P.vm_spare.empty()) { auto it = vm_lru(P); if (it == P.vm_idle.end()) break; vm_unmap_idle(P, it, &synced); }
-		(void)hipMemRelease(P.vm_spare.back()); P.vm_spare.pop_back();
-		P.vm_cached -= VM_CH; P.vm_phys -= VM_CH; ++P.n_release;
-	}
-	P.ms_release += now_ms() - t0;
-}
-static void pool_trim(DevPool &P);
-static void *vm_alloc(DevPool &P, size_t bytes)
-{
-	const size_t need = (bytes + VM_CH - 1) / VM_CH * VM_CH, m = need / VM_CH;
-	auto fit = P.vm_idle_sz.lower_bound(need);
-	if (fit != P.vm_idle_sz.end() && fit->first <= need + std::max(need / 8, VM_CH)) {      /* an idle range of about this size, as it is */
-		char *p = fit->second;
-		auto it = P.vm_idle.find(p);
-		DevPool::VmRange r = std::move(it->second);
-		vm_idle_drop(P, it);
-		P.vm_cached -= r.size; P.in_use += r.size; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
-		r.stamp = ++P.clock;
-		P.vm_live[p] = std::move(r);
-		++P.n_vm_reuse;
-		return p;
-	}
-	const double t0 = now_ms();
-	bool remapped = false;
-	while (P.vm_spare.size() < m) { auto it = vm_lru(P); if (it == P.vm_idle.end()) break; vm_unmap_idle(P, it, &remapped); }
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	hipMemAllocationProp prop = {};
-	prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
-	bool trimmed = false;
-	const double tc0 = now_ms();
-	while (P.vm_spare.size() < m) {
-		hipMemGenericAllocationHandle_t h;
-		if (hipMemCreate(&h, VM_CH, &prop, 0) != hipSuccess) {
-			(void)hipGetLastError();
-			if (trimmed) return 0;                                  /* the device is full: the chunks gathered so far stay spare */
-			pool_trim(P); trimmed = true;                           /* the superblocks' idle memory goes back to the driver first */
-			continue;
-		}
-		P.vm_spare.push_back(h); P.vm_cached += VM_CH; P.vm_phys += VM_CH; ++P.n_vm_create;
-		P.gb_malloc += (double)VM_CH / 1e9;
-	}
-	P.ms_vm_create += now_ms() - tc0;
-	void *va = 0;
-	if (hipMemAddressReserve(&va, need, 0, 0, 0) != hipSuccess) { (void)hipGetLastError(); P.vm_off = true; return 0; }
-	DevPool::VmRange r;
-	r.size = need; r.stamp = ++P.clock;
-	size_t mapped = 0;
-	bool ok = true;
-	for (; mapped < m && ok; ++mapped) {
-		hipMemGenericAllocationHandle_t h = P.vm_spare.back();
-		ok = hipMemMap((char*)va + mapped * VM_CH, VM_CH, 0, h, 0) == hipSuccess;
-		if (ok) { P.vm_spare.pop_back(); r.h.push_back(h); } else --mapped;
-	}
-	if (ok) {
-		/* this device, and every peer that can reach it (a sharded table's image is read across devices by the set operations and the peer-copy exchange) */
-		std::vector<hipMemAccessDesc> acc;
-		int nd = 1;
-		(void)hipGetDeviceCount(&nd);
-		for (int d = 0; d < nd; ++d) {
-			int can = d == dev;
-			if (!can && hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess) { can = 0; (void)hipGetLastError(); }
-			if (!can) continue;
-			hipMemAccessDesc a = {};
-			a.location.type = hipMemLocationTypeDevice; a.location.id = d; a.flags = hipMemAccessFlagsProtReadWrite;
-			if (d == dev) acc.insert(acc.begin(), a); else acc.push_back(a);
-		}
-		ok = hipMemSetAccess(va, need, acc.data(), acc.size()) == hipSuccess;
-		if (!ok && acc.size() > 1) { (void)hipGetLastError(); ok = hipMemSetAccess(va, need, acc.data(), 1) == hipSuccess; }
-	}
-	if (!ok) {
-		(void)hipGetLastError();
-		if (!r.h.empty()) (void)hipMemUnmap(va, r.h.size() * VM_CH);
-		(void)hipMemAddressFree(va, need);
-		for (auto h : r.h) P.vm_spare.push_back(h);
-		P.vm_off = true;
-		fprintf(stderr, "[W::yak_amd] the virtual-memory tier of the device pool failed to map a range: large buffers come from hipMalloc from now on\n");
-		return 0;
-	}
-	P.vm_cached -= need; P.in_use += need; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
-	P.vm_live[(char*)va] = std::move(r);
-	P.ms_vm_map += now_ms() - t0;
-	if (remapped) ++P.n_vm_remap; else ++P.n_vm_new;
-	return va;
-}
-
-static void *pool_alloc_(size_t bytes, bool plain);
-/* test switch YAKAMD_POOL_FILL = v + 1: every buffer is filled with byte v before it is handed out (the null stream: behind everything queued) -- no result may
- * depend on what a buffer held when it was obtained, be it the driver's zeros or its last user's data */
-static void *pool_alloc(size_t bytes, bool plain = false)
-{
-	void *p = pool_alloc_(bytes, plain);
-	const int64_t f = yk_knob("YAKAMD_POOL_FILL", 0);
-	if (p && f > 0) { (void)hipMemset(p, (int)(f - 1) & 0xff, bytes); }
-	return p;
-}
-static void *pool_alloc_(size_t bytes, bool plain)
-{
-	static const bool on = true;
-	DevPool &P = pool_here();
-	const size_t gran = bytes >= (1u << 20) ? (2u << 20) : 256;
-	bytes = (bytes + gran - 1) / gran * gran;
-	std::lock_guard<std::mutex> lk(P.mu);
-	if (bytes >= (size_t)yk_knob("YAKAMD_POOL_VM_MIN", (int64_t)VM_MIN) && !plain && !P.vm_off && yk_knob("YAKAMD_POOL_VM", 1) != 0) {   /* (YAKAMD_POOL_VM_MIN: tests send small buffers through the tier) */
-		void *p = vm_alloc(P, bytes);
-		if (p) return p;
-	}
-	if (on) {
-		auto it = P.free_sz.lower_bound(bytes);
-		if (it != P.free_sz.end() && (it->first <= bytes + bytes / 4 || bytes >= POOL_SPLIT_MIN)) {
-			char *p = it->second;
-			const size_t have = it->first;
-			pool_range_drop(P, P.free_at.find(p));
-			size_t take = bytes;
-			if (have - take < (2u << 20) || bytes < POOL_SPLIT_MIN) take = have;      /* no crumbs; small requests never split */
-			if (have > take) { P.free_at[p + take] = have - take; P.free_sz.insert({ have - take, p + take }); P.cached += have - take; }
-			P.live[p] = take;
-			P.in_use += take; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
-			pool_super_of(P, p)->second.stamp = ++P.clock;
-			return p;
-		}
-	}
-	void *p = 0;
-	const double t0 = now_ms();
-	if (hipMalloc(&p, bytes) != hipSuccess) {
-		(void)hipGetLastError();
-		pool_trim(P);
-		vm_release(P, 0);
-		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
-	}
-	P.ms_malloc += now_ms() - t0; ++P.n_malloc; P.gb_malloc += (double)bytes / 1e9;
-	P.supers[(char*)p] = DevPool::Super{ bytes, ++P.clock };
-	P.live[p] = bytes;
-	P.in_use += bytes; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
-	return p;
-}
-
-static void pool_free(void *p)
-{
-	static const bool on = true;
-	/* idle bytes kept per device: three quarters of the HBM.  A step of the larger configurations
-	 * (1 Gb assembly, 30 M reads) turns over > 100 GB; a cap below the turnover makes every step pay the driver for its buffers again
-	 * (measured with 96 GB: 2.3 s instead of 0.27 s per cfg4 pass).  An allocation that fails drops the whole cache and retries */
-	static const size_t cap = []() -> size_t {
-		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)96 << 30; }
-		return tot / 4 * 3;
-	}();
-	/* the block's owner is the pool that handed it out, whatever device is current now */
-	DevPool *Pp = &pool_here();
-	{
-		bool mine;
-		{ std::lock_guard<std::mutex> lk(Pp->mu); mine = Pp->live.count(p) != 0 || Pp->vm_live.count((char*)p) != 0; }
-		for (int d = 0; d < 16 && !mine; ++d) { std::lock_guard<std::mutex> lk(g_pool[d].mu); if (g_pool[d].live.count(p) || g_pool[d].vm_live.count((char*)p)) { Pp = &g_pool[d]; mine = true; } }
-	}
-	DevPool &P = *Pp;
-	std::lock_guard<std::mutex> lk(P.mu);
-	{
-		auto vt = P.vm_live.find((char*)p);
-		if (vt != P.vm_live.end()) {                                  /* stays mapped: the next request of this size takes it as it is */
-			DevPool::VmRange r = std::move(vt->second);
-			P.vm_live.erase(vt);
-			P.in_use -= r.size; P.vm_cached += r.size;
-			r.stamp = ++P.clock;
-			P.vm_idle_sz.insert({ r.size, (char*)p });
-			P.vm_idle[(char*)p] = std::move(r);
-			if (P.cached + P.vm_cached > cap) { vm_release(P, cap > P.cached ? cap - P.cached : 0); }
-			return;
-		}
-	}
-	auto it = P.live.find(p);
-	if (it == P.live.end()) { (void)hipFree(p); return; }          /* not the pool's */
-	const size_t n = it->second;
-	P.live.erase(it);
-	P.in_use -= n;
-	pool_range_add(P, (char*)p, n);
-	pool_release(P, on ? (cap > P.vm_cached ? cap - P.vm_cached : 0) : 0);
-}
-
-size_t yk_pool_cached_bytes(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); return P.cached + P.vm_cached; }
-
-/* high-water mark of the device memory the library had IN USE on device `dev` (what a job needs; the idle ranges the pool keeps are not in it);
- * reset != 0 starts a new measurement from what is in use now */
-extern "C" int64_t yakamd_peak_bytes(int dev, int reset)
-{
-	DevPool &P = g_pool[dev & 15];
-	std::lock_guard<std::mutex> lk(P.mu);
-	const int64_t v = (int64_t)P.peak_in_use;
-	if (reset) P.peak_in_use = P.in_use;
-	return v;
-}
-extern "C" void yakamd_trim(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); pool_trim(P); vm_release(P, 0); }
-void yk_pool_report(const char *what)
-{
-	DevPool &P = pool_here();
-	std::lock_guard<std::mutex> lk(P.mu);
-	size_t live = 0, sup = 0;
-	for (auto &kv : P.live) live += kv.second;
-	for (auto &kv : P.supers) sup += kv.second.size;
-	fprintf(stderr, "[yak_amd] pool after %s: %llu hipMalloc (%.1f GB, %.0f ms), %llu hipFree (%.0f ms), %llu trims; %zu superblocks of %.1f GB hold %.1f GB in use and %.1f GB free in %zu ranges\n", what,
-	        (unsigned long long)P.n_malloc, P.gb_malloc, P.ms_malloc, (unsigned long long)P.n_release, P.ms_release, (unsigned long long)P.n_trim, P.supers.size(), (double)sup / 1e9, (double)live / 1e9, (double)P.cached / 1e9, P.free_at.size());
-	size_t vlive = 0, vidle = 0;
-	for (auto &kv : P.vm_live) vlive += kv.second.size;
-	for (auto &kv : P.vm_idle) vidle += kv.second.size;
-	fprintf(stderr, "[yak_amd] pool after %s, large buffers: %.1f GB of %zu MiB chunks obtained (%llu created in %.0f ms) hold %.1f GB in use in %zu ranges, %.1f GB idle in %zu mapped ranges and %zu spare chunks; %llu ranges new, %llu taken as they were, %llu built from other ranges' chunks (%.1f ms of mapping, %.1f GB of address space left behind); in use at the peak (both tiers) %.1f GB%s\n", what,
-	        (double)P.vm_phys / 1e9, VM_CH >> 20, (unsigned long long)P.n_vm_create, P.ms_vm_create, (double)vlive / 1e9, P.vm_live.size(), (double)vidle / 1e9, P.vm_idle.size(), P.vm_spare.size(),
-	        (unsigned long long)P.n_vm_new, (unsigned long long)P.n_vm_reuse, (unsigned long long)P.n_vm_remap, P.ms_vm_map, (double)P.vm_dead_va / 1e9, (double)P.peak_in_use / 1e9, P.vm_off ? " (tier switched off after a failed call)" : "");
-}
-
-template <class T> static int dmalloc(T **p, size_t n)
-{
-	if (n == 0) n = 1;
-	*p = (T*)pool_alloc(n * sizeof(T));
-	if (!*p) return fail("device allocation of %zu bytes failed", n * sizeof(T));
-	return 0;
-}
-template <class T> static void dfree(T *&p) { if (p) { pool_free((void*)p); p = 0; } }
 
 /* ------------------------------------------------------------------------------------------ */
 
-struct yakamd_ctx {
-	int k, pre, P, n_hash, bf_shift, nb;
-	bool has_bloom;
-	int dev, plo, phi;
-	hipStream_t st;
-
-	/* table image */
-	u32 *d_bits, *d_used, *d_delta;
-	u64 *d_off, *d_keys;
-	u64 n_slots;                       /* arena size (multiple of 32) */
-	std::vector<u32> h_bits, h_count;
-	std::vector<u64> h_off;
-	u64 img_keys_total;                /* sum of counts */
-
-	/* bloom */
-	u32 *d_bf; size_t bf_words;
-	bool bf_virgin;                    /* allocated but never written: logically all zero */
-	bool bf_deferred;                  /* the last pass left its bits in LDS only (FastParams.bf_nowb): the filter is whatever k_bf_rebuild makes of the retained records (ret2) */
-	u32 *d_multi; int multi_bits;
-
-	/* running pass */
-	bool delta_dirty;                  /* the running pass left pending counts in d_delta (k_img_fold at its end) */
-	bool in_pass; int create_new; bool bloom_mode; bool gate_off; int or_mode;   /* gate_off: puts of a merge never consult the filter */
-	AccTab acc; u64 acc_count;
-	u64 *d_counters, *d_lastput, *d_lpbatch;
-	u32 *d_missing, *d_nmissing;
-	Rec *d_rec; int64_t rec_cap;
-	u64 *d_newlist, *d_miss, *d_cand; int64_t new_cap;
-	uint8_t *d_stage; int64_t stage_cap;
-	u32 *d_rows; u64 *d_partial, *d_bstart; int rows_blk; int nb_bits;
-	/* fast path: level-1 partitioned batches kept until pass_end */
-	struct Kept { Rec *d_rec; u64 n; u64 t0, span; std::vector<u64> bstart; bool owned; int fmt; };   /* fmt 1: tagged 8-byte records (yk_device.h YK_R8_*) */
-	std::vector<Kept> kept;
-	bool fast; u64 kept_bytes, fast_budget; u64 t_pass0; bool t_pass0_set; u64 keys_at_begin;
-	double ms_part2, ms_lds;
-	u64 t_end;
-	u64 list_t;                        /* running stream time of yak_ch_insert_list calls */
-	yakamd_stats_t st_cur, st_last;
-
-	/* level-1 records of the last create_new pass, kept for a count pass over the SAME input (yakamd_retain_input / yakamd_count_retained):
-	 * the second pass of the bloom protocol (reference main.c:53-57) then neither reads nor hashes the input again */
-	struct Retained { u64 *d_rec; u64 n; std::vector<u64> bstart; };
-	std::vector<Retained> retained; bool retain_on, retain_broken; u64 retained_bytes;
-	/* ... or, when the whole pass was one slice into an empty table, its level-2 records (grouped by sub-bucket) + the keys every sub-bucket put
-	 * into the table: the count pass then owns each key's counter in LDS (k_cnt2) */
-	struct Ret2 { Rec *d_r2; u64 *d_sbstart, *d_koff, *d_kkc, *d_segbase; FastParams fp; u64 n_total, n_keys; bool valid; } ret2;
-	int n_slices;                      /* slices of the running pass counted so far (fast_flush_slice) */
-	u64 src_id[5]; bool src_set;       /* identity of the file the retained records came from + its sequence count (yak_count) */
-
-	std::mutex api_mu;                 /* serialises whole-table entry points that callers may reach from several threads (yak_ch_insert_list) */
-	void *d_scratch; size_t scratch_bytes;
-
-	/* host mirror */
-	bool host_valid;
-	u64 *hm_keys; u32 *hm_used; u64 hm_slots;
-	struct yak_ht_t *hts;
-};
-
-struct yak_ch_ext { yak_ch_t pub; yakamd_ctx *ctx; u32 magic; int n_sub; yak_ch_t **sub; };   /* n_sub > 1: a table sharded over several GPUs (yak_api.cpp) */
-#define EXT_MAGIC 0x59414b41u
 
 static yakamd_ctx *ctx_of(const yak_ch_t *h)
 {
@@ -1516,425 +1063,6 @@ extern "C" int64_t yakamd_extract_dev(int k, const void *d_bases, int64_t n_byte
 	return (int64_t)n;
 }
 
-/* ------------------------------------------------------------------------------------------
- * layout planning + replay
- * ------------------------------------------------------------------------------------------ */
-
-/* capacity after `m` new keys on a table of (cap, cnt), plus one possible trailing doubling */
-static u32 plan_cap(u32 cap, u32 cnt, u32 m, bool may_trail)
-{
-	u64 n = cap, c = cnt, rem = m;
-	while (rem > 0) {
-		const u64 thr = (n >> 1) + (n >> 2);
-		if (c >= thr) { n = n ? n << 1 : 4; continue; }
-		const u64 b = std::min(rem, thr - c);
-		c += b; rem -= b;
-	}
-	if (may_trail && c >= (n >> 1) + (n >> 2)) n = n ? n << 1 : 4;
-	return (u32)n;
-}
-
-/* rebuild the image from per-sub-table ordered record lists.  rec_t/lastput may be NULL (shrink) */
-/* launch parameters of k_replay for a set of tasks (shared by the two replay drivers) */
-static void legacy_replay_launch(yakamd_ctx *c, const std::vector<ReplayTask> &tasks, const ReplayTask *d_tasks, u64 *nk, u32 *nu, u32 *su, u32 *so, u64 *sp,
-                                 const u64 *d_rec_kc, const u64 *d_rec_t, const u64 *d_lastput, u32 *d_ob, u32 *d_oc)
-{
-	const int P = c->P, n_active = c->phi - c->plo;
-	u32 cap_top = 0;
-	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
-	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 16384));   /* 64 KB: two workgroups per CU (measured 18.5 ms against 20.5 with 128 KB); 0: owner ranks in global scratch */
-	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
-	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
-	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
-	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, lds_words, c->st);
-}
-
-/* Layout replay with the large sub-tables on the streaming kernels (kernels.hip "replay2").  A sub-table whose
- * final capacity stays within 2^SB slots is replayed by k_replay as before.  A larger one is brought to 2^SB slots
- * by k_replay (everything in LDS there), then all of them advance together, step by step: a placement of the next
- * keys up to the growth threshold, or a doubling.  The schedule is khashl's (khashl.h:202: grow BEFORE the put once
- * count >= 0.75 capacity; a trailing put-call on an existing key can still double) and is simulated here on the
- * host; the kernels only move keys.  Returns 0 done, -1 error, 1 not applicable / refused (caller: k_replay). */
-static u32 g_r2_used = 0, g_r2_refused = 0;        /* debug counters: replays done by the streaming kernels / handed back to k_replay */
-
-static int run_replay_v2(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_rec_kc, const u64 *d_rec_t,
-                         const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty, const std::vector<u64> *rec_off_in)
-{
-	const int P = c->P;
-	if (env_i64("YAKAMD_REPLAY2", 1) == 0 || P > 65536) return 1;
-	const u32 SB = (u32)std::min<int64_t>(20, std::max<int64_t>(5, env_i64("YAKAMD_R2_SMALL_BITS", 13))), SMALLCAP = 1u << SB;
-	std::vector<ReplayTask> tasks(P);
-	std::vector<u64> rec_off(P), new_off(P);
-	std::vector<u32> cap0(P), cnt0(P), capm(P);
-	std::vector<char> large(P, 0);
-	u64 rec = 0, tot = 0;
-	bool any = false;
-	for (int p = 0; p < P; ++p) {
-		const u32 ob = from_empty ? YK_NOCAP : c->h_bits[p], ib = init_bits ? (*init_bits)[p] : YK_NOCAP;
-		cnt0[p] = from_empty ? 0 : c->h_count[p];
-		cap0[p] = ob == YK_NOCAP ? 0 : 1u << ob;
-		if (cap0[p] == 0 && ib != YK_NOCAP) cap0[p] = 1u << ib;
-		rec_off[p] = rec_off_in ? (*rec_off_in)[p] : rec; rec += m[p];
-		capm[p] = plan_cap(cap0[p], cnt0[p], m[p], d_lastput != 0);
-		large[p] = capm[p] > SMALLCAP;
-		any = any || large[p];
-		new_off[p] = tot; tot += std::max<u64>(32, capm[p]);
-	}
-	if (!any) return 1;
-	/* trailing put-calls (device data: last put-call and the time of the last new key per sub-table) */
-	std::vector<u32> trail(P, 0);
-	std::vector<u64> lp_host(P, 0);
-	u32 *d_m = 0, *d_trail = 0; u64 *d_ro = 0, *d_lp2 = 0;
-	u64 *nk = 0, *sp = 0, *K0 = 0, *K1 = 0, *pk = 0, *spill = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0, *TAG = 0, *OCC = 0, *USED = 0, *pcnt = 0, *pr = 0, *segst = 0, *head = 0, *Fc = 0, *misc = 0;
-	ReplayTask *d_tasks = 0; R2Tab *d_tabs = 0; R2Act *d_acts = 0; R2Load *d_ld = 0; R2Pub *d_pub = 0;
-	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {
-		dfree(d_m); dfree(d_trail); dfree(d_ro); dfree(d_lp2); dfree(nk); dfree(sp); dfree(K0); dfree(K1); dfree(pk); dfree(spill); dfree(nu); dfree(su); dfree(so);
-		dfree(d_ob); dfree(d_oc); dfree(TAG); dfree(OCC); dfree(USED); dfree(pcnt); dfree(pr); dfree(segst); dfree(head); dfree(Fc); dfree(misc); dfree(d_tasks); dfree(d_tabs); dfree(d_acts); dfree(d_ld); dfree(d_pub);
-	} };
-	if (d_lastput) {
-		if (dmalloc(&d_m, P) || dmalloc(&d_trail, P) || dmalloc(&d_ro, P) || dmalloc(&d_lp2, P)) return -1;
-		HIPCK(hipMemcpyAsync(d_m, m.data(), P * 4, hipMemcpyHostToDevice, c->st));
-		HIPCK(hipMemcpyAsync(d_ro, rec_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
-		yk_r2_trail(d_lastput, d_rec_t, d_ro, d_m, P, d_trail, c->st);
-		HIPCK(hipMemcpyAsync(trail.data(), d_trail, P * 4, hipMemcpyDeviceToHost, c->st));
-		HIPCK(hipMemcpyAsync(lp_host.data(), d_lastput, P * 8, hipMemcpyDeviceToHost, c->st));
-		HIPCK(hipStreamSynchronize(c->st));
-	}
-	/* the schedule of every large sub-table: keys placed by k_replay first (m1), then its actions */
-	struct Act { u32 kind, bits, i0, batch; };
-	std::vector<std::vector<Act> > sched(P);
-	std::vector<u32> m1(P, 0), bitsS(P, YK_NOCAP), cntS(P, 0), bitsF(P, YK_NOCAP), cntF(P, 0);
-	size_t n_steps = 0;
-	u32 n_large = 0;
-	for (int p = 0; p < P; ++p) {
-		if (!large[p]) continue;
-		++n_large;
-		u64 cap = cap0[p], cnt = cnt0[p], rem = m[p];
-		while (rem > 0 && cap0[p] <= SMALLCAP) {                   /* the part k_replay does: up to a full table of SMALLCAP slots */
-			const u64 thr = (cap >> 1) + (cap >> 2);
-			if (cnt >= thr) { if (cap >= SMALLCAP) break; cap = cap ? cap << 1 : 4; continue; }
-			const u64 b = std::min(rem, thr - cnt);
-			cnt += b; rem -= b;
-		}
-		m1[p] = (u32)(m[p] - rem);
-		bitsS[p] = cap ? (u32)ceil_log2_u64(cap) : YK_NOCAP; cntS[p] = (u32)cnt;
-		if (cap == 0) { large[p] = 0; --n_large; continue; }       /* cannot happen: a large sub-table has keys or a table */
-		for (;;) {
-			const u64 thr = (cap >> 1) + (cap >> 2);
-			if (rem > 0) {
-				if (cnt >= thr) { sched[p].push_back({ 2u, (u32)ceil_log2_u64(cap), 0u, 0u }); cap <<= 1; continue; }
-				const u64 b = std::min(rem, thr - cnt);
-				sched[p].push_back({ 1u, (u32)ceil_log2_u64(cap), (u32)(m[p] - rem), (u32)b });
-				cnt += b; rem -= b;
-			} else {
-				if (trail[p] && cnt >= thr) { sched[p].push_back({ 2u, (u32)ceil_log2_u64(cap), 0u, 0u }); cap <<= 1; }
-				break;
-			}
-		}
-		bitsF[p] = (u32)ceil_log2_u64(cap); cntF[p] = (u32)cnt;
-		if ((1ull << bitsF[p]) > capm[p]) return fail("replay schedule exceeds the planned capacity");
-		n_steps = std::max(n_steps, sched[p].size());
-	}
-	if (n_large == 0) return 1;
-	for (int p = 0; p < P; ++p) if (large[p] && (int)bitsF[p] - yk_r2_seg_log() > 10) return 1;   /* more than 1024 segments per sub-table: not handled */
-	/* k_replay: the small sub-tables into the final arena, the first part of the large ones into a side arena behind it */
-	const u64 tot_ext = tot + (u64)n_large * std::max<u64>(32, SMALLCAP);
-	{
-		u64 side = tot;
-		for (int p = 0; p < P; ++p) {
-			ReplayTask &t = tasks[p];
-			t.old_bits = from_empty ? YK_NOCAP : c->h_bits[p];
-			t.old_count = cnt0[p]; t.old_off = c->h_off[p];
-			t.rec_off = rec_off[p]; t.m = m[p];
-			t.init_bits = init_bits ? (*init_bits)[p] : YK_NOCAP;
-			t.cap_max_bits = capm[p] ? (u32)ceil_log2_u64(capm[p]) : 0;
-			t.dbg = (u32)env_i64("YAKAMD_DBG", 0);
-			t.new_off = new_off[p];
-			if (large[p]) {
-				t.new_off = side; side += std::max<u64>(32, SMALLCAP);
-				lp_host[p] = 0;                                       /* the trailing put-call is the schedule's business */
-				if (cap0[p] > SMALLCAP) { t.old_bits = YK_NOCAP; t.old_count = 0; t.m = 0; t.init_bits = YK_NOCAP; t.cap_max_bits = 0; }   /* already beyond: loaded straight from the old image */
-				else { t.m = m1[p]; t.cap_max_bits = SB; }
-			}
-		}
-	}
-	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
-	/* k_replay's scratch arrays (ranks, second bitmap, doubling lists: 28 bytes per slot) are indexed by arena offsets.  When every sub-table it
-	 * touches is a large one -- an assembly, any pass of a big count -- it only works in the side arena behind the final one, so the arrays
-	 * cover that alone and are addressed from `tot` on: at 2 G keys they were 85 GB that nothing touched, more than the pool could keep, and the
-	 * hipMalloc / hipFree of them cost 5 s per pass (the kernels of the whole layout stage: 0.28 s) */
-	bool only_side = true;
-	for (int p = 0; p < P; ++p) if (!large[p] && (m[p] || cap0[p])) only_side = false;
-	const u64 scr_lo = only_side ? tot : 0, scr_n = tot_ext - scr_lo;
-	if (only_side) {
-		/* the scratch pointers handed to k_replay below are shifted by scr_lo: that is only sound while the kernel touches no scratch below `tot`,
-		 * i.e. while every task outside the side arena is an empty one, and while bitmap words of the two arenas do not straddle */
-		if (tot % 32 != 0) return fail("replay: arena size %llu is not a multiple of 32", (unsigned long long)tot);
-		for (int p = 0; p < P; ++p) {
-			if (large[p]) continue;
-			if (tasks[p].m != 0 || tasks[p].old_count != 0 || cap0[p] != 0) return fail("replay: sub-table %d is not empty but lies outside the side arena", p);
-			lp_host[p] = 0;                                          /* no put-call can have hit a sub-table that holds nothing: never let a stray time grow it */
-		}
-	}
-	/* Every sub-table that holds anything is a large one and ends at the capacity the arena reserves for it (no trailing doubling left out): the
-	 * two buffers the doublings alternate between are then laid out exactly like the arena, and whichever holds most of the final tables BECOMES the
-	 * table image -- the others' tables are copied over, nothing else is (the copy of every slot into a third array was 12 ms and 34 GB beside a
-	 * 2 Gb assembly).  k_replay's side arena is then all that `nk` / `nu` hold; they are addressed from `tot` on like its scratch */
-	bool inplace = only_side;
-	for (int p = 0; p < P && inplace; ++p) if (large[p] && (1ull << bitsF[p]) != std::max<u64>(32, capm[p])) inplace = false;
-	const u64 nk_lo = inplace ? tot : 0;
-	u64 *nk_al = 0; u32 *nu_al = 0, *img_u = 0;                  /* what was allocated: nk / nu below are shifted by nk_lo; img_u: the image's bitmap when a buffer becomes the image */
-	struct GuardNk { std::function<void()> f; ~GuardNk() { f(); } } guard_nk{ [&]() { dfree(nk_al); dfree(nu_al); dfree(img_u); nk = 0; nu = 0; } };
-	if ((par && dmalloc(&sp, 2 * scr_n)) || dmalloc(&nk_al, tot_ext - nk_lo) || dmalloc(&nu_al, (tot_ext - nk_lo) / 32 + 1) || dmalloc(&su, scr_n / 32 + 1) || dmalloc(&so, scr_n) ||
-	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
-	nk = nk_al - nk_lo; nu = nu_al - nk_lo / 32;
-	if (inplace) {
-		HIPCK(hipMemsetAsync(nk_al, 0xff, (tot_ext - tot) * 8, c->st));
-		HIPCK(hipMemsetAsync(nu_al, 0, ((tot_ext - tot) / 32 + 1) * 4, c->st));
-	} else if (only_side) {
-		/* k_r2_publish writes every slot and every bitmap word of a large sub-table: only the side arena and the (empty, 32-slot) regions of
-		 * the other sub-tables need the empty pattern -- not 8 bytes per slot of the whole arena (1 Gb assembly: 2.9 ms) */
-		HIPCK(hipMemsetAsync(nk + tot, 0xff, (tot_ext - tot) * 8, c->st));
-		HIPCK(hipMemsetAsync(nu + tot / 32, 0, ((tot_ext - tot) / 32 + 1) * 4, c->st));
-		for (int p = 0; p < P;) {
-			if (large[p]) { ++p; continue; }
-			int q = p;
-			while (q < P && !large[q]) ++q;                          /* a run of sub-tables without a large table: contiguous in the arena */
-			const u64 a = new_off[p], b = q < P ? new_off[q] : tot;
-			HIPCK(hipMemsetAsync(nk + a, 0xff, (b - a) * 8, c->st));
-			HIPCK(hipMemsetAsync(nu + a / 32, 0, (b - a) / 32 * 4, c->st));
-			p = q;
-		}
-	} else {
-		HIPCK(hipMemsetAsync(nk, 0xff, tot_ext * 8, c->st));
-		HIPCK(hipMemsetAsync(nu, 0, (tot_ext / 32 + 1) * 4, c->st));
-	}
-	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
-	if (d_lastput) HIPCK(hipMemcpyAsync(d_lp2, lp_host.data(), P * 8, hipMemcpyHostToDevice, c->st));
-	legacy_replay_launch(c, tasks, d_tasks, nk, nu, su - scr_lo / 32, so - scr_lo, sp ? sp - 2 * scr_lo : 0, d_rec_kc, d_rec_t, d_lastput ? d_lp2 : 0, d_ob, d_oc);
-	std::vector<u32> ob(P), oc(P);
-	HIPCK(hipMemcpyAsync(ob.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipMemcpyAsync(oc.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
-	dfree(sp); dfree(su); dfree(so);
-	/* buffers of the large sub-tables */
-	std::vector<R2Tab> tabs(P);
-	std::vector<u32> seg0(P, 0);
-	const int SEGLOG = yk_r2_seg_log();
-	u64 tot2 = 0, nseg_tot = 0; u32 bmaxF = 0, bmaxS = 0;
-	for (int p = 0; p < P; ++p) {
-		tabs[p].off = inplace ? new_off[p] : tot2; tabs[p].rec_off = rec_off[p];
-		if (!large[p]) continue;
-		if (cap0[p] <= SMALLCAP && (ob[p] != bitsS[p] || oc[p] != cntS[p])) return fail("replay: sub-table %d left k_replay with 2^%u slots / %u keys, the schedule says 2^%u / %u", p, ob[p], oc[p], bitsS[p], cntS[p]);
-		tot2 += 1ull << bitsF[p];
-		seg0[p] = (u32)nseg_tot;
-		nseg_tot += (bitsF[p] > (u32)SEGLOG ? 1ull << (bitsF[p] - SEGLOG) : 1) + 1;
-		bmaxF = std::max(bmaxF, bitsF[p]); bmaxS = std::max(bmaxS, bitsS[p]);
-	}
-	std::vector<R2Act> acts(std::max<size_t>(1, n_steps) * P);
-	memset(acts.data(), 0, acts.size() * sizeof(R2Act));
-	std::vector<R2Load> ld(P); std::vector<R2Pub> pub(P);
-	u64 side = tot;
-	for (int p = 0; p < P; ++p) {
-		ld[p].bits = YK_NOCAP; ld[p].src_off = 0; ld[p].from_src = 0; ld[p].dst = 0; ld[p].pad = 0;
-		pub[p].bits = YK_NOCAP; pub[p].new_off = new_off[p]; pub[p].src = 0;
-		if (!large[p]) continue;
-		ld[p].bits = bitsS[p];
-		if (cap0[p] > SMALLCAP) { const bool old = !from_empty && c->h_bits[p] != YK_NOCAP; ld[p].from_src = old ? 2 : 0; ld[p].src_off = old ? c->h_off[p] : 0; }
-		else { ld[p].from_src = 1; ld[p].src_off = side; }
-		side += std::max<u64>(32, SMALLCAP);
-		u32 src = 0;
-		for (size_t k = 0; k < sched[p].size(); ++k) {
-			R2Act &a = acts[k * P + p];
-			a.kind = sched[p][k].kind; a.bits = sched[p][k].bits; a.i0 = sched[p][k].i0; a.batch = sched[p][k].batch; a.src = src; a.seg0 = seg0[p];
-			if (a.kind == 2) src ^= 1;
-		}
-		pub[p].bits = bitsF[p]; pub[p].src = src;
-	}
-	/* the buffer that becomes the image, known before anything runs (the schedule is simulated): a sub-table that ends there with a placement gets
-	 * its "used" bits from that step's kernels (R2Act.pad0) and needs no pass of k_r2_publish */
-	bool img_is1 = false;
-	std::vector<char> pub_needed(P, 1);
-	if (inplace) {
-		u64 in1 = 0, in0 = 0;
-		for (int p = 0; p < P; ++p) if (large[p]) (pub[p].src ? in1 : in0) += 1ull << bitsF[p];
-		img_is1 = in1 > in0;
-		if (dmalloc(&img_u, tot / 32 + 1)) return -1;
-		for (int p = 0; p < P; ++p) {
-				if (!large[p] || sched[p].empty() || sched[p].back().kind != 1 || (pub[p].src != 0) != img_is1) continue;
-				acts[(sched[p].size() - 1) * P + p].pad0 = 1;
-				pub_needed[p] = 0;
-			}
-	}
-	if (inplace) tot2 = tot;                                     /* the buffers are arenas */
-	const u32 spill_cap = (u32)std::min<u64>(1u << 28, std::max<u64>(1u << 20, tot2 / 16));   /* also the list of long runs of a doubling round */
-	u64 n_keys = 0;
-	for (int p = 0; p < P; ++p) n_keys = std::max(n_keys, rec_off[p] + m[p]);
-	if (dmalloc(&K0, tot2) || dmalloc(&K1, tot2) || dmalloc(&TAG, tot2 / 2 + 1) || dmalloc(&OCC, tot2 / 16 + (size_t)P + 64) || dmalloc(&USED, tot2 / 32 + 64) || dmalloc(&d_tabs, P) || dmalloc(&d_acts, acts.size()) || dmalloc(&d_ld, P) || dmalloc(&d_pub, P) ||
-	    dmalloc(&pk, n_keys) || dmalloc(&pr, n_keys) || dmalloc(&segst, nseg_tot + 1) || dmalloc(&head, (size_t)nseg_tot * yk_r2_head()) || dmalloc(&spill, spill_cap) || dmalloc(&Fc, 4 * (size_t)P) || dmalloc(&misc, 4)) return -1;
-	/* few large sub-tables (a shard): the keys of a stage are grouped by G workgroups per sub-table instead of one (YAKAMD_R2_PPART_G: tests) */
-	int ppG = (int)std::min<int64_t>(16, std::max<int64_t>(1, env_i64("YAKAMD_R2_PPART_G", n_large <= 512 ? 1024 / std::max<u32>(1, n_large) : 1)));
-	if ((size_t)P * ppG > (64u << 10)) ppG = 1;                   /* (the counters are indexed by sub-table: 4 KB per sub-table and share) */
-	if (ppG > 1 && dmalloc(&pcnt, (size_t)P * ppG * 1024)) return -1;
-	HIPCK(hipMemcpyAsync(d_tabs, tabs.data(), P * sizeof(R2Tab), hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemcpyAsync(d_acts, acts.data(), acts.size() * sizeof(R2Act), hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemcpyAsync(d_ld, ld.data(), P * sizeof(R2Load), hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemsetAsync(misc, 0, 16, c->st));
-	u32 *d_fail = misc, *d_nspill = misc + 1;
-	yk_r2_load(d_tabs, d_ld, P, bmaxS, nk, c->d_keys, K0, K1, USED, c->st);
-	const bool prof = env_i64("YAKAMD_VERBOSE", 0) > 1;
-	auto lap = [&](const char *what, size_t k, u32 bits, double *t0) {
-		if (!prof) return;
-		hipStreamSynchronize(c->st);
-		const double t1 = now_ms();
-		fprintf(stderr, "[yak_amd] replay2 step %zu (2^%u): %s %.3f ms\n", k, bits, what, t1 - *t0);
-		*t0 = t1;
-	};
-	double tl = now_ms();
-	lap("k_replay part + load", 0, bmaxS, &tl);
-	for (size_t k = 0; k < n_steps; ++k) {
-		u32 bd = 0, bp = 0; bool any_d = false, any_p = false;
-		int p_lo = P, p_hi = 0;                                      /* the sub-tables that place in this step: a shard's are a contiguous range of the P */
-		for (int p = 0; p < P; ++p) {
-			const R2Act &a = acts[k * P + p];
-			if (a.kind == 2) { any_d = true; bd = std::max(bd, a.bits); }
-			else if (a.kind == 1) { any_p = true; bp = std::max(bp, a.bits); p_lo = std::min(p_lo, p); p_hi = p + 1; }
-		}
-		const R2Act *da = d_acts + k * P;
-		if (any_d) {
-			yk_r2_binit(d_tabs, da, P, bd, OCC, USED, c->st);
-			lap("binit", k, bd, &tl);
-			int n_dbl = 0;
-			for (int p = 0; p < P; ++p) n_dbl += acts[k * P + p].kind == 2;
-			yk_r2_dsmall(d_tabs, da, P, K0, K1, TAG, OCC, USED, Fc, Fc + 2 * P, d_fail, c->st);
-			lap("dsmall", k, bd, &tl);
-			/* the rounds from there on in one launch: a workgroup per sub-table walks its rounds behind workgroup barriers.  A sub-table that does
-			 * not reach its end raises `fail` (read once, after the last step: whatever the later steps then do is thrown away with the buffers) */
-			yk_r2_double(d_tabs, da, P, n_dbl, K0, K1, TAG, OCC, USED, Fc, Fc + P, d_fail, c->st);
-			lap("double (fused rounds)", k, bd, &tl);
-		}
-		if (any_p) { yk_r2_place(d_tabs, da, P, p_lo, p_hi - p_lo, bp, K0, K1, d_rec_kc, pk, pr, segst, head, spill, d_nspill, spill_cap, d_fail, img_u, USED, pcnt, ppG, c->st); lap("place", k, bp, &tl); }
-	}
-	u64 *img_k = 0;                                               /* the new image, once it is certain */
-	if (inplace) {
-		u64 *A = img_is1 ? K1 : K0;
-		/* the regions of the sub-tables that hold nothing: empty pattern, no bit */
-		for (int p = 0; p < P;) {
-			if (large[p]) { ++p; continue; }
-			int q = p;
-			while (q < P && !large[q]) ++q;
-			const u64 a = new_off[p], b = q < P ? new_off[q] : tot;
-			HIPCK(hipMemsetAsync(A + a, 0xff, (b - a) * 8, c->st));
-			HIPCK(hipMemsetAsync(img_u + a / 32, 0, (b - a) / 32 * 4, c->st));
-			p = q;
-		}
-		for (int p = 0; p < P; ++p) { pub[p].new_off = tabs[p].off; if (!pub_needed[p]) pub[p].bits = YK_NOCAP; }
-		HIPCK(hipMemcpyAsync(d_pub, pub.data(), P * sizeof(R2Pub), hipMemcpyHostToDevice, c->st));
-		yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, A, img_u, c->st);   /* a table already in A only gets its bitmap */
-		img_k = A;
-	} else yk_r2_publish(d_tabs, d_pub, P, bmaxF, K0, K1, nk, nu, c->st);
-	lap("publish", n_steps, bmaxF, &tl);
-	u32 h_fail = 0;
-	HIPCK(hipMemcpyAsync(&h_fail, d_fail, 4, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
-	if (h_fail) {
-		if (env_i64("YAKAMD_VERBOSE", 0)) fprintf(stderr, "[yak_amd] streaming replay refused (code %u): falling back to k_replay\n", h_fail);
-		++g_r2_refused;
-		return 1;
-	}
-	++g_r2_used;
-	for (int p = 0; p < P; ++p) {
-		if (large[p]) { c->h_bits[p] = bitsF[p]; c->h_count[p] = cntF[p]; }
-		else { c->h_bits[p] = ob[p]; c->h_count[p] = oc[p]; }
-	}
-	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
-	if (inplace) {
-		c->d_keys = img_k; c->d_used = img_u; img_u = 0;
-		if (img_k == K0) K0 = 0; else K1 = 0;                     /* the guard releases the other one */
-	} else { c->d_keys = nk_al; c->d_used = nu_al; nk_al = 0; nu_al = 0; }
-	c->n_slots = tot;
-	c->h_off = new_off;
-	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
-	c->img_keys_total = 0;
-	for (int p = 0; p < P; ++p) c->img_keys_total += c->h_count[p];
-	c->host_valid = false;
-	return 0;
-}
-
-static int run_replay(yakamd_ctx *c, const std::vector<u32> &m, const u64 *d_seg_off, const u64 *d_rec_kc, const u64 *d_rec_t,
-                      const u64 *d_lastput, const std::vector<u32> *init_bits, bool from_empty, const std::vector<u64> *rec_off = 0)
-{
-	{
-		const int r2 = run_replay_v2(c, m, d_rec_kc, d_rec_t, d_lastput, init_bits, from_empty, rec_off);
-		if (r2 <= 0) return r2;
-	}
-	const int P = c->P;
-	std::vector<ReplayTask> tasks(P);
-	std::vector<u64> new_off(P);
-	u64 tot = 0, rec = 0;
-	for (int p = 0; p < P; ++p) {
-		ReplayTask &t = tasks[p];
-		t.old_bits = from_empty ? YK_NOCAP : c->h_bits[p];
-		t.old_count = from_empty ? 0 : c->h_count[p];
-		t.old_off = c->h_off[p];
-		t.rec_off = rec_off ? (*rec_off)[p] : rec; t.m = m[p]; rec += m[p];
-		t.init_bits = init_bits ? (*init_bits)[p] : YK_NOCAP;
-		u32 cap0 = t.old_bits == YK_NOCAP ? 0 : 1u << t.old_bits;
-		if (cap0 == 0 && t.init_bits != YK_NOCAP) cap0 = 1u << t.init_bits;
-		const u32 capm = plan_cap(cap0, t.old_count, t.m, d_lastput != 0);
-		t.cap_max_bits = capm ? (u32)ceil_log2_u64(capm) : 0;
-		t.dbg = (u32)env_i64("YAKAMD_DBG", 0);
-		new_off[p] = tot; t.new_off = tot;
-		tot += std::max<u64>(32, capm);
-	}
-	(void)d_seg_off;
-	u64 *nk = 0, *sp = 0; u32 *nu = 0, *su = 0, *so = 0, *d_ob = 0, *d_oc = 0;
-	ReplayTask *d_tasks = 0;
-	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ [&]() {   /* nk / nu are handed to the context on success (set to 0 there) */
-		dfree(su); dfree(so); dfree(sp); dfree(d_tasks); dfree(d_ob); dfree(d_oc); dfree(nk); dfree(nu);
-	} };
-	const bool par = env_i64("YAKAMD_PAR_REPLAY", 1) != 0;
-	if ((par && dmalloc(&sp, 2 * tot)) || dmalloc(&nk, tot) || dmalloc(&nu, tot / 32) || dmalloc(&su, tot / 32) || dmalloc(&so, tot) ||
-	    dmalloc(&d_tasks, P) || dmalloc(&d_ob, P) || dmalloc(&d_oc, P)) return -1;
-	HIPCK(hipMemsetAsync(nk, 0xff, tot * 8, c->st));
-	HIPCK(hipMemsetAsync(nu, 0, tot / 8, c->st));
-	HIPCK(hipMemcpyAsync(d_tasks, tasks.data(), P * sizeof(ReplayTask), hipMemcpyHostToDevice, c->st));
-	/* few, large sub-tables (a shard of a multi-GPU job): more lanes per sub-table */
-	const int n_active = c->phi - c->plo;
-	/* owner ranks of the placement stages in LDS: 32-bit up to lds_words slots, 16-bit up to twice that */
-	u32 cap_top = 0;
-	for (int p = 0; p < P; ++p) if (tasks[p].m) cap_top = std::max(cap_top, 1u << tasks[p].cap_max_bits);
-	u32 lds_words = std::min<u32>(cap_top, (u32)env_i64("YAKAMD_REPLAY_LDS", 16384));   /* 64 KB: two workgroups per CU (measured 18.5 ms against 20.5 with 128 KB); 0: owner ranks in global scratch */
-	int n_thr = n_active <= 256 ? 1024 : n_active <= 512 ? 512 : 256;
-	if (lds_words * 4 >= 96 * 1024) n_thr = 1024; else if (lds_words * 4 >= 48 * 1024) n_thr = std::max(n_thr, 512);
-	n_thr = (int)env_i64("YAKAMD_REPLAY_THREADS", n_thr);
-	yk_launch_replay(d_tasks, P, n_thr, c->d_keys, c->d_used, nk, nu, su, so, sp, d_rec_kc, d_rec_t, d_lastput, d_ob, d_oc, lds_words, c->st);
-	if (env_i64("YAKAMD_DBG", 0) & 32) {
-		HIPCK(hipStreamSynchronize(c->st));
-		u64 pr[8]; yk_replay_prof(pr);
-		fprintf(stderr, "[yak_amd] replay block 0 (100 MHz ticks): double<32K %llu, double>=32K %llu, place<32K %llu, place>=32K %llu, publish %llu | par doubling: setup+base %llu, rounds %llu, verify+commit %llu\n",
-		        (unsigned long long)pr[0], (unsigned long long)pr[1], (unsigned long long)pr[2], (unsigned long long)pr[3], (unsigned long long)pr[4],
-		        (unsigned long long)pr[5], (unsigned long long)pr[6], (unsigned long long)pr[7]);
-	}
-	HIPCK(hipMemcpyAsync(c->h_bits.data(), d_ob, P * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipMemcpyAsync(c->h_count.data(), d_oc, P * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
-	dfree(c->d_keys); dfree(c->d_used); dfree(c->d_delta);
-	c->d_keys = nk; c->d_used = nu; c->n_slots = tot;
-	nk = 0; nu = 0;
-	c->h_off = new_off;
-	HIPCK(hipMemcpyAsync(c->d_bits, c->h_bits.data(), P * 4, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipMemcpyAsync(c->d_off, c->h_off.data(), P * 8, hipMemcpyHostToDevice, c->st));
-	HIPCK(hipStreamSynchronize(c->st));
-	c->img_keys_total = 0;
-	for (int p = 0; p < P; ++p) c->img_keys_total += c->h_count[p];
-	c->host_valid = false;
-	return 0;
-}
-
 /* pass_end of the fast path: level-2 partition -> exclusive LDS counting (+ bloom gate) ->
  * per sub-table sort by insertion time -> exact layout replay */
 static int fast_finish(yakamd_ctx *c, bool last)
@@ -2355,7 +1483,7 @@ static int fast_finish(yakamd_ctx *c, bool last)
 	{
 		EvTimer tm(c->st);
 		ro.resize(P);
-		if (run_replay(c, m, 0, kc[cur], tt[cur], c->d_lastput, 0, false, &ro)) return -1;
+		if (yk_run_replay(c, m, 0, kc[cur], tt[cur], c->d_lastput, 0, false, &ro)) return -1;
 		c->st_cur.ms_replay += tm.stop();
 	}
 	lap("exact layout");
@@ -2437,7 +1565,7 @@ static int64_t pass_end_body(yakamd_ctx *c)
 		}
 		{
 			EvTimer tm(c->st);
-			if (run_replay(c, m, d_segoff, kc[cur], tt[cur], c->d_lastput, 0, false)) return -1;
+			if (yk_run_replay(c, m, d_segoff, kc[cur], tt[cur], c->d_lastput, 0, false)) return -1;
 			c->st_cur.ms_replay += tm.stop();
 		}
 		n_ins = (int64_t)(c->img_keys_total - before);
@@ -2454,7 +1582,7 @@ extern "C" void yakamd_debug_counters(uint32_t *out4)
 {
 	out4[0] = out4[1] = 0;
 	yk_par_counters(&out4[0], &out4[1]);
-	out4[2] = g_r2_used; out4[3] = g_r2_refused;
+	yk_replay_counters(&out4[2], &out4[3]);
 }
 
 /* small runtime services for callers that hold no HIP runtime of their own (bench.py's single-GPU mode, the tests): page-locked host memory and
@@ -2536,7 +1664,7 @@ static int rebuild(yakamd_ctx *c, int cmin, int cmax, int which, yakamd_ctx *oth
 	HIPCK(hipMemcpyAsync(d_segoff, seg_off.data(), (P + 1) * 8, hipMemcpyHostToDevice, c->st));
 	yk_launch_shrink_scatter(img_view(c), P, cmin, cmax, which, ov, d_segoff, d_kc, c->st, d_segcnt);
 	EvTimer tm(c->st);
-	const int r = run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
+	const int r = yk_run_replay(c, m, d_segoff, d_kc, 0, 0, &init, true);
 	c->st_last.ms_shrink = tm.stop();
 	if (r) return r;
 	*tot = c->img_keys_total;
@@ -2649,8 +1777,6 @@ int yk_ctx_list_hashes(yakamd_ctx *c, int cmin, int cmax, u64 **d_hash, u32 **d_
 	done = true;
 	return 0;
 }
-void yk_pool_release(void *p) { if (p) pool_free(p); }
-void *yk_pool_get(size_t bytes) { return pool_alloc(bytes ? bytes : 1, true); }   /* (plain hipMalloc memory: what the collective library's transports are used with) */   /* the current device's pool (multi-GPU chunk and exchange buffers: a job's second call finds the first one's) */
 
 /* the .yak bytes of sub-tables [lo, hi) -- per sub-table capacity and size (4 bytes each) and the stored keys in ascending slot order,
  * htab.c:385-389 -- put together on the device: *d_img (pool memory: yk_pool_release) holds *n_words 8-byte words, ready on the table's stream */
@@ -2705,7 +1831,7 @@ int yk_ctx_load(yakamd_ctx *c, const uint32_t *caps, const uint32_t *sizes, cons
 	u64 *d_kc = 0;
 	if (dmalloc(&d_kc, tot)) return -1;
 	HIPCK(hipMemcpyAsync(d_kc, keys, tot * 8, hipMemcpyHostToDevice, c->st));
-	const int r = run_replay(c, m, 0, d_kc, 0, 0, &init, true);
+	const int r = yk_run_replay(c, m, 0, d_kc, 0, 0, &init, true);
 	dfree(d_kc);
 	return r;
 }

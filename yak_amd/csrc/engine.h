@@ -1,4 +1,4 @@
-/* engine.h -- internal interface between engine.cpp and yak_api.cpp */
+/* engine.h -- internal interface between pool.cpp, engine.cpp and the yak.h surface (yak_api.cpp, yak_reader.cpp, yak_multi.cpp) */
 #ifndef YK_ENGINE_H
 #define YK_ENGINE_H
 #include "../../include/yak_amd.h"
@@ -22,6 +22,9 @@ void yk_pool_release(void *p);
 int yk_set_error(const char *fmt, ...);                      /* this thread's yakamd_last_error() text (+ a line on stderr); returns -1 */
 int64_t yk_knob(const char *name, int64_t dflt);             /* a run-time setting: the test hook's value, else (public names only) the environment's, else dflt */
 void *yk_pool_get(size_t bytes);
+void *yk_pool_alloc(size_t bytes, bool plain);              /* pool.cpp: a device buffer from the current device's pool (plain: never from the virtual-memory tier); 0 when the device is full */
+void yk_pool_free(void *p);
+double yk_now_ms(void);                                      /* monotonic wall clock */
 int yk_ctx_dump_image_dev(yakamd_ctx *c, int lo, int hi, u64 **d_img, u64 *n_words);   /* the .yak bytes of sub-tables [lo, hi), in pool memory */
 void yk_ctx_gate(yakamd_ctx *c, bool on);
 void yk_ctx_or_mode(yakamd_ctx *c, int mode);   /* 0 counting; 1 flag loads; 2 saved-count loads (yk_device.h FastParams.or_mode) */
@@ -37,6 +40,7 @@ int  yk_ctx_sync_host(yakamd_ctx *c, yak_ch_t *h);
 u64  yk_ctx_list_time(yakamd_ctx *c, u64 n);
 int  yk_ctx_device(yakamd_ctx *c);
 size_t yk_pool_cached_bytes(void);
+size_t yk_pool_held_bytes(int dev);
 void yk_pool_report(const char *what);
 hipStream_t yk_ctx_stream(yakamd_ctx *c);
 void yk_ctx_set_source(yakamd_ctx *c, const uint64_t id[4], int64_t n_seq);

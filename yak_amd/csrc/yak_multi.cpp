@@ -140,7 +140,17 @@ struct MultiJob {
  * and one pass holds ~70 bytes per selected key at its peak -- such inputs are counted as N ranks on one device, i.e. in N sweeps over
  * prefix ranges (N so that a sweep sees at most ~2.8 G positions of its own: 5 Gb in 2 sweeps, 2.4 s on a device whose memory has been in use
  * before, 2.4 s in 4; round 3 needed 4 -- a rank of 2 held a third copy of its table and 4 bytes of pending counts per slot while its layout
- * was replayed).  YAKAMD_GPUS set to anything switches the rule off */
+ * was replayed).  YAKAMD_GPUS set to anything switches the rule off.
+ *
+ * What the memory costs (round 6).  `yak count` is one job per process (main.c:53-61), and a process pays the driver ~30 ms for every GB of device
+ * memory beyond the first ~150 (profiles/r06_mb_vmm5.txt; from any number of threads): the 5 Gb assembly in 2 sweeps obtains 239 GB and spends 2.7 of
+ * its 4.4 s there, in 8 sweeps it peaks at 103 GB, obtains 150 and takes 1.96 s -- 1.77 s once the memory is the process's own, against 1.60-1.68 in 2
+ * (profiles/r06_experiments.txt e11).  So a process that does not hold the memory of the plan above yet takes more sweeps: the smallest N whose
+ * estimated peak -- 14 bytes per input byte for the table of an assembly + 56 per byte of a sweep's share -- stays within YAKAMD_COLD_GB (110; 0 = the
+ * rule above alone).  That also sends files between 1.6 and 2.5 GB through 2 sweeps on a cold device.  A process whose pool already holds what the
+ * smaller N needs (an earlier job obtained it) keeps the smaller N. */
+static int g_last_sweeps = 1;
+extern "C" int yakamd_last_sweeps(void) { return g_last_sweeps; }   /* ranks (= sweeps on one device) of this process's last yak_count() */
 int auto_sweeps(const yak_copt_t *opt, const char *fn)
 {
 	if (fn == 0 || strcmp(fn, "-") == 0 || opt->bf_shift > opt->pre) return 1;
@@ -148,16 +158,27 @@ int auto_sweeps(const yak_copt_t *opt, const char *fn)
 	const double lim = (g ? atof(g) : 2.5) * 1e9;
 	if (lim <= 0) return 1;
 	struct stat sb;
-	if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode) || (double)sb.st_size <= lim) return 1;
+	if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
 	unsigned char m[2] = { 0, 0 };
 	const int f = ::open(fn, O_RDONLY);
 	if (f < 0) return 1;
 	const bool gz = ::read(f, m, 2) == 2 && m[0] == 0x1f && m[1] == 0x8b;
 	::close(f);
 	if (gz) return 1;                                           /* compressed: the size says little; the knob is there */
-	int N = 2;
-	while (N < 16 && (double)sb.st_size / N > 2.8e9) N <<= 1;
-	return (1 << opt->pre) % N ? 1 : N;
+	const int P = 1 << opt->pre;
+	const double sz = (double)sb.st_size;
+	int N = 1;
+	if (sz > lim) { N = 2; while (N < 16 && sz / N > 2.8e9) N <<= 1; }
+	const char *cg = getenv("YAKAMD_COLD_GB");
+	const double cold = (cg ? atof(cg) : 110.0) * 1e9;
+	auto peak = [&](int n) { return sz * (14.0 + 56.0 / n); };
+	if (cold > 0 && peak(N) > cold) {
+		int nd = 0, d = 0;
+		if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) { const char *dv = getenv("YAKAMD_DEVICE"), *lr = getenv("LOCAL_RANK"); d = (dv ? atoi(dv) : lr ? atoi(lr) : 0) % nd; }
+		if ((double)yk_pool_held_bytes(d) < peak(N))            /* the process does not own that memory yet */
+			while (N < 16 && P % (2 * N) == 0 && peak(N) > cold) N <<= 1;
+	}
+	return N > 1 && P % N ? 1 : N;
 }
 
 int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *fn)
@@ -165,13 +186,15 @@ int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *fn)
 	const char *e = getenv("YAKAMD_GPUS");
 	if (!e) {
 		const int S = auto_sweeps(opt, fn);
+		g_last_sweeps = 1;
 		if (S <= 1) return 1;
 		int nd = 0;
 		if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return 1;
 		const char *dv = getenv("YAKAMD_DEVICE"), *lr = getenv("LOCAL_RANK");
 		const int d = (dv ? atoi(dv) : lr ? atoi(lr) : 0) % nd;
 		dev->assign(S, d);
-		fprintf(stderr, "[M::yak_count] %s: no filter and a large plain file: counting in %d sweeps over prefix ranges on device %d (YAKAMD_GPUS / YAKAMD_AUTO_SWEEP_GB change that)\n", fn, S, d);
+		fprintf(stderr, "[M::yak_count] %s: no filter and a large plain file: counting in %d sweeps over prefix ranges on device %d (YAKAMD_GPUS / YAKAMD_AUTO_SWEEP_GB / YAKAMD_COLD_GB change that)\n", fn, S, d);
+		g_last_sweeps = S;
 		return S;
 	}
 	const int N = atoi(e);
@@ -183,6 +206,7 @@ int multi_gpus(const yak_copt_t *opt, std::vector<int> *dev, const char *fn)
 	if (const char *l = getenv("YAKAMD_GPU_LIST")) { for (const char *q = l; *q; ) { dev->push_back(atoi(q) % nd); while (*q && *q != ',') ++q; if (*q) ++q; } }
 	for (int r = (int)dev->size(); r < N; ++r) dev->push_back(r % nd);
 	dev->resize(N);
+	g_last_sweeps = N;
 	return N;
 }
 
