@@ -509,7 +509,12 @@ def main():
         a.bf_shift = 0
     if a.config in ("cfg3shard", "cfg4", "cfg5"):
         import bench_configs
-        return bench_configs.run(a)
+        try:
+            return bench_configs.run(a)
+        finally:
+            if os.environ.get("YAKAMD_VERBOSE"):
+                import yak_amd as _y
+                _y.lib().yakamd_pool_report(b"the bench")
     if a.scaling == "strong":
         if a.total_reads <= 0:
             raise SystemExit("--scaling strong needs --total-reads")
@@ -1050,6 +1055,8 @@ def main():
     if not a.no_cpu_baseline and world == 1:                      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(a.reads, genome, a.bf_shift, min(os.cpu_count() or 8, 32))
     print(json.dumps(out))
+    if os.environ.get("YAKAMD_VERBOSE"):
+        yak_amd.lib().yakamd_pool_report(b"the bench")
     if sharded:
         dist.destroy_process_group()
 

@@ -180,6 +180,8 @@ int yakamd_mem_info(size_t *free_bytes, size_t *total_bytes);
 int64_t yakamd_peak_bytes(int dev, int reset);
 /* release the device-memory cache kept between passes (memory pool) */
 void yakamd_trim(void);
+/* one line per tier on stderr: what the current device's pool has obtained from the driver, holds in use and idle, and how its large buffers came about */
+void yakamd_pool_report(const char *what);
 /* how many ranks this process's last yak_count() ran as (> 1 on one device: the pass went in that many sweeps over prefix ranges -- YAKAMD_GPUS, or the
  * library's own rule for large unfiltered inputs, which takes more sweeps while the process does not own the device memory of fewer: INTEGRATION.md section 4) */
 int yakamd_last_sweeps(void);

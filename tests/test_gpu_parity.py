@@ -326,7 +326,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                                  dict(YAKAMD_S2_BITS="14", YAKAMD_CH2="4096"), dict(YAKAMD_LC_FLAT="1"), dict(YAKAMD_LC_FLAT="1", YAKAMD_S2_BITS="5", YAKAMD_BATCH="65536"), dict(YAKAMD_LC_FLAT="0"),
                                  dict(YAKAMD_TSORT="0"), dict(YAKAMD_TSORT="1"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="0"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="3", YAKAMD_LC_FLAT="1"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="6", YAKAMD_BATCH="65536"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="12", YAKAMD_CH2="4096"),
                                  dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="6", YAKAMD_TS_JOIN="3"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="4", YAKAMD_TS_JOIN="2", YAKAMD_TS_CAP="100"), dict(YAKAMD_TSORT="1", YAKAMD_TS_BITS="0", YAKAMD_TS_CAP="64"),
-                                 dict(YAKAMD_POOL_FILL="166"), dict(YAKAMD_POOL_FILL="1", YAKAMD_POOL_VM="0"), dict(YAKAMD_POOL_VM_MIN="1048576", YAKAMD_POOL_FILL="166"), dict(YAKAMD_POOL_VM_MIN="4194304", YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536")],
+                                 dict(YAKAMD_POOL_FILL="166"), dict(YAKAMD_POOL_FILL="1", YAKAMD_POOL_VM="0"), dict(YAKAMD_POOL_VM_MIN="1048576", YAKAMD_POOL_FILL="166"), dict(YAKAMD_POOL_VM_MIN="4194304", YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536"),
+                                 dict(YAKAMD_POOL_VM_MIN="1048576", YAKAMD_POOL_VM_ROOMY="0", YAKAMD_POOL_FILL="90"), dict(YAKAMD_POOL_VM_MIN="2097152", YAKAMD_POOL_VM_ROOMY="0", YAKAMD_FAST_BUDGET="3000000", YAKAMD_BATCH="65536")],
                          ids=["general_path", "lds_overflow_to_global", "budget_exceeded_midpass", "s2_3_multibatch", "part6_general",
                               "write_combined_level2", "write_combined_level2_wide", "write_combined_level2_segments", "plain_scatters",
                               "range_count_whole_table", "range_count_split", "range_count_cross_sweep", "range_count_short_list",
@@ -341,7 +342,8 @@ def test_prefix_sharded_path_on_one_gpu(bf, ya, oracle, synth):
                               "level2_two_sweeps_16k_sub_buckets", "flat_gather", "flat_gather_multibatch", "one_workgroup_per_sub_table_gather",
                               "sort_stable_radix_passes", "sort_bitmap_ranks", "sort_one_bin_per_sub_table", "sort_8_bins_plain_scatter", "sort_64_bins_multibatch", "sort_4096_bins_in_segments",
                               "sort_bins_joined_by_8", "sort_joined_bins_beyond_the_stage", "sort_one_bin_in_windows",
-                              "every_buffer_prefilled_with_0xa5", "every_buffer_zeroed_superblocks_only", "mapped_ranges_from_1_mib_prefilled", "mapped_ranges_from_4_mib_pass_in_slices"])
+                              "every_buffer_prefilled_with_0xa5", "every_buffer_zeroed_superblocks_only", "mapped_ranges_from_1_mib_prefilled", "mapped_ranges_from_4_mib_pass_in_slices",
+                              "mapped_ranges_taken_apart_prefilled", "mapped_ranges_taken_apart_pass_in_slices"])
 def test_every_insert_path_is_exact(env, ya, oracle, synth, monkeypatch, knob):
     """the exclusive-ownership LDS path, its global-scratch overflow variant, the accumulator path
     and the mid-pass switch between them all give the reference bytes"""

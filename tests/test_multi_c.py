@@ -65,6 +65,13 @@ def test_large_unfiltered_plain_files_are_counted_in_sweeps(reads):
         assert open(got, "rb").read() == open(want, "rb").read()
     r = subprocess.run([YAM, "count", "-k21", "-o", got, reads["fa"]], check=True, env=dict(env, YAKAMD_GPUS="1"), stderr=subprocess.PIPE)
     assert b"sweeps over prefix ranges" not in r.stderr
+    # a process that does not own the device memory of the few-sweep plan yet takes more sweeps (YAKAMD_COLD_GB: the estimated peak of a sweep's share
+    # against what the driver hands out without charging); 0 switches that off.  Same bytes either way.
+    subprocess.run([YKO, "count", "-k21", "-o", want, reads["fa"]], check=True, stderr=subprocess.DEVNULL)
+    for cold, n in (("0.000001", b"counting in 16 sweeps"), ("0", b"counting in 2 sweeps")):
+        r = subprocess.run([YAM, "count", "-k21", "-o", got, reads["fa"]], check=True, env=dict(env, YAKAMD_COLD_GB=cold), stderr=subprocess.PIPE)
+        assert n in r.stderr
+        assert open(got, "rb").read() == open(want, "rb").read()
 
 
 def test_a_sequence_longer_than_a_chunk_is_split_with_an_overlap(reads):

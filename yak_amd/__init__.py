@@ -33,7 +33,7 @@ YAK_AMD_H_SYMBOLS = [
     "yakamd_tagged_ok", "yakamd_pass_fast", "yakamd_partition_tagged_dev", "yakamd_feed_partitioned_tagged_dev",
     "yakamd_lookup_dev", "yakamd_qv_reduce_dev", "yakamd_host_image", "yakamd_host_image_packed", "yakamd_gz_tune", "yakamd_gz_inflate", "yakamd_test_set", "yakamd_test_reset",
     "yakamd_retain_input", "yakamd_count_retained", "yakamd_retained_instances", "yakamd_count_multi_dev",
-    "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info", "yakamd_last_sweeps",
+    "yakamd_host_alloc", "yakamd_host_free", "yakamd_device_sync", "yakamd_mem_info", "yakamd_last_sweeps", "yakamd_pool_report",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
     L.yakamd_dump_range_mem.argtypes = [P(ChT), C.c_int, C.c_int, P(P(C.c_uint8))]
     L.yakamd_peak_bytes.restype = C.c_int64; L.yakamd_peak_bytes.argtypes = [C.c_int, C.c_int]
     L.yakamd_last_sweeps.restype = C.c_int; L.yakamd_last_sweeps.argtypes = []
+    L.yakamd_pool_report.restype = None; L.yakamd_pool_report.argtypes = [C.c_char_p]
     L.yakamd_subtable.restype = C.c_int
     L.yakamd_subtable.argtypes = [P(ChT), C.c_int, P(C.c_uint32), P(C.c_uint32)]
     L.yakamd_get_stats.restype = C.c_int; L.yakamd_get_stats.argtypes = [P(ChT), P(StatsT)]

@@ -77,6 +77,7 @@ struct DevPool {
 	std::multimap<size_t, char*> vm_idle_sz;           /* the idle ranges by length */
 	std::vector<hipMemGenericAllocationHandle_t> vm_spare;   /* chunks mapped nowhere */
 	size_t vm_cached = 0, vm_phys = 0, vm_dead_va = 0; /* bytes idle (ranges + spare chunks); bytes of chunks obtained from the driver and not given back; bytes of address space left behind by unmapped ranges */
+	size_t total_mem = 0;                              /* of the device (hipMemGetInfo, once) */
 	bool vm_off = false;                               /* a virtual-memory call failed: large buffers come from superblocks like the small ones */
 	u64 n_vm_new = 0, n_vm_reuse = 0, n_vm_remap = 0, n_vm_create = 0; double ms_vm_map = 0, ms_vm_create = 0;
 };
@@ -129,13 +130,13 @@ static void pool_trim(DevPool &P) { ++P.n_trim; pool_release(P, 0); }
 /* Large buffers: fungible memory.  A superblock that is free but of the wrong size is useless to the next request -- the 5 Gb assembly obtained 329 GB
  * from the driver for 188 GB in use (buffers of 22-90 GB that do not fit the ranges earlier ones left; one out-of-memory trim on the way gave 115 GB
  * back that were then obtained again), and the driver charges ~30 ms per GB beyond the first ~112 GB of a process (tests/tools/mb/mb_malloc.hip).  So a
- * request of VM_MIN bytes or more gets a virtual range of its own, backed by physical chunks of VM_CH bytes (hipMemCreate / hipMemMap).  A freed range
+ * request of VM_MIN (2 GiB) bytes or more gets a virtual range of its own, backed by physical chunks of VM_CH bytes (hipMemCreate / hipMemMap).  A freed range
  * stays mapped (the next request of that size takes it as it is: the steady state of a benchmark's steps costs nothing); a request that finds no idle
  * range of its size takes the chunks of idle ranges, least recently used first, and maps them into a fresh range -- 0.1 ms per GB
  * (tests/tools/mb/mb_vmm.hip: map 5 us per chunk, access 0.02 ms per GB, unmap 0.06 ms per GB; fills and random probes run as on hipMalloc memory) -- and
  * only what is still missing is created.  The driver is asked for the high-water mark of the buffers in use, rounded to chunks, and never for the
  * same memory twice.  YAKAMD_POOL_VM=0 (test switch), or any failing virtual-memory call, sends large buffers to the superblocks instead. */
-static const size_t VM_MIN = (size_t)1 << 30;
+static const size_t VM_MIN = (size_t)2 << 30;        /* (a cfg3 rank takes ~1.1 GB per feed round, 64 times a job, each of another size: those split superblocks at no cost -- 0.519 -> 0.504 s) */
 /* the chunk size is fixed with the first large buffer of the process (test switch YAKAMD_POOL_VM_CH: a multiple of 2 MiB) */
 static size_t vm_ch()
 {
@@ -186,8 +187,16 @@ static void pool_trim(DevPool &P);
 static void *vm_alloc(DevPool &P, size_t bytes)
 {
 	const size_t need = (bytes + VM_CH - 1) / VM_CH * VM_CH, m = need / VM_CH;
+	/* While the pool holds less than YAKAMD_POOL_VM_ROOMY per cent (60) of the device, ranges are not taken apart: a request takes an idle range of up to
+	 * 1.5 x its size as it is, or gets new chunks -- the ranges a repeated job needs settle after its first run and every later request finds one (taking a
+	 * 16 GB range apart for a 12 GB request, and building the 16 GB range again a moment later, cost the default step 5.5 of its 50.7 ms: every unmap
+	 * waits for the device first).  Beyond that the memory is worth more than the mapping: tight fits only, and chunks come from idle ranges */
+	if (P.total_mem == 0) { size_t fr = 0, tt = 0; if (hipMemGetInfo(&fr, &tt) == hipSuccess) P.total_mem = tt; else (void)hipGetLastError(); }
+	size_t held = P.vm_phys;
+	for (auto &kv : P.supers) held += kv.second.size;
+	const bool roomy = P.total_mem && (double)(held + need) <= (double)P.total_mem * (double)yk_knob("YAKAMD_POOL_VM_ROOMY", 60) / 100.0;
 	auto fit = P.vm_idle_sz.lower_bound(need);
-	if (fit != P.vm_idle_sz.end() && fit->first <= need + std::max(need / 8, VM_CH)) {      /* an idle range of about this size, as it is */
+	if (fit != P.vm_idle_sz.end() && fit->first <= need + (roomy ? std::max(need / 2, VM_CH) : std::max(need / 8, VM_CH))) {      /* an idle range of about this size, as it is */
 		char *p = fit->second;
 		auto it = P.vm_idle.find(p);
 		DevPool::VmRange r = std::move(it->second);
@@ -200,7 +209,7 @@ static void *vm_alloc(DevPool &P, size_t bytes)
 	}
 	const double t0 = now_ms();
 	bool remapped = false;
-	while (P.vm_spare.size() < m) { auto it = vm_lru(P); if (it == P.vm_idle.end()) break; vm_unmap_idle(P, it, &remapped); }
+	if (!roomy) while (P.vm_spare.size() < m) { auto it = vm_lru(P); if (it == P.vm_idle.end()) break; vm_unmap_idle(P, it, &remapped); }
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	hipMemAllocationProp prop = {};
@@ -211,7 +220,8 @@ static void *vm_alloc(DevPool &P, size_t bytes)
 		hipMemGenericAllocationHandle_t h;
 		if (hipMemCreate(&h, VM_CH, &prop, 0) != hipSuccess) {
 			(void)hipGetLastError();
-			if (trimmed) return 0;                                  /* the device is full: the chunks gathered so far stay spare */
+			{ auto it = vm_lru(P); if (it != P.vm_idle.end()) { vm_unmap_idle(P, it, &remapped); continue; } }   /* the device is full: idle ranges give their chunks up after all */
+			if (trimmed) return 0;                                  /* nothing left to take: the chunks gathered so far stay spare */
 			pool_trim(P); trimmed = true;                           /* the superblocks' idle memory goes back to the driver first */
 			continue;
 		}
@@ -377,6 +387,8 @@ extern "C" int64_t yakamd_peak_bytes(int dev, int reset)
 	return v;
 }
 extern "C" void yakamd_trim(void) { DevPool &P = pool_here(); std::lock_guard<std::mutex> lk(P.mu); pool_trim(P); vm_release(P, 0); }
+void yk_pool_report(const char *what);
+extern "C" void yakamd_pool_report(const char *what) { yk_pool_report(what ? what : "the call"); }
 void yk_pool_report(const char *what)
 {
 	DevPool &P = pool_here();
