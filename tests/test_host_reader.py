@@ -92,6 +92,34 @@ def test_synthetic_fastq_fasta_and_gzip(oracle, tmp_path):
     assert same(gz, oracle, 31) == a
 
 
+def test_named_pipes_deliver_the_whole_stream(oracle, tmp_path):
+    """`yak count ... <(zcat reads.fq.gz)` (the reference's README) hands yak_count() a pipe by NAME (/dev/fd/NN): every byte must arrive, plain or
+    gzipped, through the reader and through the reference-facing entry point's own image.  (Until round 6 the reader opened a second descriptor
+    on a file zlib had called uncompressed -- behind the buffer zlib had already pulled out of the pipe: the first megabyte of the stream was lost.)"""
+    import threading
+    import yak_amd
+    fq = str(tmp_path / "r.fq")
+    subprocess.check_call([SYN, "-n", "20000", "-l", "150", "-g", "100000", "-s", "5", "-o", fq])      # 6 MB: several of zlib's buffers
+    want = oracle.read_image(fq, 31)
+    gz = str(tmp_path / "r.fq.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(open(fq, "rb").read())
+    fifo = str(tmp_path / "pipe")
+    os.mkfifo(fifo)
+    for src in (fq, gz):
+        for fast in (True, False):
+            def feed():
+                with open(fifo, "wb") as w:
+                    w.write(open(src, "rb").read())
+            t = threading.Thread(target=feed)
+            t.start()
+            try:
+                got = yak_amd.host_image(fifo, 31, fast=fast)
+            finally:
+                t.join()
+            assert got == want, (src, fast)
+
+
 def test_awkward_shapes(oracle, tmp_path):
     rnd = random.Random(11)
 

@@ -167,7 +167,11 @@ struct FxReader {
 		fp = is_stdin ? gzdopen(0, "r") : gzopen(fn, "r");
 		if (fp == 0) return false;
 		gzbuffer(fp, 1 << 20);                               /* zlib's default 8 KB means a read() per 8 KB */
-		if (!is_stdin && gzdirect(fp)) fd = ::open(fn, O_RDONLY);
+		/* plain bytes of a REGULAR file are read directly (no copy through zlib).  Not a FIFO -- `yak count ... <(zcat reads.fq.gz)`, the usual way to
+		 * feed gzipped reads, hands over /dev/fd/NN --: gzdirect() has pulled the first buffer out of the pipe already, a second descriptor would go
+		 * on behind it and the first megabyte of the stream would be lost (until round 6 it was) */
+		struct stat sb_;
+		if (!is_stdin && gzdirect(fp) && stat(fn, &sb_) == 0 && S_ISREG(sb_.st_mode)) fd = ::open(fn, O_RDONLY);
 		buf = (unsigned char*)malloc(BUF);
 		return true;
 	}
