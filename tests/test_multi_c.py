@@ -63,6 +63,10 @@ def test_count_from_named_pipes(reads):
         for src, env in ((f"cat {reads['fq']}", {}), (f"zcat {gz}", {}), (f"cat {reads['fq']}", dict(YAKAMD_GPUS="2", YAKAMD_GPU_LIST="0,0", YAKAMD_MGPU_CHUNK="300000"))):
             subprocess.run(["bash", "-c", f"{YAM} count {args} -o {got} <({src}) <({src})"], check=True, env=dict(os.environ, **env), stderr=subprocess.PIPE)
             assert open(got, "rb").read() == open(want, "rb").read(), (args, src, env)
+    # standard input (count.c:151: gzdopen(0)): redirected from a file, from a pipe, gzipped through a pipe
+    for cmd in (f"{YAM} count -k21 -o {got} - < {reads['fq']}", f"cat {reads['fq']} | {YAM} count -k21 -o {got} -", f"cat {gz} | {YAM} count -k21 -t1 -o {got} -"):
+        subprocess.run(["bash", "-c", cmd], check=True, stderr=subprocess.PIPE)
+        assert open(got, "rb").read() == open(want, "rb").read(), cmd
 
 
 def test_large_unfiltered_plain_files_are_counted_in_sweeps(reads):

@@ -130,13 +130,13 @@ static void pool_trim(DevPool &P) { ++P.n_trim; pool_release(P, 0); }
 /* Large buffers: fungible memory.  A superblock that is free but of the wrong size is useless to the next request -- the 5 Gb assembly obtained 329 GB
  * from the driver for 188 GB in use (buffers of 22-90 GB that do not fit the ranges earlier ones left; one out-of-memory trim on the way gave 115 GB
  * back that were then obtained again), and the driver charges ~30 ms per GB beyond the first ~112 GB of a process (tests/tools/mb/mb_malloc.hip).  So a
- * request of VM_MIN (2 GiB) bytes or more gets a virtual range of its own, backed by physical chunks of VM_CH bytes (hipMemCreate / hipMemMap).  A freed range
+ * request of VM_MIN (1 GiB) bytes or more gets a virtual range of its own, backed by physical chunks of VM_CH bytes (hipMemCreate / hipMemMap).  A freed range
  * stays mapped (the next request of that size takes it as it is: the steady state of a benchmark's steps costs nothing); a request that finds no idle
  * range of its size takes the chunks of idle ranges, least recently used first, and maps them into a fresh range -- 0.1 ms per GB
  * (tests/tools/mb/mb_vmm.hip: map 5 us per chunk, access 0.02 ms per GB, unmap 0.06 ms per GB; fills and random probes run as on hipMalloc memory) -- and
  * only what is still missing is created.  The driver is asked for the high-water mark of the buffers in use, rounded to chunks, and never for the
  * same memory twice.  YAKAMD_POOL_VM=0 (test switch), or any failing virtual-memory call, sends large buffers to the superblocks instead. */
-static const size_t VM_MIN = (size_t)2 << 30;        /* (a cfg3 rank takes ~1.1 GB per feed round, 64 times a job, each of another size: those split superblocks at no cost -- 0.519 -> 0.504 s) */
+static const size_t VM_MIN = (size_t)1 << 30;        /* (2 GiB serves a cfg3 rank 3 % better -- its ~1.1 GB per-round buffers split superblocks at no cost -- and two ranks' jobs on one device twice as badly: near a full device the superblocks of that class are released and obtained over and over, 573 -> 1107 ms; r06_experiments.txt e14) */
 /* the chunk size is fixed with the first large buffer of the process (test switch YAKAMD_POOL_VM_CH: a multiple of 2 MiB) */
 static size_t vm_ch()
 {
