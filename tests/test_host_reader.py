@@ -118,6 +118,33 @@ def test_named_pipes_deliver_the_whole_stream(oracle, tmp_path):
             finally:
                 t.join()
             assert got == want, (src, fast)
+    # a short input whose writer has closed its end before the reader looks at the name a second time: every byte is in the pipe, nobody may open() the
+    # FIFO again (that open would wait for a writer for ever: the parallel routes did so until round 6, for inputs that fit the pipe's buffer).  The reader
+    # runs in a child with a deadline: a blocked open() must fail the test, not hang it
+    import sys
+    tiny = str(tmp_path / "tiny.fq")
+    open(tiny, "wb").write(b"".join(open(fq, "rb").readlines()[:400]))
+    tiny_gz = str(tmp_path / "tiny.fq.gz")
+    with gzip.open(tiny_gz, "wb") as f:
+        f.write(open(tiny, "rb").read())
+    tiny_want = oracle.read_image(tiny, 31)
+    out = str(tmp_path / "tiny.img")
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); import yak_amd; open({out!r}, 'wb').write(yak_amd.host_image({fifo!r}, 31))"
+    for src in (tiny, tiny_gz):
+        for thr in ("1", "4"):
+            def feed():
+                with open(fifo, "wb") as w:
+                    w.write(open(src, "rb").read())
+            pr = subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, YAKAMD_PARSE_THREADS=thr))
+            t = threading.Thread(target=feed)
+            t.start()
+            t.join()
+            try:
+                pr.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                raise AssertionError(("the reader blocked on the FIFO", src, thr))
+            assert pr.returncode == 0 and open(out, "rb").read() == tiny_want, (src, thr)
 
 
 def test_awkward_shapes(oracle, tmp_path):

@@ -584,9 +584,10 @@ struct Reader {
 
 	/* false: not a file this reader takes (not regular, not gzip, too small) -- the caller keeps its gzread() path */
 	bool open(const char *fn, int threads, bool any_size = false) {
+		struct stat sb;
+		if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;   /* (before open(): opening a FIFO whose writer has gone blocks for ever) */
 		fd = ::open(fn, O_RDONLY);
 		if (fd < 0) return false;
-		struct stat sb;
 		if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18 || (!any_size && (size_t)sb.st_size < tune().min_size)) { ::close(fd); fd = -1; return false; }
 		void *m = mmap(0, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
 		if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }

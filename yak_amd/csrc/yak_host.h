@@ -164,8 +164,13 @@ struct FxReader {
 	/* open `fn` (NULL or "-": stdin); a plain (not gzip) regular file is then read with read(2), skipping zlib's copy */
 	bool open_file(const char *fn) {
 		const bool is_stdin = fn == 0 || strcmp(fn, "-") == 0;
-		fp = is_stdin ? gzdopen(0, "r") : gzopen(fn, "r");
-		if (fp == 0) return false;
+		/* (a pipe is asked for 1 MiB of buffer instead of the usual 64 KiB: 1.9 GB/s instead of 1.1 between `cat` and a reader on this kind of host; the
+		 * request fails harmlessly on anything that is no pipe) */
+		const int f0 = is_stdin ? 0 : ::open(fn, O_RDONLY);
+		if (f0 < 0) return false;
+		(void)fcntl(f0, 1031 /* F_SETPIPE_SZ (Linux) */, 1 << 20);
+		fp = gzdopen(f0, "r");
+		if (fp == 0) { if (!is_stdin) ::close(f0); return false; }
 		gzbuffer(fp, 1 << 20);                               /* zlib's default 8 KB means a read() per 8 KB */
 		/* plain bytes of a REGULAR file are read directly (no copy through zlib).  Not a FIFO -- `yak count ... <(zcat reads.fq.gz)`, the usual way to
 		 * feed gzipped reads, hands over /dev/fd/NN --: gzdirect() has pulled the first buffer out of the pipe already, a second descriptor would go

@@ -169,9 +169,10 @@ int auto_sweeps(const yak_copt_t *opt, const char *fn)
 	const double sz = (double)sb.st_size;
 	int N = 1;
 	if (sz > lim) { N = 2; while (N < 16 && sz / N > 2.8e9) N <<= 1; }
+	const double bases = m[0] == '@' ? sz * 0.5 : sz;           /* a FASTQ record spends half of its bytes on the quality line */
 	const char *cg = getenv("YAKAMD_COLD_GB");
 	const double cold = (cg ? atof(cg) : 110.0) * 1e9;
-	auto peak = [&](int n) { return sz * (14.0 + 56.0 / n); };
+	auto peak = [&](int n) { return bases * (14.0 + 56.0 / n); };
 	if (cold > 0 && peak(N) > cold) {
 		int nd = 0, d = 0;
 		if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) { const char *dv = getenv("YAKAMD_DEVICE"), *lr = getenv("LOCAL_RANK"); d = (dv ? atoi(dv) : lr ? atoi(lr) : 0) % nd; }

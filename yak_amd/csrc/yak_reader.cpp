@@ -237,6 +237,7 @@ bool parallel_source(const char *fn, const FxReader &fx, int n_thr, int64_t min_
 		return true;
 	}
 	if (fn == 0 || strcmp(fn, "-") == 0) return false;
+	if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;   /* (never open() a FIFO a second time: with its writer gone -- a short input, all of it in the pipe already -- that open blocks for ever) */
 	const int f = ::open(fn, O_RDONLY);
 	if (f < 0) return false;
 	if (!src->index_bgzf(f) || src->size <= min_size) { ::close(f); src->fd = -1; src->bgzf = false; return false; }
