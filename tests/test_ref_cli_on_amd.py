@@ -60,6 +60,22 @@ def test_count_second_file_for_pass2(files):
     assert a == b
 
 
+def test_count_from_process_substitution(files):
+    """the command line the reference's README gives for gzipped short reads -- `yak count -b.. -o out <(zcat r.fq.gz) <(zcat r.fq.gz)` -- through the
+    whole reference and through its caller files on the library: the pipes arrive by name (/dev/fd/NN), every byte of them must be counted"""
+    gz = os.path.join(files["dir"], "ps.fq.gz")
+    subprocess.run(f"gzip -1 -c {files['fq']} > {gz}", shell=True, check=True)
+    res = []
+    for exe, tag in ((REF, "ref"), (ONAMD, "amd")):
+        out = os.path.join(files["dir"], f"ps.{tag}")
+        subprocess.run(["bash", "-c", f"{exe} count -k31 -b24 -t4 -o {out} <(zcat {gz}) <(zcat {gz})"], check=True, stderr=subprocess.PIPE, timeout=300)
+        res.append(open(out, "rb").read())
+    assert res[0] == res[1] and len(res[0]) > 16 + 8 * 1024
+    # ... and the same bytes as from the file itself
+    a, b = both(["count", "-k31", "-b24", "-o", "@OUT@", files["fq"]], "psf", files)
+    assert a == res[0] == b
+
+
 def test_qv_and_inspect(files):
     tab = both(["count", "-k27", "-b24", "-o", "@OUT@", files["fq"]], "qt", files)
     assert tab[0] == tab[1]
