@@ -74,6 +74,13 @@ def test_count_from_process_substitution(files):
     # ... and the same bytes as from the file itself
     a, b = both(["count", "-k31", "-b24", "-o", "@OUT@", files["fq"]], "psf", files)
     assert a == res[0] == b
+    # yak qv reading its sequences from a pipe as well (qv.c:115: the same gzopen / kseq route)
+    tab = os.path.join(files["dir"], "ps.ref")
+    outs = []
+    for exe in (REF, ONAMD):
+        r = subprocess.run(["bash", "-c", f"{exe} qv -t2 {tab} <(cat {files['fa']})"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        outs.append(sorted(l for l in r.stdout.decode().splitlines() if not l.startswith("CC")))
+    assert outs[0] == outs[1] and any(l.startswith("QV") for l in outs[0])
 
 
 def test_qv_and_inspect(files):
